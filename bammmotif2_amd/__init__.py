@@ -1,0 +1,11 @@
+"""MI355X-native EM refinement hot path of BaMMmotif2.
+
+`csrc/` holds the HIP kernels and the C ABI (include/bamm_em.h); `em.py` mirrors the
+reference's EM / ScoreSeqSet interface over that ABI; `synth.py` makes the benchmark inputs.
+"""
+from . import abi, synth  # noqa: F401
+from .em import (EM, Context, PackedSeqs, SeqSet, calculate_p, logodds, libc_srand,  # noqa: F401
+                 v_size, v_offset, bg_size, bg_offset)
+
+__all__ = ["EM", "Context", "PackedSeqs", "SeqSet", "calculate_p", "logodds", "libc_srand",
+           "v_size", "v_offset", "bg_size", "bg_offset", "abi", "synth"]

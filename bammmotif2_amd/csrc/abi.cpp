@@ -1,0 +1,749 @@
+// Device-side half of the C ABI (include/bamm_em.h): contexts, resident sequence sets, EM
+// handles and the scorer.  Host code only -- kernels live in kernels.hip.
+//
+// Reference seam this replaces: class EM (/root/reference/src/refinement/EM.h:11-69,
+// EM.cpp:7-259,505-527) and ScoreSeqSet::calcLogOdds (seq_scoring/ScoreSeqSet.cpp:25-67).
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "common.h"
+
+using namespace bamm;
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    BAMM_HIP(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
+    return BAMM_OK;
+}
+
+template <class T>
+int dev_upload(T** p, const T* host, size_t count, hipStream_t st) {
+    int rc = dev_alloc(p, count);
+    if (rc) return rc;
+    if (count) BAMM_HIP(hipMemcpyAsync(*p, host, count * sizeof(T), hipMemcpyHostToDevice, st));
+    return BAMM_OK;
+}
+
+struct Bucket {
+    int mclass = 0;
+    uint32_t count = 0;
+    uint32_t* d_idx = nullptr;   // nullptr: all sequences in natural order
+    double work = 0;             // sum of M over the bucket (LDS instruction proxy)
+};
+
+struct ExcK {                    // exceptions relevant at one model order
+    uint64_t* d_off = nullptr;
+    uint2* d_exc = nullptr;
+    uint64_t count = 0;
+};
+
+}  // namespace
+
+struct bamm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint32_t blocks = 0, threads = 0;   // 0 = default
+    int num_cus = 0;
+    std::string name;
+};
+
+struct bamm_seqs {
+    bamm_ctx* ctx = nullptr;
+    int refs = 1;
+    uint64_t n = 0, total_len = 0;
+    uint32_t max_len = 0, min_len = 0;
+    uint64_t hbm_bytes = 0;
+    uint32_t* d_words = nullptr;
+    uint64_t* d_word_off = nullptr;
+    uint32_t* d_len = nullptr;
+    uint64_t* d_pos_off = nullptr;
+    std::vector<uint32_t> h_len;
+    std::vector<uint64_t> h_pos_off;
+    std::vector<uint64_t> h_exc_off;            // full (11-mer level) exception list
+    std::vector<uint32_t> h_exc_pos, h_exc_kmer, h_exc_clean;
+    std::vector<Bucket> buckets;
+    std::map<uint32_t, ExcK> exc_by_order;
+};
+
+struct bamm_em {
+    bamm_ctx* ctx = nullptr;
+    bamm_seqs* seqs = nullptr;
+    bamm_em_params prm{};
+    uint32_t Y = 0, Kbg = 0;
+    size_t vsz = 0, cells = 0;
+    float *d_vbg = nullptr, *d_A = nullptr, *d_v = nullptr, *d_n = nullptr, *d_s = nullptr;
+    float *d_q = nullptr, *d_status = nullptr, *d_trace = nullptr;
+    uint32_t* d_iteration = nullptr;
+    uint8_t* d_mask = nullptr;
+    double* d_red = nullptr;
+    float* d_partial_n = nullptr;
+    double* d_partial_stat = nullptr;
+    float* h_status = nullptr;                  // pinned, 8 floats
+    uint32_t total_blocks = 0;
+    std::vector<uint32_t> bucket_blocks;
+    uint32_t threads = 0;
+    const ExcK* exc = nullptr;
+    bool estep_done = false;
+    float llh_prev = 0.0f;                      // EM.h:61
+    uint32_t host_iteration = 0;
+    bamm_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    uint32_t events_used = 0;
+};
+
+namespace {
+
+SeqView make_view(const bamm_seqs* s, const ExcK* exc, const Bucket& b, const uint8_t* d_mask) {
+    SeqView v;
+    v.words = s->d_words;
+    v.word_off = s->d_word_off;
+    v.len = s->d_len;
+    v.pos_off = s->d_pos_off;
+    v.exc_off = exc->d_off;
+    v.exc = exc->d_exc;
+    v.mask = d_mask;
+    v.idx = b.d_idx;
+    v.count = b.count;
+    return v;
+}
+
+// build (once per order) the list of positions whose kmer_ mod 4^(K+1) differs from what the
+// 2-bit stream gives
+int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
+    auto it = s->exc_by_order.find(K);
+    if (it != s->exc_by_order.end()) { *out = &it->second; return BAMM_OK; }
+    const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
+    std::vector<uint64_t> off(s->n + 1, 0);
+    std::vector<uint2> ex;
+    for (uint64_t n = 0; n < s->n; n++) {
+        off[n] = ex.size();
+        for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
+            if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
+                ex.push_back(make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY));
+    }
+    off[s->n] = ex.size();
+    ExcK k;
+    k.count = ex.size();
+    int rc = dev_upload(&k.d_off, off.data(), off.size(), s->ctx->stream);
+    if (rc) return rc;
+    rc = dev_upload(&k.d_exc, ex.data(), ex.size(), s->ctx->stream);
+    if (rc) return rc;
+    BAMM_HIP(hipStreamSynchronize(s->ctx->stream));   // host vectors go out of scope
+    auto ins = s->exc_by_order.emplace(K, k);
+    *out = &ins.first->second;
+    return BAMM_OK;
+}
+
+uint32_t default_threads(const bamm_ctx* c, int mclass) {
+    uint32_t t = c->threads ? c->threads : max_threads_for_mclass(mclass);
+    return std::min(t, max_threads_for_mclass(mclass));
+}
+
+uint32_t default_blocks(const bamm_ctx* c, uint32_t threads) {
+    if (c->blocks) return c->blocks;
+    const uint32_t cus = c->num_cus > 0 ? (uint32_t)c->num_cus : 256u;
+    return cus * std::max(1u, 2048u / threads);       // fill 32 waves per CU
+}
+
+int record_event(bamm_em* em, bool start) {
+    if (start) {
+        if (em->events_used == em->events.size()) {
+            hipEvent_t a, b;
+            BAMM_HIP(hipEventCreate(&a));
+            BAMM_HIP(hipEventCreate(&b));
+            em->events.emplace_back(a, b);
+        }
+        BAMM_HIP(hipEventRecord(em->events[em->events_used].first, em->ctx->stream));
+    } else {
+        BAMM_HIP(hipEventRecord(em->events[em->events_used].second, em->ctx->stream));
+        em->events_used++;
+    }
+    return BAMM_OK;
+}
+
+// local E(+M) pass over every length bucket, then the deterministic partial reduction
+int run_accumulate(bamm_em* em, bool accum) {
+    bamm_seqs* s = em->seqs;
+    hipStream_t st = em->ctx->stream;
+    int rc = record_event(em, true);
+    if (rc) return rc;
+    uint32_t block_base = 0;
+    for (size_t b = 0; b < s->buckets.size(); b++) {
+        const Bucket& bk = s->buckets[b];
+        EmKernelArgs a{};
+        a.sv = make_view(s, em->exc, bk, em->d_mask);
+        a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
+        a.s = em->d_s; a.q = em->d_q;
+        a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
+        a.partial_stat = em->d_partial_stat + (size_t)block_base * 4;
+        a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
+        rc = launch_em_seq(bk.mclass, accum, false, a, em->bucket_blocks[b],
+                           default_threads(em->ctx, bk.mclass), st);
+        if (rc) return rc;
+        block_base += em->bucket_blocks[b];
+    }
+    rc = record_event(em, false);
+    if (rc) return rc;
+    if (em->total_blocks == 0) {
+        BAMM_HIP(hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), st));
+        return BAMM_OK;
+    }
+    return launch_reduce_partials(accum ? em->d_partial_n : nullptr, em->d_partial_stat, em->total_blocks,
+                                  em->prm.W, em->Y, em->d_red, st);
+}
+
+int run_allreduce(bamm_em* em) {
+    if (!em->allreduce) return BAMM_OK;
+    int rc = em->allreduce(em->allreduce_user, em->d_red, em->cells + 3, (void*)em->ctx->stream);
+    if (rc != 0) {
+        set_error("all-reduce callback failed with %d", rc);
+        return BAMM_ERR_COMM;
+    }
+    return BAMM_OK;
+}
+
+int run_update(bamm_em* em) {
+    UpdateArgs u{};
+    u.K = em->prm.K; u.W = em->prm.W; u.Kbg = em->Kbg;
+    u.red = em->d_red; u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s;
+    u.q = em->d_q; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
+    u.iteration = em->d_iteration; u.optimize_q = em->prm.optimize_q;
+    u.n_seqs_override = (double)em->prm.n_seqs_global;
+    int rc = launch_update(u, em->ctx->stream);
+    if (rc) return rc;
+    em->host_iteration++;
+    em->estep_done = false;
+    return BAMM_OK;
+}
+
+int fetch_status(bamm_em* em) {
+    BAMM_HIP(hipMemcpyAsync(em->h_status, em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
+    BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
+    return BAMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------ context ----
+int bamm_ctx_create(int device, void* hip_stream, bamm_ctx** out) {
+    if (!out) { set_error("bamm_ctx_create: null out"); return BAMM_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device visible: the gfx950 extension cannot run (there is no CPU fallback)");
+        return BAMM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) {
+        set_error("device %d out of range (0..%d)", device, count - 1);
+        return BAMM_ERR_ARG;
+    }
+    BAMM_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BAMM_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error("device %d is %s; this library only carries gfx950 code objects", device, prop.gcnArchName);
+        return BAMM_ERR_NO_DEVICE;
+    }
+    bamm_ctx* c = new bamm_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    c->name = prop.name;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            delete c;
+            return BAMM_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return BAMM_OK;
+}
+
+int bamm_ctx_destroy(bamm_ctx* c) {
+    if (!c) return BAMM_OK;
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return BAMM_OK;
+}
+
+int bamm_ctx_sync(bamm_ctx* c) {
+    if (!c) { set_error("null ctx"); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipStreamSynchronize(c->stream));
+    return BAMM_OK;
+}
+
+int bamm_ctx_device_name(bamm_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || !cap) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    snprintf(buf, cap, "%s", c->name.c_str());
+    return BAMM_OK;
+}
+
+int bamm_ctx_set_launch(bamm_ctx* c, uint32_t blocks, uint32_t threads) {
+    if (!c || (threads & 63u) || threads > 1024u) { set_error("threads must be a multiple of 64 <= 1024"); return BAMM_ERR_ARG; }
+    c->blocks = blocks;
+    c->threads = threads;
+    return BAMM_OK;
+}
+
+// ------------------------------------------------------------------------------ sequences --
+int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t end, bamm_seqs** out) {
+    if (!c || !p || !out || begin > end || end > p->n_seqs) {
+        set_error("bamm_seqs_upload: bad argument");
+        return BAMM_ERR_ARG;
+    }
+    if (end - begin > 0xfffffff0ull) { set_error("more than 2^32 sequences per device"); return BAMM_ERR_UNSUPPORTED; }
+    BAMM_HIP(hipSetDevice(c->device));
+    std::unique_ptr<bamm_seqs> s(new bamm_seqs());
+    s->ctx = c;
+    s->n = end - begin;
+    const uint64_t w0 = p->word_off[begin], w1 = p->word_off[end];
+    std::vector<uint64_t> woff(s->n + 1);
+    s->h_len.assign(p->len + begin, p->len + end);
+    s->h_pos_off.resize(s->n + 1);
+    s->h_exc_off.resize(s->n + 1);
+    const uint64_t e0 = p->exc_off[begin], e1 = p->exc_off[end];
+    uint64_t pos = 0;
+    s->min_len = s->n ? UINT32_MAX : 0;
+    for (uint64_t n = 0; n < s->n; n++) {
+        woff[n] = p->word_off[begin + n] - w0;
+        s->h_pos_off[n] = pos;
+        s->h_exc_off[n] = p->exc_off[begin + n] - e0;
+        pos += s->h_len[n];
+        s->max_len = std::max(s->max_len, s->h_len[n]);
+        s->min_len = std::min(s->min_len, s->h_len[n]);
+    }
+    woff[s->n] = w1 - w0;
+    s->h_pos_off[s->n] = pos;
+    s->h_exc_off[s->n] = e1 - e0;
+    s->total_len = pos;
+    s->h_exc_pos.assign(p->exc_pos + e0, p->exc_pos + e1);
+    s->h_exc_kmer.assign(p->exc_kmer + e0, p->exc_kmer + e1);
+    s->h_exc_clean.assign(p->exc_clean + e0, p->exc_clean + e1);
+
+    // length buckets: one kernel instantiation per positions-per-lane class
+    std::vector<std::vector<uint32_t>> members(kNumMClasses);
+    for (uint64_t n = 0; n < s->n; n++) {
+        int mc = m_class_for_len(s->h_len[n]);
+        if (mc < 0) {
+            set_error("sequence %llu has %u positions; the kernels cover L <= %d (incl. reverse complement)",
+                      (unsigned long long)(begin + n), s->h_len[n], 64 * kMClasses[kNumMClasses - 1]);
+            return BAMM_ERR_UNSUPPORTED;
+        }
+        members[mc].push_back((uint32_t)n);
+    }
+    int rc;
+    if ((rc = dev_upload(&s->d_words, p->words + w0, w1 - w0, c->stream))) return rc;
+    if ((rc = dev_upload(&s->d_word_off, woff.data(), woff.size(), c->stream))) return rc;
+    if ((rc = dev_upload(&s->d_len, s->h_len.data(), s->h_len.size(), c->stream))) return rc;
+    if ((rc = dev_upload(&s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size(), c->stream))) return rc;
+    int used = 0;
+    for (int mc = 0; mc < kNumMClasses; mc++) used += !members[mc].empty();
+    for (int mc = 0; mc < kNumMClasses; mc++) {
+        if (members[mc].empty()) continue;
+        Bucket b;
+        b.mclass = mc;
+        b.count = (uint32_t)members[mc].size();
+        b.work = (double)b.count * kMClasses[mc];
+        if (used > 1)
+            if ((rc = dev_upload(&b.d_idx, members[mc].data(), members[mc].size(), c->stream))) return rc;
+        s->buckets.push_back(b);
+    }
+    BAMM_HIP(hipStreamSynchronize(c->stream));
+    s->hbm_bytes = (w1 - w0) * 4 + (s->n + 1) * 8 * 2 + s->n * 4;
+    *out = s.release();
+    return BAMM_OK;
+}
+
+int bamm_seqs_destroy(bamm_seqs* s) {
+    if (!s) return BAMM_OK;
+    if (--s->refs > 0) return BAMM_OK;
+    (void)hipFree(s->d_words);
+    (void)hipFree(s->d_word_off);
+    (void)hipFree(s->d_len);
+    (void)hipFree(s->d_pos_off);
+    for (auto& b : s->buckets) (void)hipFree(b.d_idx);
+    for (auto& kv : s->exc_by_order) { (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc); }
+    delete s;
+    return BAMM_OK;
+}
+
+int bamm_seqs_info(const bamm_seqs* s, uint64_t* n_seqs, uint64_t* total_len, uint32_t* max_len, uint64_t* hbm_bytes) {
+    if (!s) { set_error("null seqs"); return BAMM_ERR_ARG; }
+    if (n_seqs) *n_seqs = s->n;
+    if (total_len) *total_len = s->total_len;
+    if (max_len) *max_len = s->max_len;
+    if (hbm_bytes) *hbm_bytes = s->hbm_bytes;
+    return BAMM_OK;
+}
+
+// ------------------------------------------------------------------------------ EM ---------
+int bamm_em_destroy(bamm_em* em) {
+    if (!em) return BAMM_OK;
+    (void)hipStreamSynchronize(em->ctx->stream);
+    for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_q,
+                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_red,
+                    (void*)em->d_partial_n, (void*)em->d_partial_stat})
+        (void)hipFree(p);
+    if (em->h_status) (void)hipHostFree(em->h_status);
+    for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    bamm_seqs_destroy(em->seqs);
+    delete em;
+    return BAMM_OK;
+}
+
+int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, const float* vbg, const float* A,
+                   const float* v_init, const uint8_t* seq_mask, bamm_em** out) {
+    if (!c || !seqs || !prm || !vbg || !A || !v_init || !out) { set_error("bamm_em_create: null argument"); return BAMM_ERR_ARG; }
+    *out = nullptr;
+    if (seqs->ctx != c) { set_error("sequence set belongs to another context"); return BAMM_ERR_ARG; }
+    if (prm->K > BAMM_MAX_ORDER) { set_error("order %u > %d (kmer_ spans 11 bases)", prm->K, BAMM_MAX_ORDER); return BAMM_ERR_ARG; }
+    if (prm->W == 0) { set_error("motif width 0"); return BAMM_ERR_ARG; }
+    if (seqs->n && seqs->min_len < prm->W) {
+        set_error("a sequence of length %u is shorter than the motif (W=%u); the reference drops those before EM (mainBaMM.cpp:75-83)",
+                  seqs->min_len, prm->W);
+        return BAMM_ERR_ARG;
+    }
+    const uint32_t Y = (uint32_t)ipow4(prm->K + 1);
+    if (em_lds_bytes(prm->W, Y, true) > 160 * 1024) {
+        set_error("K=%u W=%u needs %zu bytes of LDS for the fused E+M tables (> 160 KiB): outside this build's envelope",
+                  prm->K, prm->W, em_lds_bytes(prm->W, Y, true));
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipSetDevice(c->device));
+    bamm_em* em = new bamm_em();
+    em->ctx = c;
+    em->seqs = seqs;
+    seqs->refs++;
+    em->prm = *prm;
+    if (em->prm.max_iterations == 0) em->prm.max_iterations = 1000;
+    em->Y = Y;
+    em->Kbg = std::min(prm->bg_order, prm->K);           // EM.cpp:23
+    em->vsz = v_size(prm->K, prm->W);
+    em->cells = (size_t)Y * prm->W;
+    hipStream_t st = c->stream;
+    int rc = BAMM_OK;
+    auto fail = [&](int code) { bamm_em_destroy(em); return code; };
+    if ((rc = exceptions_for_order(seqs, prm->K, &em->exc))) return fail(rc);
+    if ((rc = dev_upload(&em->d_vbg, vbg, bg_size(prm->bg_order), st))) return fail(rc);
+    if ((rc = dev_upload(&em->d_A, A, (size_t)(prm->K + 1) * prm->W, st))) return fail(rc);
+    if ((rc = dev_upload(&em->d_v, v_init, em->vsz, st))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_n, em->vsz))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_s, (size_t)prm->W * (Y + 1)))) return fail(rc);
+    if ((rc = dev_upload(&em->d_q, &prm->q, 1, st))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_status, 8))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_trace, (size_t)em->prm.max_iterations * 3))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_iteration, 1))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_red, em->cells + 3))) return fail(rc);
+    if (hipMemsetAsync(em->d_n, 0, em->vsz * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(em->d_status, 0, 8 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(em->d_iteration, 0, sizeof(uint32_t), st) != hipSuccess ||
+        hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), st) != hipSuccess) {
+        set_error("hipMemsetAsync failed");
+        return fail(BAMM_ERR_HIP);
+    }
+    if (seq_mask && seqs->n)
+        if ((rc = dev_upload(&em->d_mask, seq_mask, seqs->n, st))) return fail(rc);
+    if (hipHostMalloc((void**)&em->h_status, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        set_error("hipHostMalloc failed");
+        return fail(BAMM_ERR_HIP);
+    }
+    memset(em->h_status, 0, 8 * sizeof(float));
+    // launch geometry: blocks split over the length buckets in proportion to their work
+    double total_work = 0;
+    for (auto& b : seqs->buckets) total_work += b.work;
+    em->total_blocks = 0;
+    for (auto& b : seqs->buckets) {
+        const uint32_t threads = default_threads(c, b.mclass);
+        const uint32_t all = default_blocks(c, threads);
+        uint32_t nb = (uint32_t)std::max(1.0, std::floor(all * (b.work / total_work) + 0.5));
+        const uint32_t waves_per_block = threads / 64u;
+        nb = std::min(nb, (b.count + waves_per_block - 1) / waves_per_block);
+        nb = std::max(nb, 1u);
+        em->bucket_blocks.push_back(nb);
+        em->total_blocks += nb;
+    }
+    if ((rc = dev_alloc(&em->d_partial_n, (size_t)em->total_blocks * em->cells))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_partial_stat, (size_t)em->total_blocks * 4))) return fail(rc);
+    if ((rc = launch_make_s(em->d_v, em->d_vbg, prm->K, prm->W, em->Kbg, em->d_s, st))) return fail(rc);
+    if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream sync failed in bamm_em_create"); return fail(BAMM_ERR_HIP); }
+    *out = em;
+    return BAMM_OK;
+}
+
+int bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    em->allreduce = fn;
+    em->allreduce_user = user;
+    return BAMM_OK;
+}
+
+int bamm_em_estep(bamm_em* em) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    // s already reflects the current v (made at create / by the last update): E only
+    int rc = run_accumulate(em, false);
+    if (rc) return rc;
+    if ((rc = run_allreduce(em))) return rc;
+    if ((rc = launch_stat_only(em->d_red, (uint32_t)em->cells, em->d_status, em->ctx->stream))) return rc;
+    em->estep_done = true;
+    return BAMM_OK;
+}
+
+int bamm_em_mstep(bamm_em* em) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (!em->estep_done) { set_error("MStep needs the responsibilities of a preceding EStep"); return BAMM_ERR_STATE; }
+    // the responsibilities are a pure function of (s, q), both unchanged since the EStep:
+    // recompute them on the fly while accumulating counts instead of storing N*L floats
+    const int32_t oq = em->prm.optimize_q;
+    em->prm.optimize_q = 0;                           // EM::MStep never touches q
+    int rc = run_accumulate(em, true);
+    if (!rc) rc = run_allreduce(em);
+    if (!rc) rc = run_update(em);
+    em->prm.optimize_q = oq;
+    return rc;
+}
+
+int bamm_em_optimize_q(bamm_em* em) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    int rc = fetch_status(em);
+    if (rc) return rc;
+    const double nseq = em->prm.n_seqs_global ? (double)em->prm.n_seqs_global : (double)em->h_status[5];
+    const float q = (float)((nseq - (double)em->h_status[4] + 1.0) / (nseq + 2.0));   // EM.cpp:515
+    BAMM_HIP(hipMemcpyAsync(em->d_q, &q, sizeof(float), hipMemcpyHostToDevice, em->ctx->stream));
+    BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
+    return BAMM_OK;
+}
+
+int bamm_em_accumulate(bamm_em* em) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    return run_accumulate(em, true);
+}
+
+int bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_doubles) {
+    if (!em || !dev_ptr || !n_doubles) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    *dev_ptr = em->d_red;
+    *n_doubles = em->cells + 3;
+    return BAMM_OK;
+}
+
+int bamm_em_update(bamm_em* em) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    return run_update(em);
+}
+
+int bamm_em_iterate(bamm_em* em, uint32_t n) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    em->events_used = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        int rc = run_accumulate(em, true);
+        if (!rc) rc = run_allreduce(em);
+        if (!rc) rc = run_update(em);
+        if (rc) return rc;
+    }
+    return BAMM_OK;
+}
+
+int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    em->events_used = 0;
+    bool iterate = true;
+    uint32_t iteration = 0;
+    float llh = em->llh_prev;
+    while (iterate && iteration < em->prm.max_iterations) {     // EM.cpp:81
+        iteration++;
+        const float llh_prev = llh;
+        int rc = run_accumulate(em, true);
+        if (!rc) rc = run_allreduce(em);
+        if (!rc) rc = run_update(em);
+        if (!rc) rc = fetch_status(em);
+        if (rc) return rc;
+        llh = em->h_status[0];
+        const float v_diff = em->h_status[1];
+        if (v_diff < em->prm.epsilon) iterate = false;                     // EM.cpp:117
+        if (llh - llh_prev < 0 && iteration > 10) iterate = false;         // EM.cpp:118
+    }
+    em->llh_prev = llh;
+    if (iterations) *iterations = iteration;
+    return BAMM_OK;
+}
+
+static int copy_out(bamm_em* em, float* dst, const float* src, size_t count) {
+    if (!em || !dst) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
+    BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
+    return BAMM_OK;
+}
+
+int bamm_em_get_v(bamm_em* em, float* v) { return copy_out(em, v, em ? em->d_v : nullptr, em ? em->vsz : 0); }
+int bamm_em_get_counts(bamm_em* em, float* n) { return copy_out(em, n, em ? em->d_n : nullptr, em ? em->vsz : 0); }
+
+int bamm_em_get_s(bamm_em* em, float* s) {
+    if (!em || !s) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    const size_t Ys = em->Y + 1;
+    std::vector<float> tmp((size_t)em->prm.W * Ys);
+    int rc = copy_out(em, tmp.data(), em->d_s, tmp.size());
+    if (rc) return rc;
+    for (uint32_t y = 0; y < em->Y; y++)
+        for (uint32_t j = 0; j < em->prm.W; j++) s[(size_t)y * em->prm.W + j] = tmp[(size_t)j * Ys + y];
+    return BAMM_OK;
+}
+
+int bamm_em_get_q(bamm_em* em, float* q) { return copy_out(em, q, em ? em->d_q : nullptr, 1); }
+
+int bamm_em_get_llh(bamm_em* em, float* llh) {
+    if (!em || !llh) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    int rc = fetch_status(em);
+    if (rc) return rc;
+    *llh = em->h_status[0];
+    return BAMM_OK;
+}
+
+int bamm_em_get_vdiff(bamm_em* em, float* vd) {
+    if (!em || !vd) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    int rc = fetch_status(em);
+    if (rc) return rc;
+    *vd = em->h_status[1];
+    return BAMM_OK;
+}
+
+int bamm_em_get_iteration(bamm_em* em, uint32_t* it) {
+    if (!em || !it) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    *it = em->host_iteration;
+    return BAMM_OK;
+}
+
+int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_t out_cap) {
+    if (!em || !out || begin > end || end > em->seqs->n) { set_error("bamm_em_get_r: bad range"); return BAMM_ERR_ARG; }
+    bamm_seqs* s = em->seqs;
+    const uint64_t base = s->h_pos_off[begin], total = s->h_pos_off[end] - base;
+    if (out_cap < total) { set_error("bamm_em_get_r: output holds %llu floats, %llu needed", (unsigned long long)out_cap, (unsigned long long)total); return BAMM_ERR_ARG; }
+    if (total == 0) return BAMM_OK;
+    hipStream_t st = em->ctx->stream;
+    float* d_r = nullptr;
+    int rc = dev_alloc(&d_r, total);
+    if (rc) return rc;
+    double* d_stat = nullptr;
+    BAMM_HIP(hipMemsetAsync(d_r, 0, total * sizeof(float), st));
+    uint32_t maxb = 0;
+    for (uint32_t nb : em->bucket_blocks) maxb = std::max(maxb, nb);
+    if ((rc = dev_alloc(&d_stat, (size_t)maxb * 4))) { (void)hipFree(d_r); return rc; }
+    for (size_t b = 0; b < s->buckets.size() && !rc; b++) {
+        const Bucket& bk = s->buckets[b];
+        EmKernelArgs a{};
+        a.sv = make_view(s, em->exc, bk, nullptr);        // masked-out sequences still have an r in the reference
+        a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
+        a.s = em->d_s; a.q = em->d_q;
+        a.partial_n = nullptr; a.partial_stat = d_stat;
+        a.r_out = d_r; a.r_base = base; a.seq_begin = (uint32_t)begin; a.seq_end = (uint32_t)end;
+        rc = launch_em_seq(bk.mclass, false, true, a, em->bucket_blocks[b], default_threads(em->ctx, bk.mclass), st);
+    }
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(out, d_r, total * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("copy of r failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
+    }
+    (void)hipFree(d_r);
+    (void)hipFree(d_stat);
+    return rc;
+}
+
+int bamm_em_get_trace(bamm_em* em, float* llh, float* v_diff, float* q, uint32_t cap, uint32_t* n) {
+    if (!em || !n) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    const uint32_t avail = std::min(em->host_iteration, em->prm.max_iterations);
+    *n = avail;
+    const uint32_t m = std::min(avail, cap);
+    if (m == 0) return BAMM_OK;
+    std::vector<float> tmp((size_t)m * 3);
+    int rc = copy_out(em, tmp.data(), em->d_trace, tmp.size());
+    if (rc) return rc;
+    for (uint32_t i = 0; i < m; i++) {
+        if (llh) llh[i] = tmp[(size_t)i * 3 + 0];
+        if (v_diff) v_diff[i] = tmp[(size_t)i * 3 + 1];
+        if (q) q[i] = tmp[(size_t)i * 3 + 2];
+    }
+    return BAMM_OK;
+}
+
+int bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches) {
+    if (!em || !total_ms || !launches) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
+    float acc = 0.0f;
+    for (uint32_t i = 0; i < em->events_used; i++) {
+        float ms = 0.0f;
+        BAMM_HIP(hipEventElapsedTime(&ms, em->events[i].first, em->events[i].second));
+        acc += ms;
+    }
+    *total_ms = acc;
+    *launches = em->events_used;
+    return BAMM_OK;
+}
+
+// ------------------------------------------------------------------------------ scorer -----
+int bamm_logodds(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, uint32_t bg_order, const float* v, const float* vbg,
+                 float* mops, uint64_t mops_cap, float* zoops, uint64_t* z) {
+    if (!c || !s || !v || !vbg || !zoops || !z) { set_error("bamm_logodds: null argument"); return BAMM_ERR_ARG; }
+    if (K > BAMM_MAX_ORDER || W == 0) { set_error("bamm_logodds: bad K/W"); return BAMM_ERR_ARG; }
+    if (s->n && s->min_len < W) { set_error("a sequence is shorter than the motif (W=%u)", W); return BAMM_ERR_ARG; }
+    if (s->n == 0) return BAMM_OK;
+    BAMM_HIP(hipSetDevice(c->device));
+    const uint32_t Y = (uint32_t)ipow4(K + 1), Ys = Y + 1, Kbg = std::min(bg_order, K);
+    const uint32_t Yb = (uint32_t)ipow4(Kbg + 1);
+    // Motif::calculateLogS (Motif.cpp:471-483) with the host's logf, laid out [j][y] + neutral row
+    std::vector<float> tab((size_t)W * Ys, 0.0f);
+    const float* vK = v + v_offset(K, W);
+    const float* b = vbg + bg_offset(Kbg);
+    for (uint32_t y = 0; y < Y; y++)
+        for (uint32_t j = 0; j < W; j++)
+            tab[(size_t)j * Ys + y] = logf(vK[(size_t)y * W + j] + 1e-5f) - logf(b[y % Yb]);
+    std::vector<uint64_t> moff(s->n + 1, 0);
+    for (uint64_t n = 0; n < s->n; n++) moff[n + 1] = moff[n] + (s->h_len[n] - W + 1);
+    if (mops && mops_cap < moff[s->n]) { set_error("mops buffer too small"); return BAMM_ERR_ARG; }
+    hipStream_t st = c->stream;
+    const ExcK* exc = nullptr;
+    int rc = exceptions_for_order(s, K, &exc);
+    if (rc) return rc;
+    float *d_tab = nullptr, *d_mops = nullptr, *d_zoops = nullptr;
+    uint64_t* d_moff = nullptr;
+    uint32_t* d_z = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_tab); (void)hipFree(d_mops); (void)hipFree(d_zoops); (void)hipFree(d_moff); (void)hipFree(d_z); };
+    if ((rc = dev_upload(&d_tab, tab.data(), tab.size(), st)) || (rc = dev_upload(&d_moff, moff.data(), moff.size(), st)) ||
+        (rc = dev_alloc(&d_zoops, s->n)) || (rc = dev_alloc(&d_z, s->n)) || (mops && (rc = dev_alloc(&d_mops, moff[s->n])))) {
+        cleanup();
+        return rc;
+    }
+    for (size_t bi = 0; bi < s->buckets.size() && !rc; bi++) {
+        const Bucket& bk = s->buckets[bi];
+        ScoreKernelArgs a{};
+        a.sv = make_view(s, exc, bk, nullptr);
+        a.K = K; a.W = W; a.Y = Y; a.s = d_tab; a.mops = d_mops; a.mops_off = d_moff; a.zoops = d_zoops; a.z = d_z;
+        const uint32_t threads = default_threads(c, bk.mclass);
+        uint32_t blocks = default_blocks(c, threads);
+        blocks = std::max(1u, std::min(blocks, (bk.count + threads / 64u - 1) / (threads / 64u)));
+        rc = launch_score(bk.mclass, a, blocks, threads, st);
+    }
+    std::vector<uint32_t> hz(s->n);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(zoops, d_zoops, s->n * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(hz.data(), d_z, s->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && mops) e = hipMemcpyAsync(mops, d_mops, moff[s->n] * sizeof(float), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("bamm_logodds: copy failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
+    }
+    if (!rc) for (uint64_t n = 0; n < s->n; n++) z[n] = hz[n];
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared declarations of the gfx950 EM hot path (host side of the C ABI + kernel launchers).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bamm_em.h"
+
+namespace bamm {
+
+void set_error(const char* fmt, ...);
+
+#define BAMM_HIP(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            ::bamm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                              __LINE__);                                                      \
+            return BAMM_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+inline size_t ipow4(size_t e) { return size_t(1) << (2 * e); }
+inline size_t v_offset(size_t k, size_t W) { return W * ((ipow4(k + 1) - 4) / 3); }
+inline size_t v_size(size_t K, size_t W) { return v_offset(K + 1, W); }
+inline size_t bg_offset(size_t k) { return (ipow4(k + 1) - 4) / 3; }
+inline size_t bg_size(size_t K) { return bg_offset(K + 1); }
+
+// positions-per-lane classes the sequence kernels are instantiated for (L <= 64*M)
+constexpr int kNumMClasses = 16;
+extern const int kMClasses[kNumMClasses];
+int m_class_for_len(uint32_t L);  // index into kMClasses, or -1 when L > 64*32
+
+// ---------------------------------------------------------------- device views ----------
+struct SeqView {                 // one length bucket of a resident sequence set
+    const uint32_t* words;       // 2-bit stream, 16 positions / word, big-endian in word
+    const uint64_t* word_off;    // [N+1]
+    const uint32_t* len;         // [N]
+    const uint64_t* pos_off;     // [N+1] prefix sum of len (layout of r)
+    const uint64_t* exc_off;     // [N+1] exceptions relevant at this order
+    const uint2*    exc;         // (position, y value)
+    const uint8_t*  mask;        // nullable
+    const uint32_t* idx;         // nullable: sequence ids of this bucket
+    uint32_t        count;       // sequences in this bucket
+};
+
+struct EmKernelArgs {
+    SeqView  sv;
+    uint32_t K, W, Y;            // Y = 4^(K+1)
+    const float* s;              // device, [W][Y+1], last row entry = neutral element
+    const float* q;              // device scalar
+    float*   partial_n;          // [blocks][W*Y] in [j][y] order (this launch's slice)
+    double*  partial_stat;       // [blocks][4]: llh, sum_r, n_seqs, unused
+    float*   r_out;              // nullable (WRITE_R): reference layout, r_base subtracted
+    uint64_t r_base;             // pos_off of the first requested sequence
+    uint32_t seq_begin, seq_end; // WRITE_R range filter (sequence ids)
+};
+
+struct ScoreKernelArgs {
+    SeqView  sv;
+    uint32_t K, W, Y;
+    const float* s;              // device log-odds table [W][Y+1], pad = 0
+    float*   mops;               // nullable, concatenated L-W+1 per sequence
+    const uint64_t* mops_off;    // [N+1]
+    float*   zoops;              // [N]
+    uint32_t* z;                 // [N]
+};
+
+struct UpdateArgs {
+    uint32_t K, W, Kbg;          // Kbg = min(bg_order, K)
+    const double* red;           // [Y*W + 3]: n_K in [y][j], llh, sum_r, n_seqs
+    const float* vbg;            // flat bg conditionals (orders 0..bg_order)
+    const float* A;              // [K+1][W]
+    float* n;                    // flat counts (all orders)
+    float* v;                    // flat conditionals (all orders), updated in place
+    float* s;                    // [W][Y+1] linear odds for the next E-step
+    float* q;                    // device scalar
+    float* status;               // [8]: llh, v_diff, q, iteration, ...
+    float* trace;                // [cap][3]
+    uint32_t trace_cap;
+    uint32_t* iteration;         // device counter
+    int32_t optimize_q;
+    double n_seqs_override;      // >0: use instead of red[..+2]
+};
+
+// launchers (kernels.hip)
+size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum);
+int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
+                  uint32_t threads, hipStream_t st);
+int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
+                 hipStream_t st);
+int launch_reduce_partials(const float* partial_n, const double* partial_stat, uint32_t blocks,
+                           uint32_t W, uint32_t Y, double* red, hipStream_t st);
+int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint32_t Kbg, float* s,
+                  hipStream_t st);
+int launch_update(const UpdateArgs& a, hipStream_t st);
+int launch_stat_only(const double* red, uint32_t cells, float* status, hipStream_t st);
+uint32_t max_threads_for_mclass(int mclass);
+
+}  // namespace bamm

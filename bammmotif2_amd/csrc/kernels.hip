@@ -1,0 +1,552 @@
+// gfx950 (MI355X / CDNA4) kernels of the BaMMmotif2 EM hot path.
+//
+// What they compute (reference lines, relative to /root/reference/src):
+//   k_em_seq        EM::EStep  refinement/EM.cpp:149-196   (responsibilities, log-likelihood)
+//                   EM::MStep  refinement/EM.cpp:231-243   (order-K fractional counts)
+//                   EM::optimize_q's sum over r            refinement/EM.cpp:509-513
+//   k_reduce_partials  the cross-thread reduction the reference gets from
+//                   `omp parallel for reduction(+:llikelihood)` (EM.cpp:148) and the CAS float
+//                   atomics (EM.cpp:203-215,240)
+//   k_update        EM.cpp:247-254 (marginalise), Motif::updateV init/Motif.h:95-136,
+//                   EM::optimize_q EM.cpp:515, v_diff EM.cpp:102-108,
+//                   Motif::calculateLinearS init/Motif.cpp:485-494
+//   k_score         ScoreSeqSet::calcLogOdds seq_scoring/ScoreSeqSet.cpp:41-66
+//
+// Design: one 64-lane wavefront owns one sequence at a time.  Lane l holds M
+// consecutive positions p = l*M+m in registers.  The odds table s[j][y] (plus a neutral pad
+// row) lives in LDS; window products are built as a systolic chain
+//       U_j(p) = U_{j-1}(p-1) * s[j][y(p)]
+// whose only cross-lane traffic is ONE `wave_shr:1` DPP move per motif column (the value
+// leaving lane l-1's last slot).  The M-step is the adjoint chain: the normalised
+// responsibilities are shifted one slot towards lower p per column (`wave_shl:1`) and added
+// into the block's count table n[j][y] in LDS with ds_add_f32.  Nothing but the 2-bit sequence
+// stream (+ the N exceptions) is read from HBM; per block one partial table is written.
+// No MFMA: this is gather/scatter, not a contraction.
+
+#include "common.h"
+
+#include <cfloat>
+
+namespace bamm {
+
+const int kMClasses[kNumMClasses] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32};
+
+int m_class_for_len(uint32_t L) {
+    for (int i = 0; i < kNumMClasses; i++)
+        if (L <= 64u * (uint32_t)kMClasses[i]) return i;
+    return -1;
+}
+
+uint32_t max_threads_for_mclass(int mclass) {
+    int M = kMClasses[mclass];
+    return M <= 8 ? 1024u : (M <= 16 ? 512u : 256u);
+}
+
+namespace {
+
+// ---- cross-lane helpers ------------------------------------------------------------------
+// DPP wave shifts exist on the GFX9 family (incl. gfx950).  `oldv` is what lane 0 (shr) /
+// lane 63 (shl) keeps.
+__device__ __forceinline__ float wave_shr1(float oldv, float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
+                                           0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float oldv, float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
+                                           0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// ---- sequence decode: M consecutive positions of one sequence into registers -------------
+// y[m] = kmer_[p] mod Y for p = lane*M+m (Sequence.cpp:35-41), PAD (= Y) where p >= limit.
+template <int M>
+__device__ __forceinline__ void decode_positions(const SeqView& sv, uint32_t seq, uint32_t L,
+                                                 uint32_t Y, uint32_t limit, int lane, uint32_t (&y)[M]) {
+    constexpr int NSEL = (M + 14) / 16 + 1;  // candidate words per position
+    const uint32_t* wp = sv.words + sv.word_off[seq];
+    const uint32_t nw = (L + 15u) >> 4;
+    const uint32_t p0 = (uint32_t)lane * M;
+    const uint32_t wi0 = p0 >> 4;
+    uint32_t w[NSEL + 1];  // w[0] = word wi0-1, w[1] = word wi0, ...
+    w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+    for (int i = 0; i < NSEL; i++) w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const uint32_t p = p0 + m;
+        const uint32_t sel = (p >> 4) - wi0;
+        uint32_t lo = w[1], hi = w[0];
+#pragma unroll
+        for (int c = 1; c < NSEL; c++) {
+            lo = (sel == (uint32_t)c) ? w[c + 1] : lo;
+            hi = (sel == (uint32_t)c) ? w[c] : hi;
+        }
+        const uint32_t sh = 30u - 2u * (p & 15u);
+        y[m] = __builtin_amdgcn_alignbit(hi, lo, sh) & (Y - 1u);
+    }
+    // positions whose k-mer the 2-bit stream cannot express (N randomisation, Sequence.cpp:38)
+    const uint64_t e0 = sv.exc_off[seq], e1 = sv.exc_off[seq + 1];
+    for (uint64_t e = e0; e < e1; e++) {
+        const uint2 x = sv.exc[e];
+        const int mm = (int)x.x - (int)p0;
+#pragma unroll
+        for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) y[m] = (p0 + m < limit) ? y[m] : Y;
+}
+
+__device__ __forceinline__ uint32_t pick_sequence(const SeqView& sv, uint32_t t) {
+    return sv.idx ? sv.idx[t] : t;
+}
+
+// ---- fused E+M sequence kernel --------------------------------------------------------------
+template <int M, bool ACCUM, bool WRITE_R, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
+    extern __shared__ float lds[];
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
+    float* s_lds = lds;                                  // [W][Y+1], row Y = 1.0f
+    float* n_lds = lds + W * Ys;                         // [W][Y]
+    const uint32_t stat_off = (W * Ys + (ACCUM ? W * Y : 0u) + 1u) & ~1u;
+    double* stat_lds = reinterpret_cast<double*>(lds + stat_off);  // [waves][3]
+
+    for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s_lds[i] = a.s[i];
+    if (ACCUM)
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n_lds[i] = 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const float q = *a.q;
+    const float one_minus_q = 1.0f - q;
+
+    double llh_acc = 0.0, sumr_acc = 0.0;
+    uint32_t seq_cnt = 0;
+
+    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
+        const uint32_t seq = pick_sequence(a.sv, t);
+        if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
+        if (a.sv.mask && !a.sv.mask[seq]) continue;
+        const uint32_t L = a.sv.len[seq];
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+
+        uint32_t y[M];
+        // EM.cpp:167: only positions ij < LW1 take part; everything beyond reads the neutral row
+        decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
+
+        // ---- E-step: U[m] after column j = prod_{j'<=j} s[j'][y(p-j+j')]  (EM.cpp:167-176)
+        float U[M];
+        const float* sj = s_lds;
+#pragma unroll
+        for (int m = 0; m < M; m++) U[m] = sj[y[m]];
+        for (uint32_t j = 1; j < W; j++) {
+            sj += Ys;
+            const float carry = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+            for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m]];
+            U[0] = carry * sj[y[0]];
+        }
+        // slot p now holds the product of window start i = p-(W-1); valid for W-1 <= p < L
+        const float pos_i = q / (float)LW1;              // EM.cpp:160
+        float zpart = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t p = p0 + m;
+            const bool valid = (p + 1u >= W) && (p < L);
+            U[m] = valid ? U[m] * pos_i : 0.0f;          // EM.cpp:180
+            zpart += U[m];
+        }
+        const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
+#pragma unroll
+        for (int m = 0; m < M; m++) U[m] = U[m] / Z;     // EM.cpp:185-187
+        llh_acc += (double)logf(Z);                      // EM.cpp:195
+        sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
+        seq_cnt++;
+
+        if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
+            float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                if (p < L) ro[L - 1u - p] = U[m];
+            }
+        }
+
+        if (ACCUM) {
+            // ---- M-step (EM.cpp:236-242): position p, column j receives r(i = p-j), which
+            // sits in slot p+(W-1-j): walk j downwards and shift the slots one step per column.
+            float* nj = n_lds + (W - 1u) * Y;
+            for (uint32_t j = W;;) {
+                j--;
+#pragma unroll
+                for (int m = 0; m < M; m++)
+                    if (y[m] != Y) atomicAdd(&nj[y[m]], U[m]);
+                if (j == 0) break;
+                const float first = U[0];
+#pragma unroll
+                for (int m = 0; m + 1 < M; m++) U[m] = U[m + 1];
+                U[M - 1] = wave_shl1(0.0f, first);
+                nj -= Y;
+            }
+        }
+    }
+
+    // ---- block epilogue: partial table + statistics
+    if (lane == 0) {
+        stat_lds[wave * 3 + 0] = llh_acc;
+        stat_lds[wave * 3 + 1] = sumr_acc;
+        stat_lds[wave * 3 + 2] = (double)seq_cnt;
+    }
+    __syncthreads();
+    if (ACCUM) {
+        float* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) out[i] = n_lds[i];
+    }
+    if (threadIdx.x < 3) {
+        double acc = 0.0;
+        for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
+        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+    }
+}
+
+// ---- log-odds scorer ----------------------------------------------------------------------
+template <int M, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_score(ScoreKernelArgs a) {
+    extern __shared__ float lds[];
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
+    float* s_lds = lds;                                  // [W][Y+1], row Y = 0.0f
+    for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s_lds[i] = a.s[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+
+    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
+        const uint32_t seq = pick_sequence(a.sv, t);
+        const uint32_t L = a.sv.len[seq];
+        const uint32_t p0 = (uint32_t)lane * M;
+        uint32_t y[M];
+        decode_positions<M>(a.sv, seq, L, Y, L, lane, y);   // full windows (ScoreSeqSet.cpp:49-54)
+
+        float U[M];
+        const float* sj = s_lds;
+#pragma unroll
+        for (int m = 0; m < M; m++) U[m] = sj[y[m]];        // 0.0f + s == s
+        for (uint32_t j = 1; j < W; j++) {
+            sj += Ys;
+            const float carry = wave_shr1(0.0f, U[M - 1]);
+#pragma unroll
+            for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] + sj[y[m]];
+            U[0] = carry + sj[y[0]];
+        }
+        float best = -FLT_MAX;                              // ScoreSeqSet.cpp:46
+        uint32_t best_i = 0;
+        float* mo = a.mops ? a.mops + a.mops_off[seq] : nullptr;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t p = p0 + m;
+            if (p + 1u >= W && p < L) {
+                const uint32_t i = p + 1u - W;
+                if (mo) mo[i] = U[m];
+                if (U[m] > best) { best = U[m]; best_i = i; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {                  // first arg-max over the wave
+            const float ob = __shfl_xor(best, o, 64);
+            const uint32_t oi = __shfl_xor(best_i, o, 64);
+            const bool take = (ob > best) || (ob == best && oi < best_i);
+            best = take ? ob : best;
+            best_i = take ? oi : best_i;
+        }
+        if (lane == 0) { a.zoops[seq] = best; a.z[seq] = best_i; }
+    }
+}
+
+// ---- reduce the per-block partial tables (deterministic, fp64) ------------------------------
+// grid.x = ceil(W*Y/64) (+1 block when there are no cells), 1024 threads = 64 cells x 16 groups
+__global__ void __launch_bounds__(1024) k_reduce_partials(const float* partial_n, const double* partial_stat,
+                                                          uint32_t blocks, uint32_t W, uint32_t Y, double* red) {
+    __shared__ double sh[16][64];
+    const uint32_t C = partial_n ? W * Y : 0u;
+    const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t g = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (c < C)
+        for (uint32_t b = g; b < blocks; b += 16u) acc += (double)partial_n[(size_t)b * C + c];
+    sh[g][threadIdx.x & 63u] = acc;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) t += sh[i][threadIdx.x];
+        const uint32_t j = c / Y, y = c % Y;               // LDS layout [j][y] -> ABI layout [y][j]
+        red[(size_t)y * W + j] = t;
+    }
+    if (blockIdx.x == 0) {
+        __syncthreads();
+        // statistics: llh, sum_r, n_seqs
+        const uint32_t k = threadIdx.x & 3u, grp = threadIdx.x >> 2;   // 256 groups
+        double a2 = 0.0;
+        if (k < 3u)
+            for (uint32_t b = grp; b < blocks; b += 256u) a2 += partial_stat[(size_t)b * 4 + k];
+        double* flat = &sh[0][0];
+        flat[threadIdx.x] = a2;
+        __syncthreads();
+        if (threadIdx.x < 3u) {
+            double t = 0.0;
+            for (uint32_t i = 0; i < 256u; i++) t += flat[i * 4 + threadIdx.x];
+            red[(size_t)W * Y + threadIdx.x] = t;
+        }
+    }
+}
+
+// ---- s[j][y] = v[K][y][j] / vbg[Kbg][y mod 4^(Kbg+1)], pad row = 1  (Motif.cpp:485-494) -----
+__global__ void k_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint32_t Kbg, float* s) {
+    const uint32_t Y = 1u << (2 * (K + 1)), Ys = Y + 1u, Yb = 1u << (2 * (Kbg + 1));
+    const float* vK = v + W * (((size_t)Y - 4) / 3);
+    const float* b = vbg + (((size_t)Yb - 4) / 3);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < W * Ys; i += gridDim.x * blockDim.x) {
+        const uint32_t j = i / Ys, y = i % Ys;
+        s[i] = (y == Y) ? 1.0f : vK[(size_t)y * W + j] / b[y % Yb];
+    }
+}
+
+// ---- model update: one block ----------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
+    __shared__ double shd[1024];
+    const uint32_t K = a.K, W = a.W;
+    const uint32_t YK = 1u << (2 * (K + 1));
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    auto voff = [W](uint32_t k) { return (size_t)W * (((size_t(1) << (2 * (k + 1))) - 4) / 3); };
+
+    // order-K counts from the (all-reduced) fp64 buffer
+    float* nK = a.n + voff(K);
+    for (uint32_t i = tid; i < YK * W; i += nt) nK[i] = (float)a.red[i];
+    __syncthreads();
+    // EM.cpp:247-254: n[k-1][y mod 4^k][j] += n[k][y][j], y ascending (same float order)
+    for (uint32_t k = K; k > 0; k--) {
+        const float* nk = a.n + voff(k);
+        float* nk1 = a.n + voff(k - 1);
+        const uint32_t Yk = 1u << (2 * k);                 // rows of order k-1
+        for (uint32_t i = tid; i < Yk * W; i += nt) {
+            const uint32_t y2 = i / W, j = i % W;
+            float acc = 0.0f;
+#pragma unroll
+            for (uint32_t bse = 0; bse < 4; bse++) acc += nk[(size_t)(bse * Yk + y2) * W + j];
+            nk1[i] = acc;
+        }
+        __syncthreads();
+    }
+    // Motif.h:100-118: order 0
+    double diff = 0.0;
+    for (uint32_t j = tid; j < W; j += nt) {
+        float sumN = 0.0f;
+        for (uint32_t y = 0; y < 4; y++) sumN += a.n[y * W + j];
+        for (uint32_t y = 0; y < 4; y++) {
+            const float nv = (a.n[y * W + j] + a.A[j] * a.vbg[y]) / (sumN + a.A[j]);
+            if (K == 0) diff += (double)fabsf(nv - a.v[y * W + j]);
+            a.v[y * W + j] = nv;
+        }
+    }
+    __syncthreads();
+    // Motif.h:121-135: orders 1..K
+    for (uint32_t k = 1; k <= K; k++) {
+        const float* nk = a.n + voff(k);
+        const float* nk1 = a.n + voff(k - 1);
+        float* vk = a.v + voff(k);
+        const float* vk1 = a.v + voff(k - 1);
+        const float* Ak = a.A + (size_t)k * W;
+        const uint32_t Yk1 = 1u << (2 * (k + 1)), Yk = 1u << (2 * k);
+        for (uint32_t i = tid; i < Yk1 * W; i += nt) {
+            const uint32_t y = i / W, j = i % W;
+            const uint32_t y2 = y % Yk, yk = y / 4;
+            float nv;
+            if (j < k) nv = vk1[(size_t)y2 * W + j];
+            else nv = (nk[i] + Ak[j] * vk1[(size_t)y2 * W + j]) / (nk1[(size_t)yk * W + j - 1] + Ak[j]);
+            if (k == K) diff += (double)fabsf(nv - vk[i]);
+            vk[i] = nv;
+        }
+        __syncthreads();
+    }
+    // v_diff (EM.cpp:102-108)
+    shd[tid] = diff;
+    __syncthreads();
+    for (uint32_t o = nt >> 1; o > 0; o >>= 1) {
+        if (tid < o) shd[tid] += shd[tid + o];
+        __syncthreads();
+    }
+    const double v_diff = shd[0];
+    // next E-step's odds table (Motif.cpp:485-494)
+    {
+        const uint32_t Ys = YK + 1u, Yb = 1u << (2 * (a.Kbg + 1));
+        const float* vK = a.v + voff(K);
+        const float* b = a.vbg + (((size_t)Yb - 4) / 3);
+        for (uint32_t i = tid; i < W * Ys; i += nt) {
+            const uint32_t j = i / Ys, y = i % Ys;
+            a.s[i] = (y == YK) ? 1.0f : vK[(size_t)y * W + j] / b[y % Yb];
+        }
+    }
+    if (tid == 0) {
+        const size_t C = (size_t)YK * W;
+        const double llh = a.red[C + 0], sum_r = a.red[C + 1];
+        const double nseq = a.n_seqs_override > 0.0 ? a.n_seqs_override : a.red[C + 2];
+        const uint32_t it = *a.iteration + 1u;
+        *a.iteration = it;
+        float q = *a.q;
+        if (a.optimize_q && it <= 5u) {                    // EM.cpp:99, :515
+            q = (float)((nseq - sum_r + 1.0) / (nseq + 2.0));
+            *a.q = q;
+        }
+        a.status[0] = (float)llh;
+        a.status[1] = (float)v_diff;
+        a.status[2] = q;
+        a.status[3] = (float)it;
+        a.status[4] = (float)sum_r;
+        a.status[5] = (float)nseq;
+        if (a.trace && it - 1u < a.trace_cap) {
+            a.trace[(size_t)(it - 1u) * 3 + 0] = (float)llh;
+            a.trace[(size_t)(it - 1u) * 3 + 1] = (float)v_diff;
+            a.trace[(size_t)(it - 1u) * 3 + 2] = q;
+        }
+    }
+}
+
+__global__ void k_stat_only(const double* red, uint32_t cells, float* status) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        status[0] = (float)red[cells + 0];
+        status[4] = (float)red[cells + 1];
+        status[5] = (float)red[cells + 2];
+    }
+}
+
+template <int M, int THREADS>
+int launch_em_variant(bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks, uint32_t threads,
+                      size_t lds, hipStream_t st) {
+    if (write_r)
+        hipLaunchKernelGGL((k_em_seq<M, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    else if (accum)
+        hipLaunchKernelGGL((k_em_seq<M, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_em_seq<M, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    return 0;
+}
+
+template <int M, int THREADS>
+void set_em_lds_attr(size_t lds) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_seq<M, true, false, THREADS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_seq<M, false, false, THREADS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_seq<M, false, true, THREADS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+}  // namespace
+
+size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum) {
+    size_t floats = ((size_t)W * (Y + 1) + (accum ? (size_t)W * Y : 0) + 1) & ~size_t(1);
+    return floats * sizeof(float) + 16 * 3 * sizeof(double);
+}
+
+#define BAMM_FOR_EACH_MCLASS(X) \
+    X(0, 1, 1024) X(1, 2, 1024) X(2, 3, 1024) X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) \
+    X(7, 8, 1024) X(8, 10, 512) X(9, 12, 512) X(10, 14, 512) X(11, 16, 512) X(12, 20, 256)             \
+    X(13, 24, 256) X(14, 28, 256) X(15, 32, 256)
+
+int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
+                  uint32_t threads, hipStream_t st) {
+    const size_t lds = em_lds_bytes(a.W, a.Y, accum);
+    if (lds > 160 * 1024) {
+        set_error("odds/count tables need %zu bytes of LDS (> 160 KiB): K=%u W=%u is outside the fused kernel's envelope",
+                  lds, a.K, a.W);
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    if (threads > max_threads_for_mclass(mclass) || (threads & 63u) || threads == 0 || blocks == 0) {
+        set_error("bad launch geometry %u x %u for M class %d", blocks, threads, mclass);
+        return BAMM_ERR_ARG;
+    }
+    switch (mclass) {
+#define X(idx, M, T)                                                   \
+    case idx:                                                          \
+        if (lds > 64 * 1024) set_em_lds_attr<M, T>(lds);               \
+        launch_em_variant<M, T>(accum, write_r, a, blocks, threads, lds, st); \
+        break;
+        BAMM_FOR_EACH_MCLASS(X)
+#undef X
+        default:
+            set_error("no kernel for M class %d", mclass);
+            return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
+    const size_t lds = (size_t)a.W * (a.Y + 1) * sizeof(float);
+    if (lds > 160 * 1024) {
+        set_error("log-odds table needs %zu bytes of LDS (> 160 KiB)", lds);
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    if (threads > max_threads_for_mclass(mclass) || (threads & 63u) || threads == 0 || blocks == 0) {
+        set_error("bad launch geometry %u x %u for M class %d", blocks, threads, mclass);
+        return BAMM_ERR_ARG;
+    }
+    switch (mclass) {
+#define X(idx, M, T)                                                                                   \
+    case idx:                                                                                          \
+        if (lds > 64 * 1024)                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<M, T>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL((k_score<M, T>), dim3(blocks), dim3(threads), lds, st, a);                  \
+        break;
+        BAMM_FOR_EACH_MCLASS(X)
+#undef X
+        default:
+            set_error("no kernel for M class %d", mclass);
+            return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+int launch_reduce_partials(const float* partial_n, const double* partial_stat, uint32_t blocks, uint32_t W,
+                           uint32_t Y, double* red, hipStream_t st) {
+    const uint32_t C = partial_n ? W * Y : 0u;
+    const uint32_t grid = C ? (C + 63u) / 64u : 1u;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(grid), dim3(1024), 0, st, partial_n, partial_stat, blocks, W, Y, red);
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint32_t Kbg, float* s, hipStream_t st) {
+    const uint32_t total = W * ((1u << (2 * (K + 1))) + 1u);
+    hipLaunchKernelGGL(k_make_s, dim3((total + 255u) / 256u), dim3(256), 0, st, v, vbg, K, W, Kbg, s);
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+int launch_update(const UpdateArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, st, a);
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+int launch_stat_only(const double* red, uint32_t cells, float* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_stat_only, dim3(1), dim3(64), 0, st, red, cells, status);
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+}  // namespace bamm

@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference's EM / ScoreSeqSet interface over the C ABI.
+
+Method names follow the reference (`EStep`, `MStep`, `optimize`, `optimize_q`, `getR`, `getQ`;
+/root/reference/src/refinement/EM.h:20-36, seq_scoring/ScoreSeqSet.h:26-36) so that the parity
+tests read like calls into the reference.  Everything numeric happens in libbamm_em.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import abi
+from .abi import check
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def v_size(K: int, W: int) -> int:
+    return W * ((4 ** (K + 2) - 4) // 3)
+
+
+def v_offset(k: int, W: int) -> int:
+    return W * ((4 ** (k + 1) - 4) // 3)
+
+
+def bg_size(K: int) -> int:
+    return (4 ** (K + 2) - 4) // 3
+
+
+def bg_offset(k: int) -> int:
+    return (4 ** (k + 1) - 4) // 3
+
+
+def libc_srand(seed: int = 42) -> None:
+    """mainBaMM.cpp:22 -- the reference seeds libc's rand() once before reading sequences."""
+    C.CDLL(None).srand(C.c_uint(seed))
+
+
+class PackedSeqs:
+    """Host-resident 2-bit packed sequence set (+ N exceptions)."""
+
+    def __init__(self, ptr):
+        self._p = ptr
+        self.lib = abi.load()
+
+    @classmethod
+    def from_kmers(cls, kmer, off) -> "PackedSeqs":
+        lib = abi.load()
+        off = _u64(off)
+        out = C.POINTER(abi.Packed)()
+        check(lib.bamm_pack_kmers(_u64(kmer), off, len(off) - 1, C.byref(out)))
+        return cls(out)
+
+    @classmethod
+    def from_codes(cls, codes, off, single_strand: bool = False, seed: Optional[int] = 42) -> "PackedSeqs":
+        lib = abi.load()
+        off = _u64(off)
+        if seed is not None:
+            libc_srand(seed)
+        out = C.POINTER(abi.Packed)()
+        check(lib.bamm_pack_codes(np.ascontiguousarray(codes, np.uint8), off, len(off) - 1,
+                                  int(single_strand), C.byref(out)))
+        return cls(out)
+
+    @property
+    def c(self):
+        return self._p.contents
+
+    @property
+    def n_seqs(self) -> int:
+        return int(self.c.n_seqs)
+
+    @property
+    def total_len(self) -> int:
+        return int(self.c.total_len)
+
+    @property
+    def lengths(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.c.len, (max(self.n_seqs, 1),))[: self.n_seqs].copy()
+
+    @property
+    def n_exceptions(self) -> int:
+        return int(self.c.n_exc)
+
+    @property
+    def words(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.c.words, (max(int(self.c.n_words), 1),))[: int(self.c.n_words)].copy()
+
+    def offsets(self) -> np.ndarray:
+        return np.concatenate([[0], np.cumsum(self.lengths.astype(np.int64))]).astype(np.uint64)
+
+    def unpack_y(self, K: int) -> np.ndarray:
+        out = np.zeros(max(self.total_len, 1), np.uint32)
+        check(self.lib.bamm_unpack_y(self._p, K, out))
+        return out[: self.total_len]
+
+    def shard_range(self, W: int, rank: int, world: int):
+        b, e = C.c_uint64(0), C.c_uint64(0)
+        lens = np.ascontiguousarray(self.lengths, np.uint32)
+        if len(lens) == 0:
+            lens = np.zeros(1, np.uint32)
+        check(self.lib.bamm_shard_range(lens, self.n_seqs, W, rank, world, C.byref(b), C.byref(e)))
+        return int(b.value), int(e.value)
+
+    def free(self):
+        if self._p:
+            self.lib.bamm_packed_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = abi.load()
+        h = C.c_void_p()
+        check(self.lib.bamm_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def sync(self):
+        check(self.lib.bamm_ctx_sync(self.h))
+
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        check(self.lib.bamm_ctx_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_launch(self, blocks: int = 0, threads: int = 0):
+        check(self.lib.bamm_ctx_set_launch(self.h, blocks, threads))
+
+    def close(self):
+        if self.h:
+            self.lib.bamm_ctx_destroy(self.h)
+            self.h = None
+
+
+class SeqSet:
+    """Sequences resident in HBM (a shard [begin, end) of a PackedSeqs)."""
+
+    def __init__(self, ctx: Context, packed: PackedSeqs, begin: int = 0, end: Optional[int] = None):
+        self.ctx, self.lib = ctx, ctx.lib
+        end = packed.n_seqs if end is None else end
+        h = C.c_void_p()
+        check(self.lib.bamm_seqs_upload(ctx.h, packed._p, begin, end, C.byref(h)))
+        self.h = h
+        self.n_seqs = end - begin
+        self.lengths = packed.lengths[begin:end]
+        self.off = np.concatenate([[0], np.cumsum(self.lengths.astype(np.int64))]).astype(np.uint64)
+
+    def info(self):
+        n, t, m, b = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()
+        check(self.lib.bamm_seqs_info(self.h, C.byref(n), C.byref(t), C.byref(m), C.byref(b)))
+        return dict(n_seqs=n.value, total_len=t.value, max_len=m.value, hbm_bytes=b.value)
+
+    def close(self):
+        if self.h:
+            self.lib.bamm_seqs_destroy(self.h)
+            self.h = None
+
+
+class EM:
+    """Drop-in for the reference's `EM` (EM.h:11-69) on one GPU shard."""
+
+    def __init__(self, ctx: Context, seqs: SeqSet, K: int, W: int, vbg, A, v_init, q: float,
+                 bg_order: int = 2, optimizeQ: bool = False, mask=None, epsilon: float = 0.01,
+                 max_iterations: int = 1000, n_seqs_global: int = 0):
+        self.ctx, self.lib, self.seqs = ctx, ctx.lib, seqs
+        self.K, self.W = K, W
+        prm = abi.EmParams()
+        self.lib.bamm_em_default_params(C.byref(prm))
+        prm.K, prm.W, prm.bg_order, prm.q = K, W, bg_order, q
+        prm.optimize_q = int(optimizeQ)
+        prm.epsilon, prm.max_iterations, prm.n_seqs_global = epsilon, max_iterations, n_seqs_global
+        self.max_iterations = max_iterations
+        vbg, A, v_init = _f32(vbg), _f32(A), _f32(v_init)
+        assert len(vbg) >= bg_size(bg_order) and len(A) == (K + 1) * W and len(v_init) == v_size(K, W)
+        mptr = None
+        if mask is not None:
+            self._mask = np.ascontiguousarray(mask, np.uint8)
+            assert len(self._mask) == seqs.n_seqs
+            mptr = self._mask.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        check(self.lib.bamm_em_create(ctx.h, seqs.h, C.byref(prm), vbg, A, v_init, mptr, C.byref(h)))
+        self.h = h
+        self._cb = None
+
+    # -- the reference's public surface ---------------------------------------------------
+    def EStep(self):
+        check(self.lib.bamm_em_estep(self.h))
+
+    def MStep(self):
+        check(self.lib.bamm_em_mstep(self.h))
+
+    def optimize_q(self):
+        check(self.lib.bamm_em_optimize_q(self.h))
+
+    def optimize(self) -> int:
+        it = C.c_uint32()
+        check(self.lib.bamm_em_optimize(self.h, C.byref(it)))
+        return int(it.value)
+
+    def getQ(self) -> float:
+        q = C.c_float()
+        check(self.lib.bamm_em_get_q(self.h, C.byref(q)))
+        return float(q.value)
+
+    def getR(self, begin: int = 0, end: Optional[int] = None) -> np.ndarray:
+        end = self.seqs.n_seqs if end is None else end
+        total = int(self.seqs.off[end] - self.seqs.off[begin])
+        out = np.zeros(max(total, 1), np.float32)
+        check(self.lib.bamm_em_get_r(self.h, begin, end, out, total))
+        return out[:total]
+
+    # -- extensions -------------------------------------------------------------------------
+    def iterate(self, n: int = 1):
+        check(self.lib.bamm_em_iterate(self.h, n))
+
+    def accumulate(self):
+        check(self.lib.bamm_em_accumulate(self.h))
+
+    def update(self):
+        check(self.lib.bamm_em_update(self.h))
+
+    def reduce_buffer(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        check(self.lib.bamm_em_reduce_buffer(self.h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def set_allreduce(self, fn: Optional[Callable[[int, int, int], int]]):
+        """fn(dev_ptr, n_doubles, hip_stream) -> 0 on success; called between the local
+        accumulation and the model update of every pass."""
+        if fn is None:
+            self._cb = abi.ALLREDUCE_FN(0)
+        else:
+            def tramp(_user, ptr, n, stream):
+                try:
+                    return int(fn(int(ptr or 0), int(n), int(stream or 0)) or 0)
+                except Exception:  # never unwind through C
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = abi.ALLREDUCE_FN(tramp)
+        check(self.lib.bamm_em_set_allreduce(self.h, self._cb, None))
+
+    def getV(self) -> np.ndarray:
+        out = np.zeros(v_size(self.K, self.W), np.float32)
+        check(self.lib.bamm_em_get_v(self.h, out))
+        return out
+
+    def getCounts(self) -> np.ndarray:
+        out = np.zeros(v_size(self.K, self.W), np.float32)
+        check(self.lib.bamm_em_get_counts(self.h, out))
+        return out
+
+    def getS(self) -> np.ndarray:
+        out = np.zeros(4 ** (self.K + 1) * self.W, np.float32)
+        check(self.lib.bamm_em_get_s(self.h, out))
+        return out
+
+    def getLLH(self) -> float:
+        x = C.c_float()
+        check(self.lib.bamm_em_get_llh(self.h, C.byref(x)))
+        return float(x.value)
+
+    def getVdiff(self) -> float:
+        x = C.c_float()
+        check(self.lib.bamm_em_get_vdiff(self.h, C.byref(x)))
+        return float(x.value)
+
+    def iteration(self) -> int:
+        x = C.c_uint32()
+        check(self.lib.bamm_em_get_iteration(self.h, C.byref(x)))
+        return int(x.value)
+
+    def trace(self):
+        cap = self.max_iterations
+        llh, vd, q = (np.zeros(cap, np.float32) for _ in range(3))
+        n = C.c_uint32()
+        check(self.lib.bamm_em_get_trace(self.h, llh, vd, q, cap, C.byref(n)))
+        m = min(int(n.value), cap)
+        return llh[:m].copy(), vd[:m].copy(), q[:m].copy()
+
+    def kernel_time(self):
+        ms, n = C.c_float(), C.c_uint32()
+        check(self.lib.bamm_em_kernel_time(self.h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)
+
+    def close(self):
+        if self.h:
+            self.lib.bamm_em_destroy(self.h)
+            self.h = None
+
+
+def logodds(ctx: Context, seqs: SeqSet, K: int, W: int, bg_order: int, v, vbg, want_mops: bool = True):
+    """ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67): returns (mops or None, zoops, z)."""
+    lib = ctx.lib
+    N = seqs.n_seqs
+    total = int((seqs.lengths.astype(np.int64) - W + 1).sum()) if N else 0
+    mops = np.zeros(max(total, 1), np.float32) if want_mops else None
+    zoops = np.zeros(max(N, 1), np.float32)
+    z = np.zeros(max(N, 1), np.uint64)
+    mptr = mops.ctypes.data_as(C.c_void_p) if want_mops else None
+    check(lib.bamm_logodds(ctx.h, seqs.h, K, W, bg_order, _f32(v), _f32(vbg), mptr, total, zoops, z))
+    return (mops[:total] if want_mops else None), zoops[:N], z[:N]
+
+
+def calculate_p(v, vbg, bg_order: int, K: int, W: int) -> np.ndarray:
+    lib = abi.load()
+    p = np.zeros(v_size(K, W), np.float32)
+    check(lib.bamm_calculate_p(_f32(v), _f32(vbg), bg_order, K, W, p))
+    return p

@@ -1,0 +1,196 @@
+/* bamm_em.h -- C ABI of the MI355X (gfx950) EM-refinement hot path of BaMMmotif2.
+ *
+ * The reference has no FFI layer: the seam is the C++ class `EM` (src/refinement/EM.h:11-69)
+ * and `ScoreSeqSet` (src/seq_scoring/ScoreSeqSet.h:14-53), which read
+ * `Sequence::getKmer()/getL()` (src/init/Sequence.h:26,36), `Motif::getV/getA/getK/getW/getQ`
+ * (src/init/Motif.h:30-38) and `BackgroundModel::getV/getOrder` (src/init/BackgroundModel.h:34-35)
+ * and mutate the caller's Motif in place.  This header is what a binding for that seam binds:
+ * plain pointers and sizes, no C++ / torch types.  INTEGRATION.md shows the reference-side
+ * glue (an `EM` whose methods forward to these entry points).
+ *
+ * Conventions
+ *   - every function returns BAMM_OK (0) or a negative error code; bamm_last_error() gives
+ *     the message of the last failure on the calling thread.  Nothing calls exit().
+ *     (the reference only ever `exit(1)`s after a std::cerr line, e.g. Global.cpp:127-131.)
+ *   - all host buffers are caller-owned and only read/written during the call.
+ *   - handles are not thread-safe individually; distinct handles may be used from distinct
+ *     threads (FDR.cpp:37 runs folds concurrently).
+ *   - flat tensor layouts (identical to oracle/bamm_oracle.h):
+ *       v, n, p : [k][y][j] row-major, orders concatenated, order k at W*(4^(k+1)-4)/3
+ *       vbg     : [k][y], order k at (4^(k+1)-4)/3
+ *       A       : [k][j], (K+1) x W          (Motif.cpp:43-46)
+ *       s       : [y][j], 4^(K+1) x W
+ *       r       : per sequence L floats, reference's reversed index: r[L-W-i] <-> window
+ *                 start i, slots >= L-W+1 are zero (EM.cpp:173,190-192)
+ */
+#ifndef BAMM_EM_H_
+#define BAMM_EM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BAMM_OK              0
+#define BAMM_ERR_ARG        -1   /* bad argument (null, size, order > BAMM_MAX_ORDER, L < W ...) */
+#define BAMM_ERR_HIP        -2   /* HIP runtime failure (message carries hipGetErrorString)      */
+#define BAMM_ERR_NO_DEVICE  -3   /* no gfx950 device / extension built for another arch         */
+#define BAMM_ERR_UNSUPPORTED -4  /* shape outside the kernels' envelope         */
+#define BAMM_ERR_STATE      -5   /* call order (e.g. MStep before any EStep)                    */
+#define BAMM_ERR_COMM       -6   /* the caller's all-reduce callback failed                     */
+
+#define BAMM_MAX_ORDER      10   /* kmer_ spans 11 bases (Sequence.cpp:37)                      */
+
+typedef struct bamm_ctx  bamm_ctx;   /* one device + one stream                                   */
+typedef struct bamm_seqs bamm_seqs;  /* a sequence set resident in HBM (2-bit packed)             */
+typedef struct bamm_em   bamm_em;    /* one EM run; replaces `class EM` (EM.h:11-69)              */
+
+const char* bamm_last_error(void);
+const char* bamm_version(void);
+
+/* ------------------------------------------------------------------ packing (host only) --
+ * Replaces what EM/ScoreSeqSet read through Sequence::getKmer() (EM.cpp:152, :233,
+ * ScoreSeqSet.cpp:44): `kmer_[i]` = up to 11 bases ending at i, newest base least
+ * significant (Sequence.cpp:35-41).  The packed form keeps 2 bits per position (digit 0 of
+ * kmer_[i]) in big-endian order inside 32-bit words, 16 positions per word, every sequence
+ * starting on a word boundary, plus an exception list for the positions whose 11-mer cannot
+ * be rebuilt from those bits (the reference randomises an unknown base independently per
+ * (position, digit), Sequence.cpp:38, and lets the byte 'N' leak into reverse complements,
+ * Alphabet.cpp:50).  Pure CPU code: usable and testable without a GPU.                       */
+typedef struct bamm_packed {
+    uint64_t  n_seqs;
+    uint64_t  n_words;
+    uint64_t  n_exc;
+    uint64_t  total_len;     /* sum of L                                                     */
+    uint32_t  max_len;
+    uint32_t  min_len;
+    uint32_t* words;         /* [n_words]                                                    */
+    uint64_t* word_off;      /* [n_seqs+1] first word of each sequence                       */
+    uint32_t* len;           /* [n_seqs]   L                                                 */
+    uint64_t* exc_off;       /* [n_seqs+1]                                                   */
+    uint32_t* exc_pos;       /* [n_exc] position inside its sequence, ascending              */
+    uint32_t* exc_kmer;      /* [n_exc] kmer_[pos] mod 4^11 as the reference holds it        */
+    uint32_t* exc_clean;     /* [n_exc] what the 2-bit stream alone would give               */
+} bamm_packed;
+
+/* kmer: concatenated kmer_ arrays, off[n_seqs+1] (positions).  Values are taken mod 4^11.    */
+int  bamm_pack_kmers(const uint64_t* kmer, const uint64_t* off, uint64_t n_seqs, bamm_packed** out);
+/* same input as the reference holds it: one pointer per Sequence (getKmer()) + getL()        */
+int  bamm_pack_kmer_ptrs(const uint64_t* const* kmer_ptrs, const uint64_t* L, uint64_t n_seqs,
+                         bamm_packed** out);
+/* from the alphabet codes of FASTA records (0 = N, 1..4 = A,C,G,T; off[n_seqs+1]) -- restates
+ * Sequence::Sequence (Sequence.cpp:4-43,91-99): appends the reverse complement unless
+ * single_strand and draws libc rand()%4 for unknown bases in the reference's order, so after
+ * the caller's srand(42) (mainBaMM.cpp:22) the result equals packing the reference's kmer_.   */
+int  bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
+                     bamm_packed** out);
+/* inverse (host): rebuild kmer_[i] mod 4^(K+1) for every position -- used by tests          */
+int  bamm_unpack_y(const bamm_packed* p, uint32_t K, uint32_t* y_out /* [total_len] */);
+void bamm_packed_free(bamm_packed* p);
+
+/* contiguous shard [begin,end) of rank `rank` of `world`, balanced by sum(L-W+1) */
+int  bamm_shard_range(const uint32_t* len, uint64_t n_seqs, uint32_t W, uint32_t rank,
+                      uint32_t world, uint64_t* begin, uint64_t* end);
+
+/* ------------------------------------------------------------------ context ------------- */
+/* stream: a hipStream_t created by the caller (e.g. torch's current stream), or NULL to let
+ * the context create its own.  Fails with BAMM_ERR_NO_DEVICE when no gfx950 GPU is visible. */
+int  bamm_ctx_create(int device, void* hip_stream, bamm_ctx** out);
+int  bamm_ctx_destroy(bamm_ctx* ctx);
+int  bamm_ctx_sync(bamm_ctx* ctx);
+int  bamm_ctx_device_name(bamm_ctx* ctx, char* buf, size_t cap);
+/* launch geometry of the sequence kernels (0 = default); exposed for tuning/benchmarks      */
+int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_block);
+
+/* ------------------------------------------------------------------ sequences ----------- */
+/* Uploads sequences [begin,end) of `p`; they stay resident and are shared (ref-counted) by
+ * any number of EM handles -- CV folds pass a mask instead of copying (FDR.cpp:49-57).       */
+int  bamm_seqs_upload(bamm_ctx* ctx, const bamm_packed* p, uint64_t begin, uint64_t end,
+                      bamm_seqs** out);
+int  bamm_seqs_destroy(bamm_seqs* s);
+int  bamm_seqs_info(const bamm_seqs* s, uint64_t* n_seqs, uint64_t* total_len, uint32_t* max_len,
+                    uint64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------ EM ------------------ */
+typedef struct bamm_em_params {
+    uint32_t K;              /* motif order             (Motif::getK)                        */
+    uint32_t W;              /* motif width             (Motif::getW)                        */
+    uint32_t bg_order;       /* BackgroundModel::getOrder(); EM uses min(bg_order,K) EM.cpp:23 */
+    float    q;              /* Motif::getQ()           (EM.cpp:12)                          */
+    int32_t  optimize_q;     /* EM ctor arg; q re-estimated while iteration <= 5 (EM.cpp:99) */
+    float    epsilon;        /* EM.h:62  (0.01)                                              */
+    uint32_t max_iterations; /* EM.h:63  (1000)                                              */
+    uint64_t n_seqs_global;  /* N used by optimize_q (EM.cpp:515); 0 = this handle's own N   */
+} bamm_em_params;
+
+void bamm_em_default_params(bamm_em_params* p);
+
+/* seq_mask: NULL, or n_seqs bytes (1 = sequence takes part).  vbg holds orders 0..bg_order.
+ * Mirrors EM::EM (EM.cpp:7-43); v_init is Motif::getV() flattened.                           */
+int  bamm_em_create(bamm_ctx* ctx, bamm_seqs* seqs, const bamm_em_params* params,
+                    const float* vbg, const float* A, const float* v_init,
+                    const uint8_t* seq_mask, bamm_em** out);
+int  bamm_em_destroy(bamm_em* em);
+
+/* EM::EStep (EM.cpp:139-200): s from the current v, responsibilities, log-likelihood.        */
+int  bamm_em_estep(bamm_em* em);
+/* EM::MStep (EM.cpp:217-259): counts from the responsibilities of the last EStep, updateV.   */
+int  bamm_em_mstep(bamm_em* em);
+/* EM::optimize_q (EM.cpp:505-519) from the responsibilities of the last EStep.               */
+int  bamm_em_optimize_q(bamm_em* em);
+/* n fused EStep+MStep(+optimize_q while iteration<=5) passes, no convergence test, no host
+ * round trip in between (benchmark / fixed-budget mode).                          */
+int  bamm_em_iterate(bamm_em* em, uint32_t n);
+/* EM::optimize (EM.cpp:62-137) including the stopping rule; *iterations = passes executed.   */
+int  bamm_em_optimize(bamm_em* em, uint32_t* iterations);
+
+/* multi-GPU: between the local accumulation and the model update the fused buffer
+ * [n_K (4^(K+1)*W) | llh | sum_r | n_seqs] (doubles, on the device, on the context's stream)
+ * is summed across ranks by the caller.  Either drive the three phases by hand ...           */
+int  bamm_em_accumulate(bamm_em* em);
+int  bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_doubles);
+int  bamm_em_update(bamm_em* em);
+/* ... or install a callback that bamm_em_iterate/optimize/mstep invoke at that point.        */
+typedef int (*bamm_allreduce_fn)(void* user, void* dev_ptr, uint64_t n_doubles, void* hip_stream);
+int  bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user);
+
+/* results (each synchronises the stream)                                                     */
+int  bamm_em_get_v(bamm_em* em, float* v_flat);        /* Motif::getV()                       */
+int  bamm_em_get_counts(bamm_em* em, float* n_flat);   /* EM::n_   (EM.h:54)                  */
+int  bamm_em_get_s(bamm_em* em, float* s);             /* Motif::getS() after EStep           */
+int  bamm_em_get_q(bamm_em* em, float* q);             /* EM::getQ()                          */
+int  bamm_em_get_llh(bamm_em* em, float* llh);         /* EM::llikelihood_ (EM.h:61)          */
+int  bamm_em_get_vdiff(bamm_em* em, float* v_diff);    /* EM.cpp:102-108, last pass           */
+int  bamm_em_get_iteration(bamm_em* em, uint32_t* it);
+/* EM::getR() for sequences [begin,end): recomputed on demand from the s of the last EStep,
+ * written in the reference's layout; out_off[n] = offset of sequence begin+n in `out`.       */
+int  bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_t out_cap);
+/* per-iteration trace of optimize()/iterate(): what the reference prints with --verbose
+ * (EM.cpp:112-115).  Returns up to cap entries, *n = entries available.                      */
+int  bamm_em_get_trace(bamm_em* em, float* llh, float* v_diff, float* q, uint32_t cap, uint32_t* n);
+/* device time of the sequence kernel over the last iterate()/optimize() call (HIP events on
+ * the context's stream): total milliseconds and number of launches.                          */
+int  bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches);
+
+/* ------------------------------------------------------------------ scorer -------------- */
+/* ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67) with Motif::calculateLogS
+ * (Motif.cpp:471-483).  mops (may be NULL): concatenated L-W+1 scores per sequence;
+ * zoops[n_seqs], z[n_seqs] (first arg-max).                                                  */
+int  bamm_logodds(bamm_ctx* ctx, bamm_seqs* seqs, uint32_t K, uint32_t W, uint32_t bg_order,
+                  const float* v_flat, const float* vbg, float* mops, uint64_t mops_cap,
+                  float* zoops, uint64_t* z);
+
+/* ------------------------------------------------------------------ small host helpers -- */
+/* Motif::calculateP (Motif.cpp:430-469); host arithmetic on <= 41k elements.                 */
+int  bamm_calculate_p(const float* v_flat, const float* vbg, uint32_t bg_order, uint32_t K,
+                      uint32_t W, float* p_flat);
+size_t bamm_v_size(uint32_t K, uint32_t W);
+size_t bamm_v_offset(uint32_t k, uint32_t W);
+size_t bamm_bg_size(uint32_t K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAMM_EM_H_ */

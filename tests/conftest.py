@@ -1,0 +1,35 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import oracle
+    o = oracle.Oracle()
+    o.set_threads(1)
+    return o
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from bammmotif2_amd import abi, build
+    build.build_library()
+    return abi.load()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(lib):
+    import bammmotif2_amd as bm
+    ctx = bm.Context(0)          # raises loudly without a gfx950 device: no fallback
+    yield ctx
+    ctx.close()

@@ -1,0 +1,112 @@
+"""CPU-only checks of the host side of the C ABI: packing, sharding, helpers, symbol export,
+and that the HIP path refuses to run without a GPU instead of falling back."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import bammmotif2_amd as bm
+from bammmotif2_amd import abi
+from tests.cases import SMALL_CASES, Case
+
+
+def test_library_exports_every_declared_symbol(lib):
+    import re
+    hdr = open(os.path.join(os.path.dirname(abi.HERE), "include", "bamm_em.h")).read()
+    declared = set(re.findall(r"\b(bamm_[a-z0-9_]+)\s*\(", hdr)) - {"bamm_allreduce_fn"}
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.bamm_version()
+
+
+@pytest.mark.parametrize("spec", SMALL_CASES, ids=[d["name"] for d in SMALL_CASES])
+def test_pack_roundtrip_matches_reference_kmers(spec, orc, lib):
+    c = Case(**spec)
+    seq, kmer, off, _ = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    assert pk.n_seqs == c.N and pk.total_len == int(off[-1])
+    for K in (0, 1, 2, 3, 5, 10):
+        y = pk.unpack_y(K)
+        assert np.array_equal(y.astype(np.uint64), kmer % np.uint64(4 ** (K + 1))), K
+    # the same packing straight from the alphabet codes, with the reference's rand() protocol
+    pk2 = bm.PackedSeqs.from_codes(c.codes, c.in_off, c.ss, seed=42)
+    assert np.array_equal(pk2.words, pk.words)
+    assert pk2.n_exceptions == pk.n_exceptions
+    assert np.array_equal(pk2.unpack_y(10), pk.unpack_y(10))
+    if not c.ss:
+        # double-strand: the strand separator is an N in every sequence (Sequence.cpp:10-13)
+        assert pk.n_exceptions >= c.N
+
+
+def test_pack_kmer_ptrs_equals_flat(orc, lib):
+    c = Case(**SMALL_CASES[0])
+    _, kmer, off, _ = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ptrs = (C.c_void_p * c.N)()
+    lens = np.diff(off.astype(np.int64)).astype(np.uint64)
+    kmer = np.ascontiguousarray(kmer)
+    for n in range(c.N):
+        ptrs[n] = kmer.ctypes.data + int(off[n]) * 8
+    out = C.POINTER(abi.Packed)()
+    abi.check(lib.bamm_pack_kmer_ptrs(ptrs, lens, c.N, C.byref(out)))
+    pk2 = bm.PackedSeqs(out)
+    assert np.array_equal(pk2.words, pk.words) and np.array_equal(pk2.unpack_y(10), pk.unpack_y(10))
+
+
+def test_pack_empty_and_tiny(lib):
+    pk = bm.PackedSeqs.from_kmers(np.zeros(0, np.uint64), np.zeros(1, np.uint64))
+    assert pk.n_seqs == 0 and pk.total_len == 0
+    # one sequence of one base (T = 3)
+    pk = bm.PackedSeqs.from_kmers(np.array([3], np.uint64), np.array([0, 1], np.uint64))
+    assert pk.words[0] == 3 << 30 and pk.n_exceptions == 0
+    # 17 bases: second word starts with position 16
+    km = np.zeros(17, np.uint64)
+    roll = 0
+    for i in range(17):
+        roll = ((roll << 2) | (i % 4)) & (4 ** 11 - 1)
+        km[i] = roll
+    pk = bm.PackedSeqs.from_kmers(km, np.array([0, 17], np.uint64))
+    assert len(pk.words) == 2 and pk.n_exceptions == 0
+    assert np.array_equal(pk.unpack_y(10).astype(np.uint64), km)
+
+
+def test_shard_ranges_partition_and_balance(orc, lib):
+    c = Case("rag", N=1000, L0=120, W=12, K=2, ragged=60)
+    _, kmer, off, _ = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    for world in (1, 2, 3, 8):
+        cuts = [pk.shard_range(c.W, r, world) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == c.N
+        for a, b in zip(cuts, cuts[1:]):
+            assert a[1] == b[0]
+        work = [int((pk.lengths[b:e].astype(np.int64) - c.W + 1).sum()) for b, e in cuts]
+        assert max(work) - min(work) <= 2 * (2 * (c.L0 + c.ragged) + 1)
+
+
+def test_calculate_p_matches_oracle(orc, lib):
+    rng = np.random.RandomState(3)
+    for K, W, bgK in ((0, 5, 2), (2, 8, 2), (3, 6, 1), (4, 9, 2)):
+        v = rng.random_sample(bm.v_size(K, W)).astype(np.float32)
+        vbg = rng.random_sample(bm.bg_size(bgK)).astype(np.float32)
+        assert np.array_equal(bm.calculate_p(v, vbg, bgK, K, W), orc.calculate_p(v, vbg, bgK, K, W))
+
+
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(abi.BammError) as e:
+        bm.Context(0)
+    assert e.value.code == abi.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(os.path.dirname(abi.HERE), "bammmotif2_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(root, f), errors="replace").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "bamm_oracle" not in txt, f

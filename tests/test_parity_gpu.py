@@ -1,0 +1,201 @@
+"""Parity of the HIP path (through the C ABI) against the pinned CPU oracle on seeded inputs.
+
+Tolerances: the window products and the odds / log-odds tables are bit-exact by construction
+(same fp32 operation order, IEEE division); the per-sequence partition sum is a wave tree sum
+instead of the reference's sequential fp32 loop and the counts are accumulated per block and
+reduced in fp64, so r / llh / n / v carry summation-order noise only.  The bar BASELINE.json
+states is 1e-5 relative on the learned conditional probabilities.
+"""
+import numpy as np
+import pytest
+
+import bammmotif2_amd as bm
+from tests.cases import SMALL_CASES, Case
+
+pytestmark = pytest.mark.gpu
+
+V_RTOL = 1e-5          # north_star: conditional probabilities within 1e-5 relative
+R_RTOL, R_ATOL = 2e-6, 1e-12
+LLH_RTOL = 2e-6
+
+
+def make_em(ctx, c, orc, **kw):
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(ctx, pk)
+    em = bm.EM(ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, **kw)
+    return em, ss, kmer, off, vbg
+
+
+@pytest.mark.parametrize("spec", SMALL_CASES, ids=[d["name"] for d in SMALL_CASES])
+def test_estep_mstep_match_oracle(spec, gpu_ctx, orc):
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    Kb = min(c.bg_order, c.K)
+    q = c.q
+    for it in range(3):
+        # step-wise parity: every pass starts from the device's own current model, so the
+        # oracle sees exactly the inputs the kernels saw
+        v = em.getV()
+        if it == 0:
+            assert np.array_equal(v, c.v0)
+        em.EStep()
+        s_o = orc.linear_s(v, vbg, c.K, c.W, Kb)
+        assert np.array_equal(em.getS(), s_o)                       # Motif.cpp:485-494, bit-exact
+        r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, q)
+        r_g = em.getR()
+        np.testing.assert_allclose(r_g, r_o, rtol=R_RTOL, atol=R_ATOL)
+        assert np.array_equal(r_g == 0, r_o == 0)                   # unused slots stay exactly zero
+        # log Z_n of a Z_n rounded to fp32 carries ~6e-8 absolute noise per sequence
+        np.testing.assert_allclose(em.getLLH(), llh_o, rtol=LLH_RTOL, atol=5e-7 * c.N)
+        em.MStep()
+        n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
+        np.testing.assert_allclose(em.getCounts(), n_o, rtol=1e-5, atol=1e-6)
+        v_o = orc.update_v(n_o, c.A, vbg, c.K, c.W)
+        np.testing.assert_allclose(em.getV(), v_o, rtol=V_RTOL, atol=1e-9)
+        assert em.getQ() == np.float32(q)                           # MStep never touches q
+    em.close(); ss.close()
+
+
+@pytest.mark.parametrize("spec", SMALL_CASES[:4], ids=[d["name"] for d in SMALL_CASES[:4]])
+def test_iterate_equals_estep_mstep_and_oracle(spec, gpu_ctx, orc):
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+    em.iterate(6)
+    res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=True,
+                       epsilon=0.0, max_iter=6)
+    assert res["iterations"] == 6
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(em.getQ(), res["q"], rtol=1e-5)
+    llh, vd, q = em.trace()
+    np.testing.assert_allclose(llh, res["trace_llh"], rtol=1e-5)
+    np.testing.assert_allclose(vd, res["trace_vdiff"], rtol=1e-3, atol=1e-6)
+    assert em.iteration() == 6
+    em.close(); ss.close()
+
+
+def test_optimize_stopping_rule(gpu_ctx, orc):
+    c = Case(**SMALL_CASES[6])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    it = em.optimize()
+    res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+    # EM.cpp:117-118: the count can only flip when v_diff lands within rounding of epsilon
+    assert abs(it - res["iterations"]) <= 1
+    m = min(it, res["iterations"])
+    llh, vd, _ = em.trace()
+    np.testing.assert_allclose(llh[:m], res["trace_llh"][:m], rtol=2e-5)
+    if it == res["iterations"]:
+        np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-4, atol=1e-8)
+    em.close(); ss.close()
+
+
+def test_optimize_q_entry_point(gpu_ctx, orc):
+    c = Case(**SMALL_CASES[0])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    em.EStep()
+    s_o = orc.linear_s(c.v0, vbg, c.K, c.W, min(c.bg_order, c.K))
+    r_o, _ = orc.estep(kmer, off, c.K, c.W, s_o, c.q)
+    em.optimize_q()
+    np.testing.assert_allclose(em.getQ(), orc.optimize_q(r_o, off, c.W), rtol=1e-5)     # EM.cpp:515
+    em.close(); ss.close()
+
+
+def test_mstep_without_estep_is_a_state_error(gpu_ctx, orc):
+    c = Case(**SMALL_CASES[0])
+    em, ss, *_ = make_em(gpu_ctx, c, orc)
+    with pytest.raises(bm.abi.BammError) as e:
+        em.MStep()
+    assert e.value.code == bm.abi.ERR_STATE
+    em.close(); ss.close()
+
+
+@pytest.mark.parametrize("spec", SMALL_CASES, ids=[d["name"] for d in SMALL_CASES])
+def test_logodds_bit_exact(spec, gpu_ctx, orc):
+    c = Case(**spec)
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(gpu_ctx, pk)
+    s_log = orc.log_s(c.v0, vbg, c.K, c.W, min(c.bg_order, c.K))
+    mops_o, zoops_o, z_o = orc.logodds(kmer, off, c.K, c.W, s_log)
+    mops, zoops, z = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, c.v0, vbg)
+    assert np.array_equal(mops, mops_o)          # same fp32 add order (ScoreSeqSet.cpp:49-54)
+    assert np.array_equal(zoops, zoops_o)
+    assert np.array_equal(z, z_o)                # first arg-max (strict '>', ScoreSeqSet.cpp:59)
+    _, zoops2, z2 = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, c.v0, vbg, want_mops=False)
+    assert np.array_equal(zoops2, zoops_o) and np.array_equal(z2, z_o)
+    ss.close()
+
+
+def test_mask_equals_subset(gpu_ctx, orc):
+    """CV folds (FDR.cpp:49-57) pass a mask over a shared resident set."""
+    c = Case(**SMALL_CASES[0])
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(gpu_ctx, pk)
+    mask = (np.arange(c.N) % 4 != 1).astype(np.uint8)
+    em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, mask=mask)
+    em.iterate(2)
+    keep = np.nonzero(mask)[0]
+    lens = np.diff(off.astype(np.int64))
+    sub_kmer = np.concatenate([kmer[int(off[n]):int(off[n + 1])] for n in keep])
+    sub_off = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.uint64)
+    res = orc.optimize(sub_kmer, sub_off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, epsilon=0.0, max_iter=2)
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
+    em.close(); ss.close()
+
+
+def test_two_shards_with_allreduce_callback_equal_one(gpu_ctx, orc):
+    """Sequences split over two handles + a summing callback == one handle."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    c = Case(**SMALL_CASES[6])
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    b0, e0 = pk.shard_range(c.W, 0, 2)
+    b1, e1 = pk.shard_range(c.W, 1, 2)
+    assert (b0, e1) == (0, c.N) and e0 == b1
+    sa, sb, sall = bm.SeqSet(gpu_ctx, pk, b0, e0), bm.SeqSet(gpu_ctx, pk, b1, e1), bm.SeqSet(gpu_ctx, pk)
+    ea = bm.EM(gpu_ctx, sa, c.K, c.W, vbg, c.A, c.v0, c.q, optimizeQ=True)
+    eb = bm.EM(gpu_ctx, sb, c.K, c.W, vbg, c.A, c.v0, c.q, optimizeQ=True)
+    eall = bm.EM(gpu_ctx, sall, c.K, c.W, vbg, c.A, c.v0, c.q, optimizeQ=True)
+    pa, n = ea.reduce_buffer()
+    pb, _ = eb.reduce_buffer()
+    ha, hb = np.zeros(n), np.zeros(n)
+    for _ in range(3):
+        ea.accumulate(); eb.accumulate()
+        gpu_ctx.sync()
+        assert hip.hipMemcpy(ha.ctypes.data_as(C.c_void_p), C.c_void_p(pa), n * 8, 2) == 0
+        assert hip.hipMemcpy(hb.ctypes.data_as(C.c_void_p), C.c_void_p(pb), n * 8, 2) == 0
+        tot = ha + hb
+        assert hip.hipMemcpy(C.c_void_p(pa), tot.ctypes.data_as(C.c_void_p), n * 8, 1) == 0
+        assert hip.hipMemcpy(C.c_void_p(pb), tot.ctypes.data_as(C.c_void_p), n * 8, 1) == 0
+        ea.update(); eb.update()
+    eall.iterate(3)
+    assert np.array_equal(ea.getV(), eb.getV())                  # redundant, identical updates
+    np.testing.assert_allclose(ea.getV(), eall.getV(), rtol=2e-6, atol=1e-10)
+    np.testing.assert_allclose(ea.getQ(), eall.getQ(), rtol=1e-6)
+    for x in (ea, eb, eall, sa, sb, sall):
+        x.close()
+
+
+def test_empty_set_and_errors(gpu_ctx, orc):
+    pk = bm.PackedSeqs.from_kmers(np.zeros(0, np.uint64), np.zeros(1, np.uint64))
+    ss = bm.SeqSet(gpu_ctx, pk)
+    c = Case(**SMALL_CASES[0])
+    _, _, _, vbg = c.encode(orc)
+    em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q)
+    em.iterate(1)
+    n = em.getCounts()
+    assert np.all(n == 0)
+    # with zero counts updateV returns the prior chain (Motif.h:110-135)
+    v_o = orc.update_v(n, c.A, vbg, c.K, c.W)
+    np.testing.assert_allclose(em.getV(), v_o, rtol=1e-6)
+    em.close(); ss.close()
+    # a sequence shorter than the motif is refused (mainBaMM.cpp:75-83 drops them beforehand)
+    c2 = Case("short", N=4, L0=5, W=8, K=1, ss=True)
+    _, kmer, off, vbg2 = c2.encode(orc)
+    ss2 = bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
+    with pytest.raises(bm.abi.BammError) as e:
+        bm.EM(gpu_ctx, ss2, c2.K, c2.W, vbg2, c2.A, c2.v0, c2.q)
+    assert e.value.code == bm.abi.ERR_ARG
+    ss2.close()
