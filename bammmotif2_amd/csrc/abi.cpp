@@ -82,7 +82,7 @@ struct bamm_em {
     uint32_t* d_iteration = nullptr;
     uint8_t* d_mask = nullptr;
     double* d_red = nullptr;
-    float* d_partial_n = nullptr;
+    unsigned long long* d_partial_n = nullptr;
     double* d_partial_stat = nullptr;
     float* h_status = nullptr;                  // pinned, 8 floats
     uint32_t total_blocks = 0;

@@ -54,7 +54,7 @@ struct EmKernelArgs {
     uint32_t K, W, Y;            // Y = 4^(K+1)
     const float* s;              // device, [W][Y+1], last row entry = neutral element
     const float* q;              // device scalar
-    float*   partial_n;          // [blocks][W*Y] in [j][y] order (this launch's slice)
+    unsigned long long* partial_n;  // [blocks][W*Y] in [j][y] order, 2^-40 fixed point
     double*  partial_stat;       // [blocks][4]: llh, sum_r, n_seqs, unused
     float*   r_out;              // nullable (WRITE_R): reference layout, r_base subtracted
     uint64_t r_base;             // pos_off of the first requested sequence
@@ -94,7 +94,7 @@ int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, u
                   uint32_t threads, hipStream_t st);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
                  hipStream_t st);
-int launch_reduce_partials(const float* partial_n, const double* partial_stat, uint32_t blocks,
+int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks,
                            uint32_t W, uint32_t Y, double* red, hipStream_t st);
 int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint32_t Kbg, float* s,
                   hipStream_t st);

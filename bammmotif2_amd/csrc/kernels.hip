@@ -52,11 +52,21 @@ __device__ __forceinline__ float wave_shr1(float oldv, float x) {
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
                                            0x138, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float wave_shl1(float oldv, float x) {
+[[maybe_unused]] __device__ __forceinline__ float wave_shl1(float oldv, float x) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
                                            0x130, 0xf, 0xf, false));
 }
+__device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x) {   // lane 63 receives 0
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x & 0xffffffffull), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), 0x130, 0xf, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// r in [0,1] -> round(r * 2^40); exact integer accumulation up to 2^24 sequences per block
+__device__ __forceinline__ unsigned long long to_fixed40(float r) {
+    return (unsigned long long)__builtin_rint((double)r * 1099511627776.0);
+}
+constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -112,13 +122,13 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     float* s_lds = lds;                                  // [W][Y+1], row Y = 1.0f
-    float* n_lds = lds + W * Ys;                         // [W][Y]
-    const uint32_t stat_off = (W * Ys + (ACCUM ? W * Y : 0u) + 1u) & ~1u;
-    double* stat_lds = reinterpret_cast<double*>(lds + stat_off);  // [waves][3]
+    const uint32_t n_off = (W * Ys + 1u) & ~1u;          // 8-byte aligned
+    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds + n_off);   // [W][Y], 2^-40 units
+    double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? 2u * W * Y : 0u));  // [waves][3]
 
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s_lds[i] = a.s[i];
     if (ACCUM)
-        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n_lds[i] = 0.0f;
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n_lds[i] = 0ull;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -184,17 +194,23 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         if (ACCUM) {
             // ---- M-step (EM.cpp:236-242): position p, column j receives r(i = p-j), which
             // sits in slot p+(W-1-j): walk j downwards and shift the slots one step per column.
-            float* nj = n_lds + (W - 1u) * Y;
+            // Counts are accumulated as 64-bit fixed point (2^-40 units) with ds_add_u64: LDS
+            // float atomics (ds_add_f32) run ~25x slower on gfx950 (tools/lds_bench.hip), and
+            // integer sums are exact, so the result does not depend on scheduling order.
+            unsigned long long F[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
+            unsigned long long* nj = n_lds + (W - 1u) * Y;
             for (uint32_t j = W;;) {
                 j--;
 #pragma unroll
                 for (int m = 0; m < M; m++)
-                    if (y[m] != Y) atomicAdd(&nj[y[m]], U[m]);
+                    if (y[m] != Y) atomicAdd(&nj[y[m]], F[m]);
                 if (j == 0) break;
-                const float first = U[0];
+                const unsigned long long first = F[0];
 #pragma unroll
-                for (int m = 0; m + 1 < M; m++) U[m] = U[m + 1];
-                U[M - 1] = wave_shl1(0.0f, first);
+                for (int m = 0; m + 1 < M; m++) F[m] = F[m + 1];
+                F[M - 1] = wave_shl1_u64(first);
                 nj -= Y;
             }
         }
@@ -208,7 +224,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     }
     __syncthreads();
     if (ACCUM) {
-        float* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
+        unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
         for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) out[i] = n_lds[i];
     }
     if (threadIdx.x < 3) {
@@ -276,7 +292,7 @@ __global__ void __launch_bounds__(THREADS) k_score(ScoreKernelArgs a) {
 
 // ---- reduce the per-block partial tables (deterministic, fp64) ------------------------------
 // grid.x = ceil(W*Y/64) (+1 block when there are no cells), 1024 threads = 64 cells x 16 groups
-__global__ void __launch_bounds__(1024) k_reduce_partials(const float* partial_n, const double* partial_stat,
+__global__ void __launch_bounds__(1024) k_reduce_partials(const unsigned long long* partial_n, const double* partial_stat,
                                                           uint32_t blocks, uint32_t W, uint32_t Y, double* red) {
     __shared__ double sh[16][64];
     const uint32_t C = partial_n ? W * Y : 0u;
@@ -284,7 +300,7 @@ __global__ void __launch_bounds__(1024) k_reduce_partials(const float* partial_n
     const uint32_t g = threadIdx.x >> 6;
     double acc = 0.0;
     if (c < C)
-        for (uint32_t b = g; b < blocks; b += 16u) acc += (double)partial_n[(size_t)b * C + c];
+        for (uint32_t b = g; b < blocks; b += 16u) acc += (double)partial_n[(size_t)b * C + c];   // exact below 2^53
     sh[g][threadIdx.x & 63u] = acc;
     __syncthreads();
     if (g == 0 && c < C) {
@@ -292,7 +308,7 @@ __global__ void __launch_bounds__(1024) k_reduce_partials(const float* partial_n
 #pragma unroll
         for (int i = 0; i < 16; i++) t += sh[i][threadIdx.x];
         const uint32_t j = c / Y, y = c % Y;               // LDS layout [j][y] -> ABI layout [y][j]
-        red[(size_t)y * W + j] = t;
+        red[(size_t)y * W + j] = t * kFixedScaleInv;
     }
     if (blockIdx.x == 0) {
         __syncthreads();
@@ -456,7 +472,7 @@ void set_em_lds_attr(size_t lds) {
 }  // namespace
 
 size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum) {
-    size_t floats = ((size_t)W * (Y + 1) + (accum ? (size_t)W * Y : 0) + 1) & ~size_t(1);
+    size_t floats = (((size_t)W * (Y + 1) + 1) & ~size_t(1)) + (accum ? 2 * (size_t)W * Y : 0);
     return floats * sizeof(float) + 16 * 3 * sizeof(double);
 }
 
@@ -521,7 +537,7 @@ int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t
     return BAMM_OK;
 }
 
-int launch_reduce_partials(const float* partial_n, const double* partial_stat, uint32_t blocks, uint32_t W,
+int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks, uint32_t W,
                            uint32_t Y, double* red, hipStream_t st) {
     const uint32_t C = partial_n ? W * Y : 0u;
     const uint32_t grid = C ? (C + 63u) / 64u : 1u;

@@ -265,6 +265,49 @@ int bamm_shard_range(const uint32_t* len, uint64_t n_seqs, uint32_t W, uint32_t 
     return BAMM_OK;
 }
 
+// BackgroundModel::BackgroundModel + calculateV restated (init/BackgroundModel.cpp:26-42,
+// :441-473): every position counts once per order with its (k+1)-mer kmer_[i] mod 4^(k+1)
+// (positions i<k see implicit zero digits), then interpolated conditionals.
+int bamm_bg_model(const bamm_packed* p, uint32_t K, const float* alpha, float* vbg_out) {
+    if (!p || !alpha || !vbg_out || K > BAMM_MAX_ORDER) {
+        set_error("bamm_bg_model: bad argument");
+        return BAMM_ERR_ARG;
+    }
+    const uint32_t maskK = (uint32_t)(ipow4(K + 1) - 1);
+    std::vector<uint64_t> top(ipow4(K + 1), 0);               // counts of the highest order
+    std::vector<std::vector<uint64_t>> cnt(K + 1);
+    for (uint64_t n = 0; n < p->n_seqs; n++) {
+        const uint32_t* w = p->words + p->word_off[n];
+        uint64_t e = p->exc_off[n];
+        const uint64_t e1 = p->exc_off[n + 1];
+        uint32_t roll = 0;
+        for (uint32_t i = 0; i < p->len[n]; i++) {
+            const uint32_t base = (w[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
+            roll = (roll << 2) | base;
+            uint32_t y = roll & maskK;
+            if (e < e1 && p->exc_pos[e] == i) { y = p->exc_kmer[e] & maskK; e++; }
+            top[y]++;
+        }
+    }
+    // lower orders: kmer mod 4^(k+1) = y_K mod 4^(k+1)
+    cnt[K] = top;
+    for (uint32_t k = K; k > 0; k--) {
+        cnt[k - 1].assign(ipow4(k), 0);
+        for (size_t y = 0; y < ipow4(k + 1); y++) cnt[k - 1][y % ipow4(k)] += cnt[k][y];
+    }
+    uint64_t base_counts = 0;
+    for (size_t y = 0; y < 4; y++) base_counts += cnt[0][y];
+    for (size_t y = 0; y < 4; y++)
+        vbg_out[y] = ((float)cnt[0][y] + alpha[0] * 0.25f) / ((float)base_counts + alpha[0]);
+    for (uint32_t k = 1; k <= K; k++) {
+        float* vk = vbg_out + bg_offset(k);
+        const float* vk1 = vbg_out + bg_offset(k - 1);
+        for (size_t y = 0; y < ipow4(k + 1); y++)
+            vk[y] = ((float)cnt[k][y] + alpha[k] * vk1[y % ipow4(k)]) / ((float)cnt[k - 1][y / 4] + alpha[k]);
+    }
+    return BAMM_OK;
+}
+
 void bamm_em_default_params(bamm_em_params* p) {
     if (!p) return;
     memset(p, 0, sizeof(*p));

@@ -102,6 +102,14 @@ class PackedSeqs:
         check(self.lib.bamm_unpack_y(self._p, K, out))
         return out[: self.total_len]
 
+    def bg_model(self, K: int, alpha) -> np.ndarray:
+        """BackgroundModel (BackgroundModel.cpp:3-46,441-473) learned from this set."""
+        out = np.zeros(bg_size(K), np.float32)
+        alpha = _f32(alpha)
+        assert len(alpha) >= K + 1
+        check(self.lib.bamm_bg_model(self._p, K, alpha, out))
+        return out
+
     def shard_range(self, W: int, rank: int, world: int):
         b, e = C.c_uint64(0), C.c_uint64(0)
         lens = np.ascontiguousarray(self.lengths, np.uint32)

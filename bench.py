@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""EM-refinement throughput on MI355X: BASELINE.json's metric on BASELINE.json's config.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one EM iteration (EStep + MStep + updateV, /root/reference/src/refinement/EM.cpp:
+81-128) over the whole synthetic set: 1M x 200 bp, W = 20, k = 2, K_bg = 2, double-stranded
+(L = 401), seeded from the planted PWM.  The set is resident in HBM
+(2-bit packed) before the timed region.  With N > 1 (launched by torch.distributed.run, one
+rank per GPU) the SAME 1M sequences are sharded over the ranks ("strong" scaling, the shape
+BASELINE.json names) and the fused count buffer is all-reduced over RCCL once per iteration.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     algorithmic HBM bytes of the sequence kernel / its HIP-event duration vs 8 TB/s
+  cpu_baseline the reference's own EM (oracle/_ref, OpenMP) timed on the host cores on a
+               bounded sample of the same workload (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+ALG_BYTES_PER_POSITION = 0.25  # the 2-bit base is the only per-position HBM read
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--nseq", type=int, default=1_000_000)
+    ap.add_argument("--len", type=int, default=200, dest="L0")
+    ap.add_argument("--width", type=int, default=20)
+    ap.add_argument("--order", type=int, default=2)
+    ap.add_argument("--ss", action="store_true", help="single strand (default: both strands, L = 2*L0+1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="sequences in the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="exercise the RCCL all-reduce path even with one rank (self-test)")
+    return ap.parse_args()
+
+
+class _DevBuf:
+    """Expose a raw device pointer to torch (for dist.all_reduce) without copying."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(codes, in_off, W, K, v0, alpha, q, sample, iters, ss):
+    """The reference's EM::EStep/MStep (compiled in place into oracle/_ref) on the host cores."""
+    import oracle
+    n = min(sample, len(in_off) - 1)
+    sub_off = np.ascontiguousarray(in_off[: n + 1])
+    sub_codes = np.ascontiguousarray(codes[: int(sub_off[-1])])
+    cores = os.cpu_count() or 1
+    alpha_bg = np.array([1.0, 10.0, 10.0], np.float32)
+    if oracle.have_reference():
+        R = oracle.Reference()
+        R.set_threads(cores)
+        S = R.session(sub_codes, sub_off, ss, 42)
+        bg, _ = S.bg(2, alpha_bg)
+        m = S.motif(W, K, alpha, bg, q, v0)
+        em = S.em(m, bg, False, False)
+        S.R.ref_em_estep(em); S.R.ref_em_mstep(em)          # warm-up pass
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            S.R.ref_em_estep(em); S.R.ref_em_mstep(em)
+        dt = time.perf_counter() - t0
+        positions = int(S.off[-1])
+        kind = "reference"
+    else:
+        O = oracle.Oracle()
+        O.set_threads(cores)
+        _, kmer, off = O.encode_set(sub_codes, sub_off, ss, 42)
+        vbg = O.bg_model(kmer, off, 2, alpha_bg)
+        from bammmotif2_amd import synth
+        A = synth.alpha_matrix(alpha, W)
+        O.optimize(kmer, off, K, W, 2, vbg, A, v0, q, epsilon=0.0, max_iter=1)
+        t0 = time.perf_counter()
+        O.optimize(kmer, off, K, W, 2, vbg, A, v0, q, epsilon=0.0, max_iter=iters)
+        dt = time.perf_counter() - t0
+        positions = int(off[-1])
+        kind = "port"
+    return {"value": positions * iters / dt, "unit": "positions/s", "cores": cores, "kind": kind,
+            "iterations_per_s_on_sample": iters / dt,
+            "sample": f"first {n} sequences of the same set, {iters} timed EM iterations "
+                      f"(EStep+MStep), OpenMP on {cores} host threads, -O2"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    import torch.distributed as dist
+    import bammmotif2_amd as bm
+    from bammmotif2_amd import synth, build
+
+    build.build_library()
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    W, K, L0 = args.width, args.order, args.L0
+    pwm = synth.make_pwm(W, 1234)
+    codes, in_off = synth.make_sequences(args.nseq, L0, pwm, 1234, plant_frac=0.5)
+    packed = bm.PackedSeqs.from_codes(codes, in_off, args.ss, seed=42)
+    alpha = synth.default_alpha(K)
+    A = synth.alpha_matrix(alpha, W)
+    vbg = packed.bg_model(2, np.array([1.0, 10.0, 10.0], np.float32))
+    v0 = synth.bamm_from_pwm((0.7 * pwm + 0.3 * 0.25).astype(np.float32), K)
+    q = 0.3
+
+    # one explicit HIP stream shared by the kernels and (through torch) the RCCL all-reduce:
+    # torch's default stream has handle 0, which the C ABI would read as "create your own"
+    tstream = torch.cuda.Stream(device=local_rank)
+    ctx = bm.Context(local_rank, tstream.cuda_stream)
+    if args.blocks or args.threads:
+        ctx.set_launch(args.blocks, args.threads)
+    begin, end = packed.shard_range(W, rank, world)
+    seqs = bm.SeqSet(ctx, packed, begin, end)
+    em = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=args.steps + args.warmup + 8)
+
+    keep = []
+    if use_dist:
+        ptr, n = em.reduce_buffer()
+        red = torch.as_tensor(_DevBuf(ptr, n), device=torch.device("cuda", local_rank))
+        assert red.data_ptr() == ptr and red.dtype == torch.float64 and red.numel() == n
+        keep.append(red)
+
+        def allreduce(_ptr, _n, _stream):
+            with torch.cuda.stream(tstream):   # RCCL waits for the count kernels, the update waits for RCCL
+                dist.all_reduce(red)
+            return 0
+
+        em.set_allreduce(allreduce)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    em.iterate(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    em.iterate(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernel_ms, launches = em.kernel_time()
+    local_positions = int(seqs.off[-1])
+    total_positions = packed.total_len
+    total_windows = int((packed.lengths.astype(np.int64) - W + 1).sum())
+    llh, vdiff, _ = em.trace()
+
+    if rank == 0:
+        its = args.steps / dt
+        avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+        alg_bytes = ALG_BYTES_PER_POSITION * local_positions
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("positions_per_launch") == local_positions:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "EM seq-positions/sec (and iterations/sec), 1Mx200bp k=2 W=20",
+            "value": total_positions * its,
+            "unit": "positions/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "iterations_per_s": its,
+            "windows_per_s": total_windows * its,
+            "config": {"workload": f"{args.nseq}x{L0}bp {'single' if args.ss else 'double'}-strand "
+                                   f"(L={int(packed.lengths[0])}), W={W}, k={K}, K_bg=2, --EM, fixed iteration budget",
+                       "n_seqs": args.nseq, "seq_len": L0, "W": W, "k": K,
+                       "parallelism": f"sequences sharded over {world} GPU(s), 1 all-reduce of "
+                                      f"{4 ** (K + 1) * W + 3} doubles per iteration" if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_em_seq (fused E+M)", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "2-bit stream only; the kernel is LDS-issue bound (DESIGN.md section 5)"},
+            "llh_last": float(llh[-1]) if len(llh) else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(codes, in_off, W, K, v0, alpha, q, args.cpu_sample,
+                                                   args.cpu_iters, args.ss)
+                out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline is a reported number, never a reason to lose the line
+                out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": os.cpu_count(),
+                                       "kind": "unavailable", "sample": repr(e)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    em.close(); seqs.close(); ctx.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -183,6 +183,9 @@ int  bamm_logodds(bamm_ctx* ctx, bamm_seqs* seqs, uint32_t K, uint32_t W, uint32
                   float* zoops, uint64_t* z);
 
 /* ------------------------------------------------------------------ small host helpers -- */
+/* BackgroundModel ctor + calculateV (BackgroundModel.cpp:3-46, :441-473): interpolated
+ * order-K conditionals learned from a packed set; alpha[K+1]; vbg_out[bamm_bg_size(K)].     */
+int  bamm_bg_model(const bamm_packed* p, uint32_t K, const float* alpha, float* vbg_out);
 /* Motif::calculateP (Motif.cpp:430-469); host arithmetic on <= 41k elements.                 */
 int  bamm_calculate_p(const float* v_flat, const float* vbg, uint32_t bg_order, uint32_t K,
                       uint32_t W, float* p_flat);

@@ -40,6 +40,16 @@ def test_pack_roundtrip_matches_reference_kmers(spec, orc, lib):
         assert pk.n_exceptions >= c.N
 
 
+@pytest.mark.parametrize("spec", SMALL_CASES[:4], ids=[d["name"] for d in SMALL_CASES[:4]])
+def test_bg_model_matches_oracle(spec, orc, lib):
+    c = Case(**spec)
+    _, kmer, off, _ = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    for K, alpha in ((0, [1.0]), (2, [1.0, 10.0, 10.0]), (4, [1.0, 10.0, 10.0, 10.0, 10.0])):
+        alpha = np.array(alpha, np.float32)
+        assert np.array_equal(pk.bg_model(K, alpha), orc.bg_model(kmer, off, K, alpha)), K
+
+
 def test_pack_kmer_ptrs_equals_flat(orc, lib):
     c = Case(**SMALL_CASES[0])
     _, kmer, off, _ = c.encode(orc)

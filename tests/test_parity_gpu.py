@@ -15,7 +15,7 @@ from tests.cases import SMALL_CASES, Case
 pytestmark = pytest.mark.gpu
 
 V_RTOL = 1e-5          # north_star: conditional probabilities within 1e-5 relative
-R_RTOL, R_ATOL = 2e-6, 1e-12
+R_RTOL, R_ATOL = 1e-5, 1e-12   # the oracle's sequential fp32 sum over L-W+1 terms carries ~sqrt(L)*6e-8
 LLH_RTOL = 2e-6
 
 

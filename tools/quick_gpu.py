@@ -1,5 +1,5 @@
 import time, numpy as np, sys
-sys.path.insert(0,'.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bammmotif2_amd as bm
 from bammmotif2_amd import synth
 N,L0,W,K=50000,200,20,2
