@@ -87,6 +87,7 @@ struct bamm_em {
     float* h_status = nullptr;                  // pinned, 8 floats
     uint32_t total_blocks = 0;
     std::vector<uint32_t> bucket_blocks;
+    std::vector<uint32_t> bucket_logc;
     uint32_t threads = 0;
     const ExcK* exc = nullptr;
     bool estep_done = false;
@@ -180,6 +181,7 @@ int run_accumulate(bamm_em* em, bool accum) {
         EmKernelArgs a{};
         a.sv = make_view(s, em->exc, bk, em->d_mask);
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
+        a.logC = em->bucket_logc[b];
         a.s = em->d_s; a.q = em->d_q;
         a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
         a.partial_stat = em->d_partial_stat + (size_t)block_base * 4;
@@ -417,9 +419,9 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         return BAMM_ERR_ARG;
     }
     const uint32_t Y = (uint32_t)ipow4(prm->K + 1);
-    if (em_lds_bytes(prm->W, Y, true) > 160 * 1024) {
+    if (em_lds_bytes(prm->W, Y, true, 0) > 160 * 1024) {
         set_error("K=%u W=%u needs %zu bytes of LDS for the fused E+M tables (> 160 KiB): outside this build's envelope",
-                  prm->K, prm->W, em_lds_bytes(prm->W, Y, true));
+                  prm->K, prm->W, em_lds_bytes(prm->W, Y, true, 0));
         return BAMM_ERR_UNSUPPORTED;
     }
     BAMM_HIP(hipSetDevice(c->device));
@@ -467,7 +469,11 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     em->total_blocks = 0;
     for (auto& b : seqs->buckets) {
         const uint32_t threads = default_threads(c, b.mclass);
-        const uint32_t all = default_blocks(c, threads);
+        // 16 waves per CU saturate the LDS pipe (tools/lds_bench2.hip); the LDS left over goes
+        // into private copies of the count table
+        const uint32_t blocks_per_cu = std::max(1u, 1024u / threads);
+        em->bucket_logc.push_back(pick_log_copies(prm->W, Y, blocks_per_cu));
+        const uint32_t all = c->blocks ? c->blocks : (uint32_t)std::max(1, c->num_cus) * blocks_per_cu;
         uint32_t nb = (uint32_t)std::max(1.0, std::floor(all * (b.work / total_work) + 0.5));
         const uint32_t waves_per_block = threads / 64u;
         nb = std::min(nb, (b.count + waves_per_block - 1) / waves_per_block);

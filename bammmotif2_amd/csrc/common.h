@@ -52,6 +52,7 @@ struct SeqView {                 // one length bucket of a resident sequence set
 struct EmKernelArgs {
     SeqView  sv;
     uint32_t K, W, Y;            // Y = 4^(K+1)
+    uint32_t logC;               // log2 of the private count-table copies per block
     const float* s;              // device, [W][Y+1], last row entry = neutral element
     const float* q;              // device scalar
     unsigned long long* partial_n;  // [blocks][W*Y] in [j][y] order, 2^-40 fixed point
@@ -89,7 +90,8 @@ struct UpdateArgs {
 };
 
 // launchers (kernels.hip)
-size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum);
+size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC);
+uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu);
 int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
                   uint32_t threads, hipStream_t st);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,

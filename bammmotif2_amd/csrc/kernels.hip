@@ -123,12 +123,15 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     float* s_lds = lds;                                  // [W][Y+1], row Y = 1.0f
     const uint32_t n_off = (W * Ys + 1u) & ~1u;          // 8-byte aligned
-    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds + n_off);   // [W][Y], 2^-40 units
-    double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? 2u * W * Y : 0u));  // [waves][3]
+    // [W][Y][C] 64-bit fixed point (2^-40 units); C = 2^logC private copies, copy = lane mod C,
+    // cut the same-address serialisation of ds_add_u64 (tools/lds_bench2.hip: 5.6 -> 2.7 ns)
+    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds + n_off);
+    const uint32_t logC = ACCUM ? a.logC : 0u;
+    double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? (2u * W * Y) << logC : 0u));  // [waves][3]
 
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s_lds[i] = a.s[i];
     if (ACCUM)
-        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n_lds[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < (W * Y) << logC; i += blockDim.x) n_lds[i] = 0ull;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -200,18 +203,19 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             unsigned long long F[M];
 #pragma unroll
             for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
-            unsigned long long* nj = n_lds + (W - 1u) * Y;
+            const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+            unsigned long long* nj = n_lds + (((W - 1u) * Y) << logC) + copy;
             for (uint32_t j = W;;) {
                 j--;
 #pragma unroll
                 for (int m = 0; m < M; m++)
-                    if (y[m] != Y) atomicAdd(&nj[y[m]], F[m]);
+                    if (y[m] != Y) atomicAdd(&nj[y[m] << logC], F[m]);
                 if (j == 0) break;
                 const unsigned long long first = F[0];
 #pragma unroll
                 for (int m = 0; m + 1 < M; m++) F[m] = F[m + 1];
                 F[M - 1] = wave_shl1_u64(first);
-                nj -= Y;
+                nj -= Y << logC;
             }
         }
     }
@@ -225,7 +229,11 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     __syncthreads();
     if (ACCUM) {
         unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
-        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) out[i] = n_lds[i];
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) {
+            unsigned long long acc = 0ull;
+            for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[((size_t)i << logC) + c];
+            out[i] = acc;
+        }
     }
     if (threadIdx.x < 3) {
         double acc = 0.0;
@@ -471,9 +479,18 @@ void set_em_lds_attr(size_t lds) {
 
 }  // namespace
 
-size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum) {
-    size_t floats = (((size_t)W * (Y + 1) + 1) & ~size_t(1)) + (accum ? 2 * (size_t)W * Y : 0);
+size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC) {
+    size_t floats = (((size_t)W * (Y + 1) + 1) & ~size_t(1)) + (accum ? (2 * (size_t)W * Y) << logC : 0);
     return floats * sizeof(float) + 16 * 3 * sizeof(double);
+}
+
+// largest number of private count-table copies (power of two <= 16) that still lets
+// `blocks_per_cu` blocks share the 160 KiB of a CU
+uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu) {
+    const size_t budget = (160 * 1024) / (blocks_per_cu ? blocks_per_cu : 1);
+    uint32_t logC = 0;
+    while (logC < 4 && em_lds_bytes(W, Y, true, logC + 1) <= budget) logC++;
+    return logC;
 }
 
 #define BAMM_FOR_EACH_MCLASS(X) \
@@ -483,7 +500,7 @@ size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum) {
 
 int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
                   uint32_t threads, hipStream_t st) {
-    const size_t lds = em_lds_bytes(a.W, a.Y, accum);
+    const size_t lds = em_lds_bytes(a.W, a.Y, accum, a.logC);
     if (lds > 160 * 1024) {
         set_error("odds/count tables need %zu bytes of LDS (> 160 KiB): K=%u W=%u is outside the fused kernel's envelope",
                   lds, a.K, a.W);

@@ -1,0 +1,134 @@
+// LDS micro-benchmarks, round 2: candidate primitives for the E-step gather and the M-step
+// histogram with cheap address streams (2 full-rate VALU per op) so that the LDS pipe is the
+// bottleneck.  Rows are drawn from a 64-row column (k=2) unless stated.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/lds_bench2.hip -o tools/lds_bench2
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+constexpr int ITER = 4000;
+constexpr int UNR = 8;
+
+// per-lane row stream: r[u] <- (r[u] + odd) & 63 : 2 full-rate VALU, rows stay "random-like"
+#define INIT_ROWS                                                       \
+    unsigned r[UNR];                                                    \
+    {                                                                   \
+        unsigned s = (threadIdx.x + 1u) * 2654435761u + blockIdx.x * 40503u; \
+        for (int u = 0; u < UNR; u++) { s = s * 1664525u + 1013904223u; r[u] = (s >> 10) & 63u; } \
+    }                                                                   \
+    const unsigned inc = ((threadIdx.x * 7u + blockIdx.x) | 1u) & 63u;
+#define STEP_ROW(u) r[u] = (r[u] + inc) & 63u
+
+template <int WORDS>  // 1: b32, 2: b64, 4: b128 per row
+__global__ void __launch_bounds__(1024) k_read(float* out, int rows) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < rows * WORDS; i += blockDim.x) lds[i] = 1.0f;
+    __syncthreads();
+    INIT_ROWS
+    float acc = 0.f;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            STEP_ROW(u);
+            if (WORDS == 1) acc += lds[r[u]];
+            if (WORDS == 2) { float2 v = reinterpret_cast<float2*>(lds)[r[u]]; acc += v.x + v.y; }
+            if (WORDS == 4) { float4 v = reinterpret_cast<float4*>(lds)[r[u]]; acc += v.x + v.y + v.z + v.w; }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+// C private copies of the column, copy = lane % C, layout [row][C]
+template <int C, int MODE>  // MODE 0: u32 no-return, 1: u32 with return (carry detect), 2: u64, 3: f64
+__global__ void __launch_bounds__(1024) k_atomic(float* out) {
+    extern __shared__ unsigned lds32[];
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds32);
+    double* ldsd = reinterpret_cast<double*>(lds32);
+    for (int i = threadIdx.x; i < 64 * C * 2 + 64; i += blockDim.x) lds32[i] = 0;
+    __syncthreads();
+    INIT_ROWS
+    const unsigned copy = (threadIdx.x & 63u) % C;
+    unsigned carries = 0;
+    const unsigned x = 0x01000000u + threadIdx.x;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            STEP_ROW(u);
+            const unsigned a = r[u] * C + copy;
+            if (MODE == 0) atomicAdd(&lds32[a], x);
+            if (MODE == 1) {
+                const unsigned old = atomicAdd(&lds32[a], x);
+                if (old + x < old) atomicAdd(&lds32[64 * C + r[u]], 1u);   // rare carry into the high word
+            }
+            if (MODE == 2) atomicAdd(&lds64[a], (unsigned long long)x << 8);
+            if (MODE == 3) atomicAdd(&ldsd[a], 1.0);
+        }
+    }
+    __syncthreads();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)lds32[threadIdx.x] + carries;
+}
+
+__global__ void __launch_bounds__(1024) k_valu(float* out) {
+    INIT_ROWS
+    unsigned acc = 0;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) { STEP_ROW(u); acc += r[u]; }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)acc;
+}
+
+template <class F>
+void run(const char* name, F launch, int blocks, int threads, int cus) {
+    launch();
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a));
+    CHECK(hipEventCreate(&b));
+    CHECK(hipEventRecord(a));
+    for (int rr = 0; rr < 3; rr++) launch();
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    ms /= 3;
+    const double wave_instr = (double)blocks * (threads / 64) * ITER * UNR;
+    printf("%-34s %8.3f ms  %6.2f ns/wave-instr/CU  (%5.1f cyc @2.4GHz)\n", name, ms, ms * 1e6 / (wave_instr / cus),
+           ms * 1e6 / (wave_instr / cus) * 2.4);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    float* d_out;
+    CHECK(hipMalloc(&d_out, 4096 * 1024 * sizeof(float)));
+    for (int wpc = 16; wpc <= 32; wpc += 16) {
+        const int B = cus * (wpc / 16), T = 1024;
+        printf("---- %d waves per CU\n", wpc);
+#define RUNK(NAME, KERNEL, LDS, ...) run(NAME, [&]() { hipLaunchKernelGGL(KERNEL, dim3(B), dim3(T), LDS, 0, __VA_ARGS__); }, B, T, cus)
+        RUNK("valu only", k_valu, 0, d_out);
+        RUNK("read b32  rand64", k_read<1>, 4096, d_out, 64);
+        RUNK("read b64  rand64", k_read<2>, 4096, d_out, 64);
+        RUNK("read b128 rand64", k_read<4>, 4096, d_out, 64);
+        RUNK("atomic u32        C=1", (k_atomic<1, 0>), 16384, d_out);
+        RUNK("atomic u32        C=2", (k_atomic<2, 0>), 16384, d_out);
+        RUNK("atomic u32        C=4", (k_atomic<4, 0>), 16384, d_out);
+        RUNK("atomic u32        C=8", (k_atomic<8, 0>), 16384, d_out);
+        RUNK("atomic u32        C=16", (k_atomic<16, 0>), 16384, d_out);
+        RUNK("atomic u32 rtn+carry C=1", (k_atomic<1, 1>), 16384, d_out);
+        RUNK("atomic u32 rtn+carry C=4", (k_atomic<4, 1>), 16384, d_out);
+        RUNK("atomic u32 rtn+carry C=8", (k_atomic<8, 1>), 16384, d_out);
+        RUNK("atomic u64        C=1", (k_atomic<1, 2>), 16384, d_out);
+        RUNK("atomic u64        C=2", (k_atomic<2, 2>), 16384, d_out);
+        RUNK("atomic u64        C=4", (k_atomic<4, 2>), 16384, d_out);
+        RUNK("atomic u64        C=8", (k_atomic<8, 2>), 16384, d_out);
+        RUNK("atomic u64        C=16", (k_atomic<16, 2>), 16384, d_out);
+        RUNK("atomic f64        C=1", (k_atomic<1, 3>), 16384, d_out);
+        RUNK("atomic f64        C=8", (k_atomic<8, 3>), 16384, d_out);
+    }
+    return 0;
+}
