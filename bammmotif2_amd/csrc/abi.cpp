@@ -79,6 +79,9 @@ struct bamm_em {
     size_t vsz = 0, cells = 0;
     float *d_vbg = nullptr, *d_A = nullptr, *d_v = nullptr, *d_n = nullptr, *d_s = nullptr;
     float *d_q = nullptr, *d_status = nullptr, *d_trace = nullptr;
+    // double buffers: the odds table / q the most recent E pass used stay intact for getR()
+    float *d_s_alt = nullptr, *d_q_alt = nullptr;
+    const float *s_last = nullptr, *q_last = nullptr;
     uint32_t* d_iteration = nullptr;
     uint8_t* d_mask = nullptr;
     double* d_red = nullptr;
@@ -89,6 +92,11 @@ struct bamm_em {
     std::vector<uint32_t> bucket_blocks;
     std::vector<uint32_t> bucket_logc;
     uint32_t threads = 0;
+    // column-sliced path (tables beyond the fused kernel's LDS budget)
+    bool sliced = false;
+    std::vector<std::pair<uint32_t, uint32_t>> e_slices, m_slices;
+    uint32_t m_slice_logc = 0;
+    float* d_state = nullptr;                   // one float per position slot: E-chain state, then r
     const ExcK* exc = nullptr;
     bool estep_done = false;
     float llh_prev = 0.0f;                      // EM.h:61
@@ -170,7 +178,7 @@ int record_event(bamm_em* em, bool start) {
 }
 
 // local E(+M) pass over every length bucket, then the deterministic partial reduction
-int run_accumulate(bamm_em* em, bool accum) {
+int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
     bamm_seqs* s = em->seqs;
     hipStream_t st = em->ctx->stream;
     int rc = record_event(em, true);
@@ -182,17 +190,30 @@ int run_accumulate(bamm_em* em, bool accum) {
         a.sv = make_view(s, em->exc, bk, em->d_mask);
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
         a.logC = em->bucket_logc[b];
-        a.s = em->d_s; a.q = em->d_q;
+        a.s = replay_last ? em->s_last : em->d_s;
+        a.q = replay_last ? em->q_last : em->d_q;
         a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
         a.partial_stat = em->d_partial_stat + (size_t)block_base * 4;
         a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
-        rc = launch_em_seq(bk.mclass, accum, false, a, em->bucket_blocks[b],
-                           default_threads(em->ctx, bk.mclass), st);
+        const uint32_t threads = default_threads(em->ctx, bk.mclass);
+        if (!em->sliced) {
+            rc = launch_em_seq(bk.mclass, accum, false, a, em->bucket_blocks[b], threads, st);
+        } else {
+            a.r_out = em->d_state;
+            for (size_t i = 0; i < em->e_slices.size() && !rc; i++)
+                rc = launch_e_slice(bk.mclass, a, em->e_slices[i].first, em->e_slices[i].second,
+                                    i + 1 == em->e_slices.size(), em->bucket_blocks[b], threads, st);
+            a.logC = em->m_slice_logc;
+            for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
+                rc = launch_m_slice(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second,
+                                    em->bucket_blocks[b], threads, st);
+        }
         if (rc) return rc;
         block_base += em->bucket_blocks[b];
     }
     rc = record_event(em, false);
     if (rc) return rc;
+    if (!replay_last) { em->s_last = em->d_s; em->q_last = em->d_q; }
     if (em->total_blocks == 0) {
         BAMM_HIP(hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), st));
         return BAMM_OK;
@@ -214,12 +235,14 @@ int run_allreduce(bamm_em* em) {
 int run_update(bamm_em* em) {
     UpdateArgs u{};
     u.K = em->prm.K; u.W = em->prm.W; u.Kbg = em->Kbg;
-    u.red = em->d_red; u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s;
-    u.q = em->d_q; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
+    u.red = em->d_red; u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s_alt;
+    u.q = em->d_q; u.q_out = em->d_q_alt; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
     u.iteration = em->d_iteration; u.optimize_q = em->prm.optimize_q;
     u.n_seqs_override = (double)em->prm.n_seqs_global;
     int rc = launch_update(u, em->ctx->stream);
     if (rc) return rc;
+    std::swap(em->d_s, em->d_s_alt);
+    std::swap(em->d_q, em->d_q_alt);
     em->host_iteration++;
     em->estep_done = false;
     return BAMM_OK;
@@ -397,7 +420,7 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_q,
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_red,
-                    (void*)em->d_partial_n, (void*)em->d_partial_stat})
+                    (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt, (void*)em->d_q_alt})
         (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
     for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -419,10 +442,17 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         return BAMM_ERR_ARG;
     }
     const uint32_t Y = (uint32_t)ipow4(prm->K + 1);
-    if (em_lds_bytes(prm->W, Y, true, 0) > 160 * 1024) {
-        set_error("K=%u W=%u needs %zu bytes of LDS for the fused E+M tables (> 160 KiB): outside this build's envelope",
-                  prm->K, prm->W, em_lds_bytes(prm->W, Y, true, 0));
-        return BAMM_ERR_UNSUPPORTED;
+    const size_t kLds = 160 * 1024;
+    const bool sliced = em_lds_bytes(prm->W, Y, true, 0) > kLds;
+    uint32_t e_cols = 0, m_cols = 0;
+    if (sliced) {
+        while (e_cols < prm->W && e_slice_lds_bytes(e_cols + 1, Y) <= kLds) e_cols++;
+        while (m_cols < prm->W && m_slice_lds_bytes(m_cols + 1, Y, 0) <= kLds) m_cols++;
+        if (e_cols == 0 || m_cols == 0) {
+            set_error("K=%u: one column of the odds/count tables (%u rows) exceeds the 160 KiB LDS of a CU; "
+                      "orders above 6 are outside this build's envelope", prm->K, Y);
+            return BAMM_ERR_UNSUPPORTED;
+        }
     }
     BAMM_HIP(hipSetDevice(c->device));
     bamm_em* em = new bamm_em();
@@ -435,6 +465,17 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     em->Kbg = std::min(prm->bg_order, prm->K);           // EM.cpp:23
     em->vsz = v_size(prm->K, prm->W);
     em->cells = (size_t)Y * prm->W;
+    em->sliced = sliced;
+    if (sliced) {
+        auto cut = [&](uint32_t max_cols, std::vector<std::pair<uint32_t, uint32_t>>& out) {
+            const uint32_t n = (prm->W + max_cols - 1) / max_cols, per = (prm->W + n - 1) / n;
+            for (uint32_t j = 0; j < prm->W; j += per) out.emplace_back(j, std::min(prm->W, j + per));
+            return per;
+        };
+        cut(e_cols, em->e_slices);
+        const uint32_t per_m = cut(m_cols, em->m_slices);
+        while (em->m_slice_logc < 4 && m_slice_lds_bytes(per_m, Y, em->m_slice_logc + 1) <= kLds) em->m_slice_logc++;
+    }
     hipStream_t st = c->stream;
     int rc = BAMM_OK;
     auto fail = [&](int code) { bamm_em_destroy(em); return code; };
@@ -444,7 +485,9 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if ((rc = dev_upload(&em->d_v, v_init, em->vsz, st))) return fail(rc);
     if ((rc = dev_alloc(&em->d_n, em->vsz))) return fail(rc);
     if ((rc = dev_alloc(&em->d_s, (size_t)prm->W * (Y + 1)))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_s_alt, (size_t)prm->W * (Y + 1)))) return fail(rc);
     if ((rc = dev_upload(&em->d_q, &prm->q, 1, st))) return fail(rc);
+    if ((rc = dev_upload(&em->d_q_alt, &prm->q, 1, st))) return fail(rc);
     if ((rc = dev_alloc(&em->d_status, 8))) return fail(rc);
     if ((rc = dev_alloc(&em->d_trace, (size_t)em->prm.max_iterations * 3))) return fail(rc);
     if ((rc = dev_alloc(&em->d_iteration, 1))) return fail(rc);
@@ -471,8 +514,8 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         const uint32_t threads = default_threads(c, b.mclass);
         // 16 waves per CU saturate the LDS pipe (tools/lds_bench2.hip); the LDS left over goes
         // into private copies of the count table
-        const uint32_t blocks_per_cu = std::max(1u, 1024u / threads);
-        em->bucket_logc.push_back(pick_log_copies(prm->W, Y, blocks_per_cu));
+        const uint32_t blocks_per_cu = sliced ? 1u : std::max(1u, 1024u / threads);
+        em->bucket_logc.push_back(sliced ? 0u : pick_log_copies(prm->W, Y, blocks_per_cu));
         const uint32_t all = c->blocks ? c->blocks : (uint32_t)std::max(1, c->num_cus) * blocks_per_cu;
         uint32_t nb = (uint32_t)std::max(1.0, std::floor(all * (b.work / total_work) + 0.5));
         const uint32_t waves_per_block = threads / 64u;
@@ -483,7 +526,10 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     }
     if ((rc = dev_alloc(&em->d_partial_n, (size_t)em->total_blocks * em->cells))) return fail(rc);
     if ((rc = dev_alloc(&em->d_partial_stat, (size_t)em->total_blocks * 4))) return fail(rc);
+    if (sliced && (rc = dev_alloc(&em->d_state, (size_t)seqs->total_len))) return fail(rc);
     if ((rc = launch_make_s(em->d_v, em->d_vbg, prm->K, prm->W, em->Kbg, em->d_s, st))) return fail(rc);
+    em->s_last = em->d_s;
+    em->q_last = em->d_q;
     if (hipStreamSynchronize(st) != hipSuccess) { set_error("stream sync failed in bamm_em_create"); return fail(BAMM_ERR_HIP); }
     *out = em;
     return BAMM_OK;
@@ -514,7 +560,7 @@ int bamm_em_mstep(bamm_em* em) {
     // recompute them on the fly while accumulating counts instead of storing N*L floats
     const int32_t oq = em->prm.optimize_q;
     em->prm.optimize_q = 0;                           // EM::MStep never touches q
-    int rc = run_accumulate(em, true);
+    int rc = run_accumulate(em, true, true);          // with the (s, q) the EStep saw, even if q moved since
     if (!rc) rc = run_allreduce(em);
     if (!rc) rc = run_update(em);
     em->prm.optimize_q = oq;
@@ -527,8 +573,10 @@ int bamm_em_optimize_q(bamm_em* em) {
     if (rc) return rc;
     const double nseq = em->prm.n_seqs_global ? (double)em->prm.n_seqs_global : (double)em->h_status[5];
     const float q = (float)((nseq - (double)em->h_status[4] + 1.0) / (nseq + 2.0));   // EM.cpp:515
-    BAMM_HIP(hipMemcpyAsync(em->d_q, &q, sizeof(float), hipMemcpyHostToDevice, em->ctx->stream));
+    // into the other q buffer: the one the last EStep used stays intact for MStep()/getR()
+    BAMM_HIP(hipMemcpyAsync(em->d_q_alt, &q, sizeof(float), hipMemcpyHostToDevice, em->ctx->stream));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
+    std::swap(em->d_q, em->d_q_alt);
     return BAMM_OK;
 }
 
@@ -637,6 +685,24 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
     if (out_cap < total) { set_error("bamm_em_get_r: output holds %llu floats, %llu needed", (unsigned long long)out_cap, (unsigned long long)total); return BAMM_ERR_ARG; }
     if (total == 0) return BAMM_OK;
     hipStream_t st = em->ctx->stream;
+    if (em->sliced) {
+        // the sliced E pass leaves r per position slot p (window start i = p-W+1) in d_state;
+        // the reference's index is L-W-i = L-1-p (EM.cpp:173)
+        uint8_t* saved_mask = em->d_mask;
+        em->d_mask = nullptr;                              // masked-out sequences still have an r
+        const uint32_t used = em->events_used;
+        int rc2 = run_accumulate(em, false, true);
+        em->events_used = used;
+        em->d_mask = saved_mask;
+        if (rc2) return rc2;
+        BAMM_HIP(hipMemcpyAsync(out, em->d_state + base, total * sizeof(float), hipMemcpyDeviceToHost, st));
+        BAMM_HIP(hipStreamSynchronize(st));
+        for (uint64_t n = begin; n < end; n++) {
+            float* r = out + (s->h_pos_off[n] - base);
+            std::reverse(r, r + s->h_len[n]);
+        }
+        return BAMM_OK;
+    }
     float* d_r = nullptr;
     int rc = dev_alloc(&d_r, total);
     if (rc) return rc;
@@ -650,7 +716,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         EmKernelArgs a{};
         a.sv = make_view(s, em->exc, bk, nullptr);        // masked-out sequences still have an r in the reference
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
-        a.s = em->d_s; a.q = em->d_q;
+        a.s = em->s_last; a.q = em->q_last;                 // the E pass the caller last ran (EM.cpp:521)
         a.partial_n = nullptr; a.partial_stat = d_stat;
         a.r_out = d_r; a.r_base = base; a.seq_begin = (uint32_t)begin; a.seq_end = (uint32_t)end;
         rc = launch_em_seq(bk.mclass, false, true, a, em->bucket_blocks[b], default_threads(em->ctx, bk.mclass), st);

@@ -57,7 +57,7 @@ struct EmKernelArgs {
     const float* q;              // device scalar
     unsigned long long* partial_n;  // [blocks][W*Y] in [j][y] order, 2^-40 fixed point
     double*  partial_stat;       // [blocks][4]: llh, sum_r, n_seqs, unused
-    float*   r_out;              // nullable (WRITE_R): reference layout, r_base subtracted
+    float*   r_out;              // WRITE_R: reference layout, r_base subtracted; sliced path: slot-indexed state / r
     uint64_t r_base;             // pos_off of the first requested sequence
     uint32_t seq_begin, seq_end; // WRITE_R range filter (sequence ids)
 };
@@ -80,7 +80,8 @@ struct UpdateArgs {
     float* n;                    // flat counts (all orders)
     float* v;                    // flat conditionals (all orders), updated in place
     float* s;                    // [W][Y+1] linear odds for the next E-step
-    float* q;                    // device scalar
+    float* q;                    // device scalar (input)
+    float* q_out;                // device scalar for the next pass (may alias q)
     float* status;               // [8]: llh, v_diff, q, iteration, ...
     float* trace;                // [cap][3]
     uint32_t trace_cap;
@@ -94,6 +95,12 @@ size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC);
 uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu);
 int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
                   uint32_t threads, hipStream_t st);
+size_t e_slice_lds_bytes(uint32_t cols, uint32_t Y);
+size_t m_slice_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC);
+int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool last, uint32_t blocks,
+                   uint32_t threads, hipStream_t st);
+int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads,
+                   hipStream_t st);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
                  hipStream_t st);
 int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks,

@@ -242,6 +242,140 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     }
 }
 
+
+// ---- column-sliced path (tables that do not fit the fused kernel's LDS budget, e.g. k=4) -----
+// The same two systolic chains, cut into column ranges [j0,j1).  The E-chain state (one float
+// per position slot) travels through HBM between slices; the last E-slice normalises and leaves
+// the responsibilities r(slot) in that buffer.  An M-slice needs no carried state: at column j
+// slot p holds r(p + W-1-j), which it reads straight from the buffer.
+template <int M, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0, uint32_t j1, int last) {
+    extern __shared__ float lds[];
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0;
+    float* s_lds = lds;                                               // [nc][Y+1]
+    double* stat_lds = reinterpret_cast<double*>(lds + ((nc * Ys + 1u) & ~1u));
+    for (uint32_t i = threadIdx.x; i < nc * Ys; i += blockDim.x) s_lds[i] = a.s[(size_t)j0 * Ys + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const float q = *a.q;
+    const float one_minus_q = 1.0f - q;
+    double llh_acc = 0.0, sumr_acc = 0.0;
+    uint32_t seq_cnt = 0;
+    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
+        const uint32_t seq = pick_sequence(a.sv, t);
+        if (a.sv.mask && !a.sv.mask[seq]) continue;
+        const uint32_t L = a.sv.len[seq];
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+        float* state = a.r_out + a.sv.pos_off[seq];
+        uint32_t y[M];
+        decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
+        float U[M];
+        const float* sj = s_lds;
+        uint32_t j = j0;
+        if (j0 == 0) {
+#pragma unroll
+            for (int m = 0; m < M; m++) U[m] = sj[y[m]];
+            j = 1;
+            sj += Ys;
+        } else {
+#pragma unroll
+            for (int m = 0; m < M; m++) U[m] = (p0 + m < L) ? state[p0 + m] : 1.0f;
+        }
+        for (; j < j1; j++, sj += Ys) {
+            const float carry = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+            for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m]];
+            U[0] = carry * sj[y[0]];
+        }
+        if (last) {
+            const float pos_i = q / (float)LW1;
+            float zpart = 0.0f;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                const bool valid = (p + 1u >= W) && (p < L);
+                U[m] = valid ? U[m] * pos_i : 0.0f;
+                zpart += U[m];
+            }
+            const float Z = one_minus_q + wave_sum(zpart);
+#pragma unroll
+            for (int m = 0; m < M; m++) U[m] = U[m] / Z;
+            llh_acc += (double)logf(Z);
+            sumr_acc += 1.0 - (double)one_minus_q / (double)Z;
+            seq_cnt++;
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++)
+            if (p0 + m < L) state[p0 + m] = U[m];
+    }
+    if (lane == 0) {
+        stat_lds[wave * 3 + 0] = llh_acc;
+        stat_lds[wave * 3 + 1] = sumr_acc;
+        stat_lds[wave * 3 + 2] = (double)seq_cnt;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 3) {
+        double acc = 0.0;
+        for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
+        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+    }
+}
+
+template <int M, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0, uint32_t j1) {
+    extern __shared__ float lds[];
+    const uint32_t W = a.W, Y = a.Y, nc = j1 - j0, logC = a.logC;
+    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y][C]
+    for (uint32_t i = threadIdx.x; i < (nc * Y) << logC; i += blockDim.x) n_lds[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
+        const uint32_t seq = pick_sequence(a.sv, t);
+        if (a.sv.mask && !a.sv.mask[seq]) continue;
+        const uint32_t L = a.sv.len[seq];
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+        const float* rs = a.r_out + a.sv.pos_off[seq];
+        uint32_t y[M];
+        decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
+        const uint32_t shift = W - j1;                               // slot offset at column j1-1
+        unsigned long long F[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t slot = p0 + m + shift;
+            F[m] = to_fixed40(slot < L ? rs[slot] : 0.0f);
+        }
+        unsigned long long* nj = n_lds + (((nc - 1u) * Y) << logC) + copy;
+        for (uint32_t j = j1;;) {
+            j--;
+#pragma unroll
+            for (int m = 0; m < M; m++)
+                if (y[m] != Y) atomicAdd(&nj[y[m] << logC], F[m]);
+            if (j == j0) break;
+            const unsigned long long first = F[0];
+#pragma unroll
+            for (int m = 0; m + 1 < M; m++) F[m] = F[m + 1];
+            F[M - 1] = wave_shl1_u64(first);
+            nj -= Y << logC;
+        }
+    }
+    __syncthreads();
+    unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y) + (size_t)j0 * Y;
+    for (uint32_t i = threadIdx.x; i < nc * Y; i += blockDim.x) {
+        unsigned long long acc = 0ull;
+        for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[((size_t)i << logC) + c];
+        out[i] = acc;
+    }
+}
+
 // ---- log-odds scorer ----------------------------------------------------------------------
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_score(ScoreKernelArgs a) {
@@ -429,10 +563,9 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         const uint32_t it = *a.iteration + 1u;
         *a.iteration = it;
         float q = *a.q;
-        if (a.optimize_q && it <= 5u) {                    // EM.cpp:99, :515
+        if (a.optimize_q && it <= 5u)                      // EM.cpp:99, :515
             q = (float)((nseq - sum_r + 1.0) / (nseq + 2.0));
-            *a.q = q;
-        }
+        *a.q_out = q;
         a.status[0] = (float)llh;
         a.status[1] = (float)v_diff;
         a.status[2] = q;
@@ -521,6 +654,52 @@ int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, u
         default:
             set_error("no kernel for M class %d", mclass);
             return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+
+size_t e_slice_lds_bytes(uint32_t cols, uint32_t Y) {
+    return ((((size_t)cols * (Y + 1)) + 1) & ~size_t(1)) * sizeof(float) + 16 * 3 * sizeof(double);
+}
+size_t m_slice_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC) { return (((size_t)cols * Y) << logC) * 8; }
+
+int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool last, uint32_t blocks,
+                   uint32_t threads, hipStream_t st) {
+    const size_t lds = e_slice_lds_bytes(j1 - j0, a.Y);
+    if (lds > 160 * 1024 || j1 <= j0) { set_error("bad E slice [%u,%u)", j0, j1); return BAMM_ERR_UNSUPPORTED; }
+    switch (mclass) {
+#define X(idx, M, T)                                                                                   \
+    case idx:                                                                                          \
+        if (lds > 64 * 1024)                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_e_slice<M, T>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL((k_e_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1, last ? 1 : 0); \
+        break;
+        BAMM_FOR_EACH_MCLASS(X)
+#undef X
+        default: set_error("no kernel for M class %d", mclass); return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads,
+                   hipStream_t st) {
+    const size_t lds = m_slice_lds_bytes(j1 - j0, a.Y, a.logC);
+    if (lds > 160 * 1024 || j1 <= j0) { set_error("bad M slice [%u,%u)", j0, j1); return BAMM_ERR_UNSUPPORTED; }
+    switch (mclass) {
+#define X(idx, M, T)                                                                                   \
+    case idx:                                                                                          \
+        if (lds > 64 * 1024)                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m_slice<M, T>),                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL((k_m_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1);        \
+        break;
+        BAMM_FOR_EACH_MCLASS(X)
+#undef X
+        default: set_error("no kernel for M class %d", mclass); return BAMM_ERR_UNSUPPORTED;
     }
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;

@@ -87,6 +87,16 @@ def run_case(R, c, store_inputs, n_iter=3, r_seqs=None, with_optimize=True):
             out[f"opt{oq}_llh"] = np.float32(S.R.ref_em_llh(e2))
             out[f"opt{oq}_q"] = np.float32(S.R.ref_em_q(e2))
             out[f"opt{oq}_n"] = S.em_n(e2, c.K, c.W)
+            # the reference does not expose its iteration count / per-pass trace; the C oracle is
+            # bit-identical to it (asserted here), so its trace is the reference's trace
+            O = oracle.Oracle()
+            O.set_threads(1)
+            res = O.optimize(kmer, S.off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=bool(oq))
+            assert np.array_equal(res["v"], out[f"opt{oq}_v"]) and np.float32(res["llh"]) == out[f"opt{oq}_llh"]
+            assert np.float32(res["q"]) == out[f"opt{oq}_q"]
+            out[f"opt{oq}_iterations"] = res["iterations"]
+            out[f"opt{oq}_trace_llh"] = res["trace_llh"]
+            out[f"opt{oq}_trace_vdiff"] = res["trace_vdiff"]
     S.close()
     return out
 

@@ -84,4 +84,4 @@ def test_two_ranks_equal_single_process(tmp_path, orc):
     res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=True,
                        epsilon=0.0, max_iter=3)
     np.testing.assert_allclose(v0, res["v"], rtol=1e-5, atol=1e-9)   # fp32 summation-order noise
-    np.testing.assert_allclose(r0[2], res["q"], rtol=1e-6)
+    np.testing.assert_allclose(r0[2], res["q"], rtol=2e-5)

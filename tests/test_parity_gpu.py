@@ -74,6 +74,51 @@ def test_iterate_equals_estep_mstep_and_oracle(spec, gpu_ctx, orc):
     em.close(); ss.close()
 
 
+def test_getR_after_iterate_is_the_last_estep(gpu_ctx, orc):
+    """EM::write / getR() after optimize() see the r of the last EStep, i.e. computed from the
+    model BEFORE the last MStep (EM.cpp:93-96,583-601)."""
+    c = Case(**SMALL_CASES[0])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+    em.iterate(1)
+    v1, q1 = em.getV(), em.getQ()
+    em.iterate(1)
+    s1 = orc.linear_s(v1, vbg, c.K, c.W, min(c.bg_order, c.K))
+    r_o, _ = orc.estep(kmer, off, c.K, c.W, s1, q1)
+    np.testing.assert_allclose(em.getR(), r_o, rtol=R_RTOL, atol=R_ATOL)
+    # EStep(); optimize_q(); MStep() : the MStep still uses the r of that EStep
+    em.EStep()
+    v2, q2 = em.getV(), em.getQ()
+    em.optimize_q()
+    assert em.getQ() != np.float32(q2)
+    em.MStep()
+    s2 = orc.linear_s(v2, vbg, c.K, c.W, min(c.bg_order, c.K))
+    r2, _ = orc.estep(kmer, off, c.K, c.W, s2, q2)
+    v3 = orc.update_v(orc.mstep_counts(kmer, off, c.K, c.W, r2), c.A, vbg, c.K, c.W)
+    np.testing.assert_allclose(em.getV(), v3, rtol=V_RTOL, atol=1e-9)
+    em.close(); ss.close()
+
+
+def test_sliced_path_for_large_tables(gpu_ctx, orc):
+    """k=4, W=30: odds + count tables exceed one CU's LDS -> column-sliced kernels with r in HBM."""
+    c = Case("k4", N=60, L0=300, W=30, K=4, ss=True, ragged=40, n_frac=0.01)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+    v, q = c.v0.copy(), c.q
+    for it in range(2):
+        v = em.getV(); q = em.getQ()
+        em.EStep()
+        s_o = orc.linear_s(v, vbg, c.K, c.W, 2)
+        r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, q)
+        np.testing.assert_allclose(em.getR(), r_o, rtol=R_RTOL, atol=R_ATOL)
+        np.testing.assert_allclose(em.getLLH(), llh_o, rtol=LLH_RTOL, atol=5e-7 * c.N)
+        em.MStep()
+        n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
+        np.testing.assert_allclose(em.getCounts(), n_o, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(em.getV(), orc.update_v(n_o, c.A, vbg, c.K, c.W), rtol=V_RTOL, atol=1e-9)
+    em.iterate(2)
+    assert em.iteration() == 4
+    em.close(); ss.close()
+
+
 def test_optimize_stopping_rule(gpu_ctx, orc):
     c = Case(**SMALL_CASES[6])
     em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
