@@ -64,13 +64,31 @@ __device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x
 }
 // r in [0,1] -> round(r * 2^40); exact integer accumulation up to 2^24 sequences per block
 __device__ __forceinline__ unsigned long long to_fixed40(float r) {
-    return (unsigned long long)__builtin_rint((double)r * 1099511627776.0);
+    // exact power-of-two scalings and an exact split; the last unit (2^-40) is truncated
+    const float a = r * 256.0f;
+    const float hi_f = floorf(a);
+    const uint32_t hi = (uint32_t)hi_f;
+    const uint32_t lo = (uint32_t)((a - hi_f) * 4294967296.0f);
+    return ((unsigned long long)hi << 32) | lo;
 }
 constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// sum over the 64 lanes without touching the LDS pipe: rotate-adds inside each row of 16 lanes
+// (row_ror:8/4/2/1), then the four row sums through SGPRs.  Same value in every lane.
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-    return x;
+    x += dpp_f<0x128>(x);
+    x += dpp_f<0x124>(x);
+    x += dpp_f<0x122>(x);
+    x += dpp_f<0x121>(x);
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 // ---- sequence decode: M consecutive positions of one sequence into registers -------------
@@ -123,15 +141,16 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     float* s_lds = lds;                                  // [W][Y+1], row Y = 1.0f
     const uint32_t n_off = (W * Ys + 1u) & ~1u;          // 8-byte aligned
-    // [W][Y][C] 64-bit fixed point (2^-40 units); C = 2^logC private copies, copy = lane mod C,
-    // cut the same-address serialisation of ds_add_u64 (tools/lds_bench2.hip: 5.6 -> 2.7 ns)
+    // [W][Y+1][C] 64-bit fixed point (2^-40 units); C = 2^logC private copies, copy = lane mod C,
+    // cut the same-address serialisation of ds_add_u64 (tools/lds_bench2.hip: 5.6 -> 2.7 ns).
+    // Row Y of every column is never written (positions beyond LW1 are exec-masked off).
     unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds + n_off);
     const uint32_t logC = ACCUM ? a.logC : 0u;
-    double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? (2u * W * Y) << logC : 0u));  // [waves][3]
+    double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? (2u * W * Ys) << logC : 0u));  // [waves][3]
 
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s_lds[i] = a.s[i];
     if (ACCUM)
-        for (uint32_t i = threadIdx.x; i < (W * Y) << logC; i += blockDim.x) n_lds[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < (W * Ys) << logC; i += blockDim.x) n_lds[i] = 0ull;
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -179,8 +198,9 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             zpart += U[m];
         }
         const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
+        const float invZ = 1.0f / Z;                     // one IEEE division per sequence
 #pragma unroll
-        for (int m = 0; m < M; m++) U[m] = U[m] / Z;     // EM.cpp:185-187
+        for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187 (r/Z within 1 ulp)
         llh_acc += (double)logf(Z);                      // EM.cpp:195
         sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
         seq_cnt++;
@@ -201,21 +221,29 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             // float atomics (ds_add_f32) run ~25x slower on gfx950 (tools/lds_bench.hip), and
             // integer sums are exact, so the result does not depend on scheduling order.
             unsigned long long F[M];
-#pragma unroll
-            for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
+            uint32_t ya[M];
             const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
-            unsigned long long* nj = n_lds + (((W - 1u) * Y) << logC) + copy;
-            for (uint32_t j = W;;) {
-                j--;
 #pragma unroll
-                for (int m = 0; m < M; m++)
-                    if (y[m] != Y) atomicAdd(&nj[y[m] << logC], F[m]);
-                if (j == 0) break;
-                const unsigned long long first = F[0];
+            for (int m = 0; m < M; m++) {
+                F[m] = to_fixed40(U[m]);
+                ya[m] = (y[m] << logC) + copy;
+            }
+            const uint32_t stride = Ys << logC;
+            unsigned long long* nj = n_lds + (W - 1u) * stride;
+            // F is kept as a ring: after t shifts logical slot m lives in F[(m+t) mod M]; the
+            // shift itself is one in-place DPP pair on F[t] (the value leaving becomes the value
+            // arriving from the next lane), so no register moves
+            for (uint32_t jb = 0; jb < W; jb += M) {
 #pragma unroll
-                for (int m = 0; m + 1 < M; m++) F[m] = F[m + 1];
-                F[M - 1] = wave_shl1_u64(first);
-                nj -= Y << logC;
+                for (int t = 0; t < M; t++) {
+                    if (jb + t < W) {
+#pragma unroll
+                        for (int m = 0; m < M; m++)
+                            if (y[m] != Y) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
+                        F[t] = wave_shl1_u64(F[t]);
+                        nj -= stride;
+                    }
+                }
             }
         }
     }
@@ -230,8 +258,9 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     if (ACCUM) {
         unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
         for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) {
+            const uint32_t j = i / Y, yy = i - j * Y;
             unsigned long long acc = 0ull;
-            for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[((size_t)i << logC) + c];
+            for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[(((size_t)j * Ys + yy) << logC) + c];
             out[i] = acc;
         }
     }
@@ -302,8 +331,9 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
                 zpart += U[m];
             }
             const float Z = one_minus_q + wave_sum(zpart);
+            const float invZ = 1.0f / Z;
 #pragma unroll
-            for (int m = 0; m < M; m++) U[m] = U[m] / Z;
+            for (int m = 0; m < M; m++) U[m] = U[m] * invZ;
             llh_acc += (double)logf(Z);
             sumr_acc += 1.0 - (double)one_minus_q / (double)Z;
             seq_cnt++;
@@ -328,9 +358,9 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0, uint32_t j1) {
     extern __shared__ float lds[];
-    const uint32_t W = a.W, Y = a.Y, nc = j1 - j0, logC = a.logC;
-    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y][C]
-    for (uint32_t i = threadIdx.x; i < (nc * Y) << logC; i += blockDim.x) n_lds[i] = 0ull;
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;
+    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y+1][C], row Y = dump
+    for (uint32_t i = threadIdx.x; i < (nc * Ys) << logC; i += blockDim.x) n_lds[i] = 0ull;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -348,30 +378,34 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
         decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
         const uint32_t shift = W - j1;                               // slot offset at column j1-1
         unsigned long long F[M];
+        uint32_t ya[M];
 #pragma unroll
         for (int m = 0; m < M; m++) {
             const uint32_t slot = p0 + m + shift;
             F[m] = to_fixed40(slot < L ? rs[slot] : 0.0f);
+            ya[m] = (y[m] << logC) + copy;
         }
-        unsigned long long* nj = n_lds + (((nc - 1u) * Y) << logC) + copy;
-        for (uint32_t j = j1;;) {
-            j--;
+        const uint32_t stride = Ys << logC;
+        unsigned long long* nj = n_lds + (nc - 1u) * stride;
+        for (uint32_t jb = 0; jb < nc; jb += M) {
 #pragma unroll
-            for (int m = 0; m < M; m++)
-                if (y[m] != Y) atomicAdd(&nj[y[m] << logC], F[m]);
-            if (j == j0) break;
-            const unsigned long long first = F[0];
+            for (int t = 0; t < M; t++) {
+                if (jb + t < nc) {
 #pragma unroll
-            for (int m = 0; m + 1 < M; m++) F[m] = F[m + 1];
-            F[M - 1] = wave_shl1_u64(first);
-            nj -= Y << logC;
+                    for (int m = 0; m < M; m++)
+                        if (y[m] != Y) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
+                    F[t] = wave_shl1_u64(F[t]);
+                    nj -= stride;
+                }
+            }
         }
     }
     __syncthreads();
     unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y) + (size_t)j0 * Y;
     for (uint32_t i = threadIdx.x; i < nc * Y; i += blockDim.x) {
+        const uint32_t j = i / Y, yy = i - j * Y;
         unsigned long long acc = 0ull;
-        for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[((size_t)i << logC) + c];
+        for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[(((size_t)j * Ys + yy) << logC) + c];
         out[i] = acc;
     }
 }
@@ -613,7 +647,7 @@ void set_em_lds_attr(size_t lds) {
 }  // namespace
 
 size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC) {
-    size_t floats = (((size_t)W * (Y + 1) + 1) & ~size_t(1)) + (accum ? (2 * (size_t)W * Y) << logC : 0);
+    size_t floats = (((size_t)W * (Y + 1) + 1) & ~size_t(1)) + (accum ? (2 * (size_t)W * (Y + 1)) << logC : 0);
     return floats * sizeof(float) + 16 * 3 * sizeof(double);
 }
 
@@ -663,7 +697,7 @@ int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, u
 size_t e_slice_lds_bytes(uint32_t cols, uint32_t Y) {
     return ((((size_t)cols * (Y + 1)) + 1) & ~size_t(1)) * sizeof(float) + 16 * 3 * sizeof(double);
 }
-size_t m_slice_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC) { return (((size_t)cols * Y) << logC) * 8; }
+size_t m_slice_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC) { return (((size_t)cols * (Y + 1)) << logC) * 8; }
 
 int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool last, uint32_t blocks,
                    uint32_t threads, hipStream_t st) {
