@@ -238,8 +238,8 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                 for (int t = 0; t < M; t++) {
                     if (jb + t < W) {
 #pragma unroll
-                        for (int m = 0; m < M; m++)
-                            if (y[m] != Y) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
+                        for (int m = 0; m < M; m++)   // adding an exact 0 is a no-op: let those lanes sit out
+                            if (y[m] != Y && F[(m + t) % M] != 0ull) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
                         F[t] = wave_shl1_u64(F[t]);
                         nj -= stride;
                     }
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
                 if (jb + t < nc) {
 #pragma unroll
                     for (int m = 0; m < M; m++)
-                        if (y[m] != Y) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
+                        if (y[m] != Y && F[(m + t) % M] != 0ull) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
                     F[t] = wave_shl1_u64(F[t]);
                     nj -= stride;
                 }

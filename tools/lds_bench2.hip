@@ -21,6 +21,8 @@ constexpr int UNR = 8;
     }                                                                   \
     const unsigned inc = ((threadIdx.x * 7u + blockIdx.x) | 1u) & 63u;
 #define STEP_ROW(u) r[u] = (r[u] + inc) & 63u
+// 320-row variant (pair tables): add an odd step, wrap by conditional subtract (3 VALU)
+#define STEP_ROW320(u) { r[u] += inc320; r[u] = r[u] >= 320u ? r[u] - 320u : r[u]; }
 
 template <int WORDS>  // 1: b32, 2: b64, 4: b128 per row
 __global__ void __launch_bounds__(1024) k_read(float* out, int rows) {
@@ -71,6 +73,31 @@ __global__ void __launch_bounds__(1024) k_atomic(float* out) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (float)lds32[threadIdx.x] + carries;
 }
 
+template <int C, int MODE>  // MODE 0: b32 read, 2: u64 atomic ; 320 rows
+__global__ void __launch_bounds__(1024) k_rows320(float* out) {
+    extern __shared__ unsigned lds32[];
+    unsigned long long* lds64 = reinterpret_cast<unsigned long long*>(lds32);
+    float* ldsf = reinterpret_cast<float*>(lds32);
+    for (int i = threadIdx.x; i < 320 * C * 2; i += blockDim.x) lds32[i] = 0;
+    __syncthreads();
+    INIT_ROWS
+    for (int u = 0; u < UNR; u++) r[u] = (r[u] * 5u + threadIdx.x) % 320u;
+    const unsigned inc320 = 1u + 2u * ((threadIdx.x * 7u + blockIdx.x) % 150u);
+    const unsigned copy = (threadIdx.x & 63u) % C;
+    float acc = 0.f;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            STEP_ROW320(u);
+            const unsigned a = r[u] * C + copy;
+            if (MODE == 0) acc += ldsf[a];
+            if (MODE == 2) atomicAdd(&lds64[a], (unsigned long long)(a + 1) << 8);
+        }
+    }
+    __syncthreads();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)lds32[threadIdx.x] + acc + (float)inc;
+}
+
 __global__ void __launch_bounds__(1024) k_valu(float* out) {
     INIT_ROWS
     unsigned acc = 0;
@@ -106,7 +133,7 @@ int main() {
     const int cus = prop.multiProcessorCount;
     float* d_out;
     CHECK(hipMalloc(&d_out, 4096 * 1024 * sizeof(float)));
-    for (int wpc = 16; wpc <= 32; wpc += 16) {
+    for (int wpc = 16; wpc <= 16; wpc += 16) {
         const int B = cus * (wpc / 16), T = 1024;
         printf("---- %d waves per CU\n", wpc);
 #define RUNK(NAME, KERNEL, LDS, ...) run(NAME, [&]() { hipLaunchKernelGGL(KERNEL, dim3(B), dim3(T), LDS, 0, __VA_ARGS__); }, B, T, cus)
@@ -127,6 +154,10 @@ int main() {
         RUNK("atomic u64        C=4", (k_atomic<4, 2>), 16384, d_out);
         RUNK("atomic u64        C=8", (k_atomic<8, 2>), 16384, d_out);
         RUNK("atomic u64        C=16", (k_atomic<16, 2>), 16384, d_out);
+        RUNK("read b32  rand320", (k_rows320<1, 0>), 320 * 8, d_out);
+        RUNK("atomic u64 rand320 C=1", (k_rows320<1, 2>), 320 * 8, d_out);
+        RUNK("atomic u64 rand320 C=2", (k_rows320<2, 2>), 320 * 16, d_out);
+        RUNK("atomic u64 rand320 C=4", (k_rows320<4, 2>), 320 * 32, d_out);
         RUNK("atomic f64        C=1", (k_atomic<1, 3>), 16384, d_out);
         RUNK("atomic f64        C=8", (k_atomic<8, 3>), 16384, d_out);
     }
