@@ -39,5 +39,33 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+HOST = os.path.join(HERE, "host")
+HOST_LIB = os.path.join(HERE, "libbamm_host.so")
+CLI = os.path.join(HERE, "BaMMmotif")
+HOST_SOURCES = ["io.cpp", "hooks.cpp"]
+
+
+def build_host(force: bool = False, verbose: bool = False):
+    """C++17 host code: libbamm_host.so (test hooks) and the `BaMMmotif` drop-in CLI."""
+    build_library(force=False, verbose=verbose)
+    deps = [os.path.join(HOST, f) for f in HOST_SOURCES + ["main.cpp", "bamm_host.h"]] + [LIB]
+    outs = [HOST_LIB, CLI]
+    if not force and all(os.path.exists(o) for o in outs) and \
+            min(os.path.getmtime(o) for o in outs) >= max(os.path.getmtime(d) for d in deps):
+        return outs
+    cxx = shutil.which("g++") or "g++"
+    common = [cxx, "-std=c++17", "-O2", "-Wall", "-fPIC", "-L" + HERE, "-Wl,-rpath,$ORIGIN"]
+    cmd = common + ["-shared"] + [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-lbamm_em", "-o", HOST_LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    cmd = common + [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "io.cpp"), "-lbamm_em", "-o", CLI]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return outs
+
+
 if __name__ == "__main__":
+    build_host(force=True, verbose=True)
     print(build_library(force=True, verbose=True))

@@ -1,0 +1,88 @@
+// extern "C" test hooks over the C++ host code (libbamm_host.so), so that the CPU test-suite can
+// drive the FASTA reader, the seeders and the model-file writers through ctypes.
+#include <cstring>
+
+#include "bamm_host.h"
+
+using namespace bammhost;
+
+static thread_local std::string g_err;
+
+extern "C" {
+
+const char* bh_last_error(void) { return g_err.c_str(); }
+
+// two-call protocol: first with codes == NULL to get sizes
+int bh_read_fasta(const char* path, uint64_t* n_seqs, uint64_t* n_codes, uint8_t* codes, uint64_t* off, float* base_freq) {
+    FastaSet fs;
+    if (read_fasta(path, fs, g_err)) return 1;
+    *n_seqs = fs.size();
+    *n_codes = fs.codes.size();
+    if (codes) {
+        memcpy(codes, fs.codes.data(), fs.codes.size());
+        memcpy(off, fs.off.data(), fs.off.size() * sizeof(uint64_t));
+        if (base_freq) memcpy(base_freq, fs.base_freq, sizeof fs.base_freq);
+    }
+    return 0;
+}
+
+int bh_write_bg(const char* dir, const char* base, uint32_t K, const float* alpha, const float* v) {
+    BgModel bg;
+    bg.K = K;
+    bg.alpha.assign(alpha, alpha + K + 1);
+    bg.v.assign(v, v + bamm_bg_size(K));
+    return bg_write(dir, base, bg, g_err);
+}
+
+int bh_read_bg(const char* path, uint32_t* K, float* alpha, float* v, uint32_t cap_k) {
+    BgModel bg;
+    if (bg_read(path, bg, g_err)) return 1;
+    if (bg.K > cap_k) { g_err = "order too high for the caller's buffers"; return 1; }
+    *K = bg.K;
+    memcpy(alpha, bg.alpha.data(), bg.alpha.size() * sizeof(float));
+    memcpy(v, bg.v.data(), bg.v.size() * sizeof(float));
+    return 0;
+}
+
+int bh_write_motif(const char* dir, const char* base, uint32_t W, uint32_t K, const float* v, uint32_t bg_order, const float* vbg) {
+    Motif m;
+    std::vector<float> alpha(K + 1, 1.f);
+    motif_alloc(m, W, K, alpha, 0.3f);
+    m.v.assign(v, v + bamm_v_size(K, W));
+    BgModel bg;
+    bg.K = bg_order;
+    bg.v.assign(vbg, vbg + bamm_bg_size(bg_order));
+    motif_calculate_p(m, bg);
+    return motif_write(dir, base, m, g_err);
+}
+
+// seeds: returns the number of motifs; v_out holds motif `index` (flat), w_out its width, q_out its q
+int bh_load_seed(const char* path, const char* tag, uint32_t l_flank, uint32_t r_flank, uint32_t K, const float* alpha,
+                 uint64_t max_pwm, float glob_q, uint32_t bg_order, const float* vbg, const bamm_packed* packed,
+                 uint32_t index, uint32_t* n_motifs, uint32_t* w_out, float* q_out, float* v_out, uint64_t v_cap) {
+    BgModel bg;
+    bg.K = bg_order;
+    bg.v.assign(vbg, vbg + bamm_bg_size(bg_order));
+    std::vector<uint32_t> yK(packed->total_len ? packed->total_len : 1);
+    if (bamm_unpack_y(packed, K, yK.data())) { g_err = bamm_last_error(); return 1; }
+    std::vector<uint64_t> off(packed->n_seqs + 1, 0);
+    for (uint64_t n = 0; n < packed->n_seqs; n++) off[n + 1] = off[n] + packed->len[n];
+    SeedSet seeds;
+    std::vector<float> al(alpha, alpha + K + 1);
+    if (load_seeds(path, tag, l_flank, r_flank, K, al, max_pwm, glob_q, bg, yK.data(), off.data(), packed->n_seqs, seeds, g_err)) return 1;
+    *n_motifs = (uint32_t)seeds.motifs.size();
+    if (index >= seeds.motifs.size()) { g_err = "motif index out of range"; return 1; }
+    const Motif& m = seeds.motifs[index];
+    *w_out = m.W;
+    *q_out = m.q;
+    if (m.v.size() > v_cap) { g_err = "v buffer too small"; return 1; }
+    memcpy(v_out, m.v.data(), m.v.size() * sizeof(float));
+    return 0;
+}
+
+const char* bh_base_name(const char* path) {
+    g_err = base_name(path);
+    return g_err.c_str();
+}
+
+}  // extern "C"

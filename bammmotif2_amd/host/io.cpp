@@ -1,0 +1,408 @@
+// FASTA reader and model-file I/O of the BaMMmotif drop-in path.  See bamm_host.h.
+#include <sys/stat.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <random>
+#include <sstream>
+
+#include "bamm_host.h"
+
+namespace bammhost {
+
+static inline size_t ipow4(size_t e) { return size_t(1) << (2 * e); }
+static inline size_t voff(size_t k, size_t W) { return W * ((ipow4(k + 1) - 4) / 3); }
+static inline size_t bgoff(size_t k) { return (ipow4(k + 1) - 4) / 3; }
+
+std::string base_name(const std::string& path) {
+    // text between the last '/' and the last '.' (refinement/utils.h:66-85)
+    size_t start = 0, end = path.size();
+    const size_t slash = path.find_last_of('/');
+    if (slash != std::string::npos && slash != 0) start = slash + 1;
+    const size_t dot = path.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) end = dot;
+    if (end < start) end = path.size();
+    return path.substr(start, end - start);
+}
+
+static inline uint8_t base_code(char c) {
+    switch (c) {   // Alphabet.cpp:36-40, STANDARD: upper and lower case, everything else is N
+        case 'A': case 'a': return 1;
+        case 'C': case 'c': return 2;
+        case 'G': case 'g': return 3;
+        case 'T': case 't': return 4;
+        default: return 0;
+    }
+}
+
+int read_fasta(const std::string& path, FastaSet& out, std::string& err) {
+    std::ifstream file(path.c_str());
+    if (!file.is_open()) { err = "Error: Cannot open FASTA file: " + path; return 1; }
+    out = FastaSet();
+    out.off.push_back(0);
+    size_t max_len = 0, min_len = SIZE_MAX;
+    size_t counts[4] = {0, 0, 0, 0};
+    std::string line, header, sequence;
+    auto flush = [&]() {
+        if (header.empty()) return;
+        if (sequence.empty()) {
+            fprintf(stderr, "Warning: Ignore FASTA entry without sequence: %s\n", path.c_str());
+            header.clear();
+            return;
+        }
+        const size_t L = sequence.size();
+        max_len = std::max(max_len, L);
+        min_len = std::min(min_len, L);
+        for (char c : sequence) {
+            const uint8_t code = base_code(c);
+            out.codes.push_back(code);
+            if (code) counts[code - 1]++;
+        }
+        out.off.push_back(out.codes.size());
+        out.headers.push_back(header);
+        sequence.clear();
+        header.clear();
+    };
+    while (std::getline(file, line)) {
+        if (line.empty()) continue;                          // blank lines are skipped
+        if (line[0] == '>') {
+            flush();
+            if (line.size() == 1) {
+                header = ">";
+            } else {                                         // up to the first TAB, then up to the first CR
+                header = line.substr(0, line.find('\t'));
+                header = header.substr(0, header.find('\r'));
+            }
+        } else if (!header.empty()) {
+            if (line.find(' ') != std::string::npos) {
+                err = "Error: FASTA sequence contains space character: " + path;
+                return 1;
+            }
+            sequence += line;
+        } else {
+            err = "Error: Wrong FASTA format: " + path;
+            return 1;
+        }
+    }
+    flush();
+    out.max_len = max_len;
+    out.min_len = out.size() ? min_len : 0;
+    const size_t sum = counts[0] + counts[1] + counts[2] + counts[3];
+    for (int i = 0; i < 4; i++) out.base_freq[i] = (float)counts[i] / (float)sum;
+    return 0;
+}
+
+// ------------------------------------------------------------------------- background ----
+int bg_learn(const bamm_packed* p, uint32_t K, const std::vector<float>& alpha, BgModel& out) {
+    out.K = K;
+    out.alpha = alpha;
+    out.v.assign(bamm_bg_size(K), 0.f);
+    return bamm_bg_model(p, K, alpha.data(), out.v.data());
+}
+
+int bg_read(const std::string& path, BgModel& out, std::string& err) {
+    struct stat sb;
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f || stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        if (f) fclose(f);
+        err = "Error: Input Background Model file does not exist.";
+        return 1;
+    }
+    int K = 0;
+    float a = 0;
+    const std::string bad = "Error: Wrong BaMM format: " + path;
+    if (fscanf(f, "# K = %d\n", &K) != 1 || K < 0 || K > BAMM_MAX_ORDER) { fclose(f); err = bad; return 1; }
+    out.K = (uint32_t)K;
+    out.alpha.assign(K + 1, 0.f);
+    if (fscanf(f, "# A = %e", &a) != 1) { fclose(f); err = bad; return 1; }
+    out.alpha[0] = a;
+    for (int k = 1; k <= K; k++) {
+        if (fscanf(f, "%e", &a) != 1) { fclose(f); err = bad; return 1; }
+        out.alpha[k] = a;
+    }
+    out.v.assign(bamm_bg_size(K), 0.f);
+    for (size_t i = 0; i < out.v.size(); i++) {
+        float x;
+        if (fscanf(f, "%e", &x) == EOF) { fclose(f); err = bad; return 1; }
+        out.v[i] = x;
+    }
+    fclose(f);
+    return 0;
+}
+
+int bg_write(const std::string& dir, const std::string& basename, const BgModel& bg, std::string& err) {
+    const uint32_t K = bg.K;
+    {   // conditional probabilities (BackgroundModel.cpp:359-377)
+        std::ofstream file(dir + '/' + basename + ".hbcp");
+        if (!file.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+        file << "# K = " << K << std::endl;
+        file << "# A =";
+        for (uint32_t k = 0; k <= K; k++) file << " " << bg.alpha[k];
+        file << std::endl;
+        for (uint32_t k = 0; k <= K; k++) {
+            for (size_t y = 0; y < ipow4(k + 1); y++)
+                file << std::scientific << std::setprecision(6) << bg.v[bgoff(k) + y] << " ";
+            file << std::endl;
+        }
+    }
+    // joint probabilities p[k][y] = v[k][y] * p[k-1][y/4]  (BackgroundModel.cpp:393-405)
+    std::vector<float> p(bg.v.size());
+    for (size_t y = 0; y < 4; y++) p[y] = bg.v[y];
+    for (uint32_t k = 1; k <= K; k++)
+        for (size_t y = 0; y < ipow4(k + 1); y++) p[bgoff(k) + y] = bg.v[bgoff(k) + y] * p[bgoff(k - 1) + y / 4];
+    std::ofstream file(dir + '/' + basename + ".hbp");
+    if (!file.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+    file << "# K = " << K << std::endl;
+    file << "# A =";
+    for (uint32_t k = 0; k <= K; k++) file << std::fixed << std::setprecision(2) << " " << bg.alpha[k];
+    file << std::endl;
+    for (uint32_t k = 0; k <= K; k++) {
+        for (size_t y = 0; y < ipow4(k + 1); y++)
+            file << std::scientific << std::setprecision(6) << p[bgoff(k) + y] << " ";
+        file << std::endl;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------ motif ----
+void motif_alloc(Motif& m, uint32_t W, uint32_t K, const std::vector<float>& alpha, float q) {
+    m.W = W;
+    m.K = K;
+    m.q = q;
+    m.alpha = alpha;
+    m.A.assign((size_t)(K + 1) * W, 0.f);
+    for (uint32_t k = 0; k <= K; k++)
+        for (uint32_t j = 0; j < W; j++) m.A[(size_t)k * W + j] = alpha[k];
+    m.v.assign(bamm_v_size(K, W), 0.f);
+    m.p.assign(bamm_v_size(K, W), 0.f);
+}
+
+void motif_calculate_p(Motif& m, const BgModel& bg) {
+    bamm_calculate_p(m.v.data(), bg.v.data(), bg.K, m.K, m.W, m.p.data());
+}
+
+// interpolated higher orders from integer counts (Motif.cpp:314-326 / :399-428)
+static void orders_from_counts(Motif& m, const std::vector<int>& n, bool order0_from_counts, size_t C, const BgModel& bg) {
+    const uint32_t W = m.W, K = m.K;
+    if (order0_from_counts)
+        for (size_t y = 0; y < 4; y++)
+            for (uint32_t j = 0; j < W; j++)
+                m.v[y * W + j] = ((float)n[y * W + j] + m.A[j] * bg.v[y]) / ((float)C + m.A[j]);
+    for (uint32_t k = 1; k <= K; k++)
+        for (size_t y = 0; y < ipow4(k + 1); y++) {
+            const size_t y2 = y % ipow4(k), yk = y / 4;
+            for (uint32_t j = 0; j < k && j < W; j++) m.v[voff(k, W) + y * W + j] = m.v[voff(k - 1, W) + y2 * W + j];
+            for (uint32_t j = k; j < W; j++) {
+                const float Ak = m.A[(size_t)k * W + j];
+                m.v[voff(k, W) + y * W + j] = ((float)n[voff(k, W) + y * W + j] + Ak * m.v[voff(k - 1, W) + y2 * W + j]) /
+                                             ((float)n[voff(k - 1, W) + yk * W + j - 1] + Ak);
+            }
+        }
+}
+
+void motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
+                         const uint64_t* off, size_t n_seqs, float q) {
+    const uint32_t W = m.W, K = m.K;
+    m.q = q;
+    std::vector<int> n(bamm_v_size(K, W), 0);
+    for (uint32_t j = 0; j < W; j++) {                       // floor at 1e-8, renormalise (Motif.cpp:205-220)
+        float norm = 0.0f;
+        for (size_t y = 0; y < 4; y++) {
+            const float x = pwm[y * W + j];
+            m.v[y * W + j] = ((double)x <= 1.e-8) ? (float)1.e-8 : x;
+            norm += m.v[y * W + j];
+        }
+        for (size_t y = 0; y < 4; y++) m.v[y * W + j] /= norm;
+    }
+    std::vector<float> score(4 * (size_t)W);
+    for (size_t y = 0; y < 4; y++)
+        for (uint32_t j = 0; j < W; j++) score[y * W + j] = m.v[y * W + j] / bg.v[y];
+    std::mt19937 rngx;                                        // default-seeded on purpose (Motif.cpp:237)
+    std::vector<float> r;
+    for (size_t s = 0; s < n_seqs; s++) {                     // serial: the reference's omp loop shares one RNG
+        const size_t L = off[s + 1] - off[s];
+        if (L < W) continue;                                  // Motif.cpp:240-248
+        const size_t LW1 = L - W + 1;
+        const uint32_t* km = yK + off[s];
+        r.assign(LW1 + 1, 0.f);
+        float normFactor = 0.0f;
+        const float pos0 = 1.0f - q, pos1 = q / (float)LW1;
+        for (size_t i = 1; i <= LW1; i++) {
+            r[i] = 1.0f;
+            for (uint32_t j = 0; j < W; j++) r[i] *= score[(km[i - 1 + j] % 4) * W + j];
+            r[i] *= pos1;
+            normFactor += r[i];
+        }
+        r[0] = pos0;
+        normFactor += r[0];
+        for (size_t i = 0; i <= LW1; i++) r[i] /= normFactor;
+        std::discrete_distribution<size_t> dist(r.begin(), r.end());
+        const size_t z = dist(rngx);
+        if (z > 0)
+            for (uint32_t k = 0; k <= K; k++)
+                for (uint32_t j = 0; j < W; j++) n[voff(k, W) + (km[z - 1 + j] % ipow4(k + 1)) * W + j]++;
+    }
+    orders_from_counts(m, n, false, 0, bg);
+    motif_calculate_p(m, bg);
+}
+
+int motif_init_from_bamm(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,
+                         std::string& err) {
+    std::ifstream file(path.c_str());
+    if (!file.is_open()) { err = "Error: Input BaMM file cannot be opened!"; return 1; }
+    const uint32_t W = m.W, K = m.K;
+    auto flank = [&](uint32_t j) {
+        for (uint32_t k = 0; k <= K; k++)
+            for (size_t y = 0; y < ipow4(k + 1); y++) m.v[voff(k, W) + y * W + j] = 0.25f;
+    };
+    for (uint32_t j = 0; j < l_flank; j++) flank(j);
+    std::string line;
+    for (uint32_t j = l_flank; j + r_flank < W; j++) {        // K+1 lines per position, then one empty line
+        for (uint32_t k = 0; k <= K; k++) {
+            std::getline(file, line);
+            std::stringstream number(line);
+            for (size_t y = 0; y < ipow4(k + 1); y++) number >> m.v[voff(k, W) + y * W + j];
+        }
+        std::getline(file, line);
+    }
+    for (uint32_t j = W - r_flank; j < W; j++) flank(j);
+    motif_calculate_p(m, bg);
+    return 0;
+}
+
+int motif_init_from_sites(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,
+                          std::string& err) {
+    std::ifstream file(path.c_str());
+    if (!file.is_open()) { err = "Error: Cannot open binding sites file: " + path; return 1; }
+    const uint32_t W = m.W, K = m.K;
+    static const char bases[] = "NACGT";
+    std::vector<int> n(bamm_v_size(K, W), 0);
+    size_t C = 0;
+    std::string site;
+    while (std::getline(file, site).good()) {
+        C++;
+        for (uint32_t i = 0; i < l_flank; i++) site.insert(site.begin(), bases[(uint8_t)rand() % 4 + 1]);
+        for (uint32_t i = 0; i < r_flank; i++) site.insert(site.end(), bases[(uint8_t)rand() % 4 + 1]);
+        if (site.size() != W) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "Error: Length of binding site on line %d differs.\nBinding sites should have the same length.", (int)C);
+            err = buf;
+            return 1;
+        }
+        if (site.size() < K + 1) { err = "Error: Length of binding site sequence is shorter than model order."; return 1; }
+        for (uint32_t k = 0; k <= K; k++)
+            for (uint32_t j = k; j < W; j++) {
+                size_t y = 0;
+                for (uint32_t a = 0; a <= k; a++) y += ipow4(a) * (size_t)(base_code(site[j - a]) - 1);
+                n[voff(k, W) + y * W + j]++;
+            }
+    }
+    orders_from_counts(m, n, true, C, bg);
+    motif_calculate_p(m, bg);
+    return 0;
+}
+
+int motif_write(const std::string& dir, const std::string& basename, const Motif& m, std::string& err) {
+    std::ofstream fv(dir + '/' + basename + ".ihbcp"), fp(dir + '/' + basename + ".ihbp");
+    if (!fv.is_open() || !fp.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+    for (uint32_t j = 0; j < m.W; j++) {                      // Motif.cpp:531-546
+        for (uint32_t k = 0; k <= m.K; k++) {
+            for (size_t y = 0; y < ipow4(k + 1); y++) {
+                fv << std::scientific << std::setprecision(3) << m.v[voff(k, m.W) + y * m.W + j] << ' ';
+                fp << std::scientific << std::setprecision(3) << m.p[voff(k, m.W) + y * m.W + j] << ' ';
+            }
+            fv << std::endl;
+            fp << std::endl;
+        }
+        fv << std::endl;
+        fp << std::endl;
+    }
+    return 0;
+}
+
+// -------------------------------------------------------------------------------- seeds ----
+int load_seeds(const std::string& path, const std::string& tag, uint32_t l_flank, uint32_t r_flank, uint32_t K,
+               const std::vector<float>& alpha, size_t max_pwm, float glob_q, const BgModel& bg, const uint32_t* yK,
+               const uint64_t* off, size_t n_seqs, SeedSet& out, std::string& err) {
+    out = SeedSet();
+    std::ifstream file(path.c_str());
+    if (tag == "bindingsites") {
+        if (!file.good()) { err = "Error: Cannot open binding sites file: " + path; return 1; }
+        std::string first;
+        std::getline(file, first);
+        Motif m;
+        motif_alloc(m, (uint32_t)first.size() + l_flank + r_flank, K, alpha, glob_q);
+        if (motif_init_from_sites(m, path, l_flank, r_flank, bg, err)) return 1;
+        out.max_w = m.W;
+        out.motifs.push_back(std::move(m));
+        return 0;
+    }
+    if (tag == "PWM") {
+        if (!file.good()) { err = "Error: Cannot open PWM file: " + path; return 1; }
+        std::string line, row;
+        while (std::getline(file, line)) {
+            if (line.find("letter-probability matrix") == std::string::npos) continue;   // MotifSet.cpp:71
+            size_t asize = 0, length = 0;
+            float q = glob_q;
+            { std::stringstream s(line.substr(line.find("h=") + 2)); s >> asize; }
+            { std::stringstream s(line.substr(line.find("w=") + 2)); s >> length; }
+            if (line.find("occur=") != std::string::npos) {
+                std::stringstream s(line.substr(line.find("occur=") + 7));               // MotifSet.cpp:86 (+7 as is)
+                s >> q;
+            }
+            if (asize != 4) { err = "Error: only the STANDARD alphabet (alength= 4) is supported: " + path; return 1; }
+            length += l_flank + r_flank;
+            Motif m;
+            motif_alloc(m, (uint32_t)length, K, alpha, q);
+            std::vector<float> pwm(4 * length, 0.25f);
+            for (size_t j = l_flank; j + r_flank < length; j++) {
+                if (!std::getline(file, row)) {
+                    err = "Error: Cannot find any PWM in the MEME-format file: " + path + "\nPlease check the content of your input MEME file.";
+                    return 1;
+                }
+                std::stringstream number(row);
+                for (size_t y = 0; y < 4; y++) number >> pwm[y * length + j];
+            }
+            motif_init_from_pwm(m, pwm, bg, yK, off, n_seqs, q);
+            out.max_w = std::max(out.max_w, m.W);
+            out.motifs.push_back(std::move(m));
+            if (out.motifs.size() >= max_pwm) break;
+        }
+        if (out.motifs.empty()) {
+            err = "Error: Cannot find any PWM in the MEME-format file: " + path + "\nPlease check the version of your input MEME file.";
+            return 1;
+        }
+        return 0;
+    }
+    if (tag == "BaMM") {
+        if (!file.good()) { err = "Error: Cannot open BaMM file: " + path; return 1; }
+        size_t model_length = 0, model_order = 0, check_lines = 0;
+        std::string line;
+        while (std::getline(file, line)) {                    // MotifSet.cpp:182-201
+            if (line.empty()) {
+                model_length++;
+                if (model_length > 1 && check_lines != model_order) { err = "This is not a BaMM-format file: " + path; return 1; }
+                check_lines = 0;
+            } else if (model_length == 0) {
+                model_order++;
+            } else {
+                check_lines++;
+            }
+        }
+        model_order -= 1;
+        if (model_order > 8) { err = "The input BaMM model order is too high: " + path; return 1; }
+        Motif m;
+        motif_alloc(m, (uint32_t)(model_length + l_flank + r_flank), K, alpha, glob_q);
+        if (motif_init_from_bamm(m, path, l_flank, r_flank, bg, err)) return 1;
+        out.max_w = m.W;
+        out.motifs.push_back(std::move(m));
+        return 0;
+    }
+    err = "Error: unknown initial model tag " + tag;
+    return 1;
+}
+
+}  // namespace bammhost

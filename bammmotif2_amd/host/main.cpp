@@ -1,0 +1,402 @@
+// BaMMmotif OUTDIR FASTA [options] -- MI355X drop-in for the reference driver
+// (/root/reference/src/refinement/mainBaMM.cpp, Global.cpp).  The EM itself runs on the GPU
+// through the C ABI (include/bamm_em.h); everything here is host plumbing with the reference's
+// flags, defaults, messages and output files.  Not ported (exit with a clear message): --CGS,
+// --FDR, --scoreSeqset, --advanceEM, non-STANDARD alphabets.
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <set>
+
+#include "bamm_host.h"
+
+using namespace bammhost;
+
+namespace {
+
+[[noreturn]] void die(const std::string& msg) {
+    std::cerr << msg << std::endl;
+    exit(1);
+}
+
+[[noreturn]] void die_abi(const char* what) { die(std::string("Error: ") + what + ": " + bamm_last_error()); }
+
+void print_help() {
+    printf("\n==================================================================\n");
+    printf("\n SYNOPSIS:  BaMMmotif OUTDIR SEQFILE [options] \n\n");
+    printf("\t DESCRIPTION \n");
+    printf("\t\t Learn Bayesian inhomogeneous Markov models (BaMMs) from sequence data (EM on an MI355X GPU).\n\n");
+    printf("\t OUTDIR:  output directory for all results. \n");
+    printf("\t SEQFILE: file with sequences from positive set in FASTA format\n\n");
+    printf("\t OPTIONS (same names and defaults as the reference, Global.cpp:142-341):\n");
+    printf("\t\t --basename <STRING> --negSeqFile <FILE> --ss --alphabet STANDARD\n");
+    printf("\t\t --bindingSiteFile <FILE> | --PWMFile <FILE> | --BaMMFile <FILE>   --maxPWM <INT>\n");
+    printf("\t\t -k, --order <INT> (2)   -a, --alpha <FLOAT>..   -b, --beta <FLOAT> (7)   -r, --gamma <FLOAT> (3)\n");
+    printf("\t\t --extend <INT> [<INT>]   --bgModelFile <FILE>   -K, --Order <INT> (2)   -A, --Alpha <FLOAT>..\n");
+    printf("\t\t --EM   -q <FLOAT> (0.3)   --optimizeQ   --verbose   --saveBaMMs   --saveInitialBaMMs\n");
+    printf("\t EXTENSIONS of this build:\n");
+    printf("\t\t --maxEMIterations <INT> (1000)   -e, --epsilon <FLOAT> (0.01)   --device <INT> (0)\n");
+    printf("\n==================================================================\n");
+}
+
+// Tokeniser in the spirit of getopt_pp (src/getopt_pp/getopt_pp.cpp:71-141): "--long", "-s", combined
+// short flags, values = following tokens that do not look like options (negative numbers do not).
+struct Args {
+    std::map<std::string, std::vector<std::string>> longs;
+    std::map<char, std::vector<std::string>> shorts;
+    std::set<std::string> used_long;
+    std::set<char> used_short;
+
+    static bool looks_like_option(const std::string& t) {
+        if (t.size() < 2 || t[0] != '-') return false;
+        if (isdigit((unsigned char)t[1]) || t[1] == '.') return false;      // -3, -.5 are values
+        return true;
+    }
+    Args(int n, char** v) {
+        std::vector<std::string>* cur = nullptr;
+        for (int i = 1; i < n; i++) {
+            std::string t = v[i];
+            if (looks_like_option(t)) {
+                if (t[1] == '-') {
+                    cur = &longs[t.substr(2)];
+                } else {
+                    for (size_t c = 1; c < t.size(); c++) cur = &shorts[t[c]];
+                }
+            } else if (cur) {
+                cur->push_back(t);
+            }
+        }
+    }
+    bool present(char s, const std::string& l) {
+        bool p = false;
+        if (s && shorts.count(s)) { used_short.insert(s); p = true; }
+        if (!l.empty() && longs.count(l)) { used_long.insert(l); p = true; }
+        return p;
+    }
+    const std::vector<std::string>* values(char s, const std::string& l) {
+        if (s && shorts.count(s)) { used_short.insert(s); return &shorts[s]; }
+        if (!l.empty() && longs.count(l)) { used_long.insert(l); return &longs[l]; }
+        return nullptr;
+    }
+    template <class T>
+    bool get(char s, const std::string& l, T& out) {
+        const auto* v = values(s, l);
+        if (!v || v->empty()) return false;
+        std::stringstream ss((*v)[0]);
+        T tmp;
+        if (!(ss >> tmp)) die("Error: bad value for option " + (l.empty() ? std::string(1, s) : l));
+        out = tmp;
+        return true;
+    }
+    bool get_str(char s, const std::string& l, std::string& out) {
+        const auto* v = values(s, l);
+        if (!v || v->empty()) return false;
+        out = (*v)[0];
+        return true;
+    }
+    template <class T>
+    bool get_vec(char s, const std::string& l, std::vector<T>& out) {
+        const auto* v = values(s, l);
+        if (!v) return false;
+        for (const auto& t : *v) { std::stringstream ss(t); T x; if (ss >> x) out.push_back(x); }
+        return true;
+    }
+    bool remain() const {
+        for (auto& kv : longs) if (!used_long.count(kv.first)) return true;
+        for (auto& kv : shorts) if (!used_short.count(kv.first)) return true;
+        return false;
+    }
+};
+
+struct Options {                       // Global.cpp:6-96 defaults
+    std::string out_dir, fasta, basename, neg_fasta, alphabet = "STANDARD";
+    std::string seed_file, seed_tag, bg_file;
+    bool ss = false, EM = false, CGS = false, FDR = false, score = false, verbose = false;
+    bool optimizeQ = false, advanceEM = false, saveBaMMs = true, saveInitial = false, mops = false, zoops = true;
+    size_t maxPWM = std::numeric_limits<size_t>::max();
+    uint32_t K = 2, Kbg = 2;
+    std::vector<float> alpha{1.f, 1.f, 1.f}, alpha_bg{1.f, 1.f, 1.f};
+    float beta = 7.0f, gamma = 3.0f, q = 0.3f, f = 0.05f, epsilon = 0.01f;
+    std::vector<size_t> extend{0, 0};
+    size_t cvFold = 4, mFold = 1, sOrder = 2, threads = 4;
+    uint32_t max_iter = 1000;
+    int device = 0;
+};
+
+template <class T>
+void fit(std::vector<T>& v, size_t n) {     // Global.cpp:210-223: truncate or pad with the last value
+    if (v.size() > n) v.resize(n);
+    else if (v.size() < n) v.resize(n, v.empty() ? T(1) : v.back());
+}
+
+Options parse(int nargs, char** args) {
+    if (nargs < 3) {
+        std::cerr << "Error: Arguments are missing! \n" << std::endl;
+        print_help();
+        exit(1);
+    }
+    Options o;
+    o.out_dir = args[1];
+    struct stat st;
+    if (stat(o.out_dir.c_str(), &st) != 0) {                 // utils.h:154-165
+        std::cout << "New output directory is created automatically.\n";
+        if (system(("mkdir -p " + o.out_dir).c_str()) != 0) {
+            std::cerr << "Error: Directory " << o.out_dir << " could not be created." << std::endl;
+            exit(-1);
+        }
+    }
+    o.fasta = args[2];
+    Args a(nargs - 2, args + 2);                              // the FASTA path plays argv[0] (Global.cpp:142)
+    if (a.present('h', "help")) { print_help(); exit(1); }
+    if (!a.get_str(0, "basename", o.basename)) o.basename = base_name(o.fasta);
+    a.present(0, "maskPosSequenceSet");
+    if (!a.get_str(0, "negSeqFile", o.neg_fasta)) o.neg_fasta = o.fasta;
+    a.present(0, "genericNeg");
+    a.get_str(0, "alphabet", o.alphabet);
+    o.ss = a.present(0, "ss");
+    { std::string tmp; a.get_str(0, "intensityFile", tmp); }
+    if (a.get_str(0, "bindingSiteFile", o.seed_file)) o.seed_tag = "bindingsites";
+    else if (a.get_str(0, "PWMFile", o.seed_file)) o.seed_tag = "PWM";
+    else if (a.get_str(0, "BaMMFile", o.seed_file)) o.seed_tag = "BaMM";
+    else { fprintf(stderr, "Error: No initial model is provided.\n"); exit(1); }
+    a.get(0, "maxPWM", o.maxPWM);
+    o.mops = a.present(0, "mops");
+    a.get(0, "zoops", o.zoops);
+    a.get('k', "order", o.K);
+    if (a.present('a', "alpha")) {
+        o.alpha.clear();
+        a.get_vec('a', "alpha", o.alpha);
+        fit(o.alpha, o.K + 1);
+    } else {
+        fit(o.alpha, o.K + 1);
+        a.get('b', "beta", o.beta);
+        a.get('r', "gamma", o.gamma);
+        for (uint32_t k = 1; k <= o.K; k++) o.alpha[k] = o.beta * powf(o.gamma, (float)k);   // Global.cpp:227-232
+    }
+    if (a.present(0, "extend")) {
+        o.extend.clear();
+        a.get_vec(0, "extend", o.extend);
+        if (o.extend.size() < 1 || o.extend.size() > 2) { fprintf(stderr, "--extend format error.\n"); exit(1); }
+        if (o.extend.size() == 1) o.extend.resize(2, o.extend.back());
+    }
+    a.get_str(0, "bgModelFile", o.bg_file);
+    a.get('K', "Order", o.Kbg);
+    if (a.present('A', "Alpha")) {
+        o.alpha_bg.clear();
+        a.get_vec('A', "Alpha", o.alpha_bg);
+        fit(o.alpha_bg, o.Kbg + 1);
+    } else {
+        fit(o.alpha_bg, o.Kbg + 1);
+        for (uint32_t k = 1; k <= o.Kbg; k++) o.alpha_bg[k] = 10.0f;                           // Global.cpp:274-278
+    }
+    o.EM = a.present(0, "EM");
+    if ((o.CGS = a.present(0, "CGS"))) {
+        for (const char* n : {"noInitialZ", "noAlphaOpti", "GibbsMH", "dissample", "noZSampling", "noQSampling"}) a.present(0, n);
+    }
+    a.present(0, "debugAlphas");
+    a.present(0, "generatePseudoSet");
+    a.get('q', "", o.q);
+    a.get('f', "", o.f);
+    if ((o.FDR = a.present(0, "FDR"))) {
+        a.get('m', "mFold", o.mFold);
+        a.get('n', "cvFold", o.cvFold);
+        a.get('s', "sOrder", o.sOrder);
+    }
+    o.score = a.present(0, "scoreSeqset");
+    { float x; a.get(0, "pvalCutoff", x); }
+    o.verbose = a.present(0, "verbose");
+    a.present(0, "debug");
+    o.saveBaMMs = a.present(0, "saveBaMMs");                  // presence overwrites the default (getopt_pp.h:497)
+    o.saveInitial = a.present(0, "saveInitialBaMMs");
+    { bool x; a.get(0, "savePRs", x); }
+    for (const char* n : {"savePvalues", "saveLogOdds", "saveBgModel", "makeMovie", "B2", "B3", "B3prime"}) a.present(0, n);
+    o.optimizeQ = a.present(0, "optimizeQ");
+    o.advanceEM = a.present(0, "advanceEM");
+    a.get(0, "threads", o.threads);
+    // extensions of this build (the reference advertises but never parses the first two, Global.cpp:479-491)
+    a.get(0, "maxEMIterations", o.max_iter);
+    a.get('e', "epsilon", o.epsilon);
+    a.get(0, "device", o.device);
+    if (a.remain()) {
+        print_help();
+        std::cerr << "Oops! Unknown option(s) remaining... \n\n";
+        exit(1);
+    }
+    return o;
+}
+
+}  // namespace
+
+int main(int nargs, char* args[]) {
+    auto t0_wall = std::chrono::high_resolution_clock::now();
+    std::cout << std::endl
+              << "======================================" << std::endl
+              << "=      Welcome to use BaMM!motif     =" << std::endl
+              << "=                   Version 2.0      =" << std::endl
+              << "=     MI355X build (bammmotif2_amd)  =" << std::endl
+              << "======================================" << std::endl;
+    srand(42);                                               // mainBaMM.cpp:22
+    Options o = parse(nargs, args);
+    if (o.alphabet != "STANDARD") die("Error: this build supports --alphabet STANDARD only.");
+    if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
+    if (o.FDR || o.score) die("Error: --FDR / --scoreSeqset are not ported yet (SURVEY.md section 8f).");
+    if (o.advanceEM) die("Error: --advanceEM is not ported.");
+    if (o.K > BAMM_MAX_ORDER) die("Error: model order above 10 is not supported (kmer_ spans 11 bases).");
+
+    std::string err;
+    FastaSet pos;
+    if (read_fasta(o.fasta, pos, err)) die(err);
+    if (pos.size() < o.cvFold) die("Error: Input sequences are too few for training! \n");
+    bamm_packed* packed = nullptr;
+    if (bamm_pack_codes(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, &packed)) die_abi("packing sequences");
+
+    if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
+    BgModel bg;
+    if (o.bg_file.empty()) {
+        if (bg_learn(packed, o.Kbg, o.alpha_bg, bg)) die_abi("background model");
+    } else if (bg_read(o.bg_file, bg, err)) {
+        die(err);
+    }
+    if (bg_write(o.out_dir, o.basename, bg, err)) die(err);   // always saved (mainBaMM.cpp:51)
+
+    if (o.verbose) std::cout << std::endl << "***************************" << std::endl << "*   Initial Motif Model   *" << std::endl << "***************************" << std::endl;
+    std::vector<uint32_t> yK(packed->total_len ? packed->total_len : 1);
+    if (bamm_unpack_y(packed, o.K, yK.data())) die_abi("unpack");
+    std::vector<uint64_t> off(pos.size() + 1, 0);
+    for (size_t n = 0; n < pos.size(); n++) off[n + 1] = off[n] + packed->len[n];
+    SeedSet seeds;
+    // MotifSet hands Global::bgModelOrder and the model's v to every Motif (mainBaMM.cpp:60-70)
+    if (load_seeds(o.seed_file, o.seed_tag, (uint32_t)o.extend[0], (uint32_t)o.extend[1], o.K, o.alpha, o.maxPWM, o.q, bg,
+                   yK.data(), off.data(), pos.size(), seeds, err)) die(err);
+
+    // drop sequences shorter than the widest motif (mainBaMM.cpp:75-83)
+    std::vector<uint8_t> keep(pos.size(), 1);
+    size_t posN = 0;
+    for (size_t n = 0; n < pos.size(); n++) { keep[n] = packed->len[n] >= seeds.max_w; posN += keep[n]; }
+    if (posN < o.cvFold) { std::cerr << "There are " << posN << " sequences longer than input motif. Exit!\n"; exit(1); }
+
+    if (o.verbose) std::cout << std::endl << "*********************" << std::endl << "*   BaMM Training   *" << std::endl << "*********************" << std::endl;
+    bamm_ctx* ctx = nullptr;
+    bamm_seqs* dseqs = nullptr;
+    if (o.EM) {
+        if (bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
+        bamm_packed* use = packed;
+        bamm_packed* filtered = nullptr;
+        if (posN != pos.size()) {                            // re-pack only the kept records; kmers are position-local
+            std::vector<uint64_t> kept_off{0};
+            std::vector<uint64_t> km;
+            std::vector<uint32_t> y10(packed->total_len);
+            bamm_unpack_y(packed, BAMM_MAX_ORDER, y10.data());
+            for (size_t n = 0; n < pos.size(); n++)
+                if (keep[n]) { for (uint64_t i = off[n]; i < off[n + 1]; i++) km.push_back(y10[i]); kept_off.push_back(km.size()); }
+            if (bamm_pack_kmers(km.data(), kept_off.data(), kept_off.size() - 1, &filtered)) die_abi("re-pack");
+            use = filtered;
+        }
+        if (bamm_seqs_upload(ctx, use, 0, use->n_seqs, &dseqs)) die_abi("upload");
+        if (filtered) bamm_packed_free(filtered);
+    }
+
+    for (size_t n = 0; n < seeds.motifs.size(); n++) {
+        Motif motif = seeds.motifs[n];                       // deep copy (mainBaMM.cpp:121)
+        const std::string mbase = o.basename + "_motif_" + std::to_string(n + 1);
+        if (o.saveInitial && motif_write(o.out_dir, o.basename + "_init_motif_" + std::to_string(n + 1), motif, err)) die(err);
+        if (o.EM) {
+            auto t0 = std::chrono::high_resolution_clock::now();
+            bamm_em_params p;
+            bamm_em_default_params(&p);
+            p.K = motif.K; p.W = motif.W; p.bg_order = bg.K; p.q = motif.q; p.optimize_q = o.optimizeQ;
+            p.epsilon = o.epsilon; p.max_iterations = o.max_iter;
+            bamm_em* em = nullptr;
+            if (bamm_em_create(ctx, dseqs, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &em)) die_abi("EM");
+            uint32_t it = 0;
+            if (bamm_em_optimize(em, &it)) die_abi("EM::optimize");
+            if (bamm_em_get_v(em, motif.v.data())) die_abi("get_v");
+            float q = 0;
+            bamm_em_get_q(em, &q);
+            motif.q = q;
+            if (o.verbose) {                                 // the lines EM.cpp:112-115 prints
+                std::vector<float> llh(it), vd(it), qq(it);
+                uint32_t cnt = 0;
+                bamm_em_get_trace(em, llh.data(), vd.data(), qq.data(), it, &cnt);
+                for (uint32_t i = 0; i < cnt && i < it; i++) {
+                    if (o.optimizeQ && i < 5) std::cout << "optimized q=" << qq[i] << std::endl;
+                    std::cout << i + 1 << " iter, llh=" << llh[i] << ", diff_llh=" << llh[i] - (i ? llh[i - 1] : 0.f)
+                              << ", v_diff=" << vd[i] << std::endl;
+                }
+            }
+            motif_calculate_p(motif, bg);
+            auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0);
+            std::cout << "\n--- Runtime for EM: " << dt.count() << " seconds ---\n";        // EM.cpp:134
+            if (o.saveBaMMs) {                                // EM::write (EM.cpp:553-601)
+                std::vector<float> cnts(bamm_v_size(motif.K, motif.W));
+                bamm_em_get_counts(em, cnts.data());
+                std::ofstream fn(o.out_dir + '/' + mbase + ".counts");
+                for (uint32_t j = 0; j < motif.W; j++) {
+                    for (uint32_t k = 0; k <= motif.K; k++) {
+                        for (size_t y = 0; y < (size_t(1) << (2 * (k + 1))); y++)
+                            fn << static_cast<int>(cnts[bamm_v_offset(k, motif.W) + y * motif.W + j]) << '\t';
+                        fn << std::endl;
+                    }
+                    fn << std::endl;
+                }
+                uint64_t ns = 0, total = 0;
+                bamm_seqs_info(dseqs, &ns, &total, nullptr, nullptr);
+                std::vector<float> r(total ? total : 1);
+                if (bamm_em_get_r(em, 0, ns, r.data(), total)) die_abi("getR");
+                std::ofstream fp(o.out_dir + '/' + mbase + ".positions");
+                fp << "seq\tlength\tstrand\tstart..end\tpattern" << std::endl;
+                static const char B[] = "NACGT";
+                uint64_t ro = 0;
+                for (size_t s = 0; s < pos.size(); s++) {
+                    if (!keep[s]) continue;
+                    const size_t Lfull = packed->len[s], L0 = pos.off[s + 1] - pos.off[s];
+                    const size_t Lshown = o.ss ? Lfull : (Lfull - 1) / 2;
+                    for (size_t i = 0; i + motif.W <= Lfull; i++) {
+                        if (r[ro + Lfull - motif.W - i] >= 0.3f) {
+                            fp << pos.headers[s] << '\t' << Lshown << '\t' << ((i < Lshown) ? '+' : '-') << '\t' << i + 1 << ".." << i + motif.W << '\t';
+                            for (size_t b = i; b < i + motif.W; b++) {
+                                uint8_t code;                 // Sequence::getSequence(): forward, N, reverse complement
+                                if (b < L0) code = pos.codes[pos.off[s] + b];
+                                else if (o.ss || b == L0) code = 0;
+                                else { const uint8_t c = pos.codes[pos.off[s] + (2 * L0 - b)]; code = (c >= 1 && c <= 4) ? (uint8_t)(5 - c) : 0; }
+                                fp << B[code];
+                            }
+                            fp << std::endl;
+                        }
+                    }
+                    ro += Lfull;
+                }
+            }
+            std::cout << "optimized q = " << q << std::endl;   // mainBaMM.cpp:147
+            bamm_em_destroy(em);
+        } else {
+            std::cout << "Note: the model is not optimized!\n";
+        }
+        if (motif_write(o.out_dir, mbase, motif, err)) die(err);
+    }
+
+    std::cout << std::endl << "******************" << std::endl << "*   Statistics   *" << std::endl << "******************" << std::endl;
+    std::cout << "Alphabet type is ACGT";                     // Global::printStat (Global.cpp:346-392)
+    std::cout << "\nGiven initial model is " << base_name(o.seed_file) << ", BaMM order: " << o.K << ", bgmodel order: " << o.Kbg;
+    std::cout << "\nBaMM is learned from " << (o.ss ? "single-stranded sequences." : "double-stranded sequences.");
+    std::cout << "\nGiven positive sequence set is " << o.basename << ".\n	" << pos.size() << " sequences, max.length: " << pos.max_len
+              << ", min.length: " << pos.min_len << "\n	base frequencies:";
+    for (int i = 0; i < 4; i++) std::cout << ' ' << pos.base_freq[i] << "(" << "ACGT"[i] << ")";
+    std::cout << "\nThe background model is generated based on cond.prob of " << o.sOrder << "-mers.";
+    auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0_wall);
+    std::cout << std::endl << "------ Runtime: " << dt.count() << " seconds -------" << std::endl;
+
+    if (dseqs) bamm_seqs_destroy(dseqs);
+    if (ctx) bamm_ctx_destroy(ctx);
+    bamm_packed_free(packed);
+    return 0;
+}

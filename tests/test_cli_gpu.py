@@ -1,0 +1,77 @@
+"""End-to-end: the C++ `BaMMmotif OUTDIR FASTA --PWMFile ... --EM` drop-in on the GPU against the
+oracle pipeline and the known answer of BASELINE config 1 (13 iterations,
+llh 454.708 -> 475.799 on example/JunD.fasta seeded from PWM_peng10.meme, -k 0)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import bammmotif2_amd as bm
+from bammmotif2_amd import build
+from tests.test_host_io_cpu import FASTA, MEME, read_fasta_py
+
+pytestmark = pytest.mark.gpu
+
+
+def parse_ihbcp(path, K, W):
+    v = np.zeros(bm.v_size(K, W), np.float32)
+    blocks = open(path).read().split("\n\n")
+    for j in range(W):
+        lines = blocks[j].strip("\n").split("\n")
+        for k in range(K + 1):
+            vals = [float(x) for x in lines[k].split()]
+            assert len(vals) == 4 ** (k + 1)
+            v[bm.v_offset(k, W) + np.arange(4 ** (k + 1)) * W + j] = vals
+    return v
+
+
+def oracle_run(orc, K):
+    codes, off = read_fasta_py(FASTA)
+    _, kmer, o = orc.encode_set(codes, off, False, 42)
+    vbg = orc.bg_model(kmer, o, 2, np.array([1, 10, 10], np.float32))
+    lines = open(MEME).read().split("\n")
+    i = [k for k, l in enumerate(lines) if "letter-probability matrix" in l][0]
+    W = 12
+    pwm = np.array([[float(x) for x in lines[i + 1 + j].split()] for j in range(W)], np.float32).T.copy()
+    A = bm.synth.alpha_matrix(bm.synth.default_alpha(K), W)
+    v0 = orc.init_from_pwm(pwm, W, K, A, vbg, kmer, o, 0.3)
+    res = orc.optimize(kmer, o, K, W, 2, vbg, A, v0, 0.3)
+    return res, kmer, o, W
+
+
+@pytest.mark.parametrize("K", [0, 2])
+def test_cli_em_on_jund(K, tmp_path, orc, gpu_ctx):
+    build.build_host()
+    out = tmp_path / "o"
+    r = subprocess.run([build.CLI, str(out), FASTA, "--PWMFile", MEME, "--EM", "-k", str(K), "--maxPWM", "1",
+                        "--verbose", "--saveBaMMs"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    res, kmer, off, W = oracle_run(orc, K)
+    it_lines = re.findall(r"^(\d+) iter, llh=([-\d.e+]+), diff_llh=([-\d.e+]+), v_diff=([-\d.e+]+)$", r.stdout, re.M)
+    llh = np.array([float(x[1]) for x in it_lines])
+    assert abs(len(it_lines) - res["iterations"]) <= 1
+    m = min(len(llh), res["iterations"])
+    np.testing.assert_allclose(llh[:m], res["trace_llh"][:m], rtol=2e-5)
+    if K == 0:                                               # the survey's probe of the real reference
+        assert len(it_lines) == 13
+        assert llh[0] == pytest.approx(454.708, abs=2e-3) and llh[-1] == pytest.approx(475.799, abs=2e-3)
+    assert re.search(r"--- Runtime for EM: [\d.e+-]+ seconds ---", r.stdout)        # EM.cpp:134
+    assert "optimized q = 0.3" in r.stdout                                           # mainBaMM.cpp:147
+    v = parse_ihbcp(out / "JunD_motif_1.ihbcp", K, W)
+    if len(it_lines) == res["iterations"]:
+        np.testing.assert_allclose(v, res["v"], rtol=2e-3, atol=1e-6)               # %.3e files
+    # --saveBaMMs: .counts are int-truncated n (EM.cpp:570), .positions lists windows with r >= 0.3
+    cnt = [l for l in open(out / "JunD_motif_1.counts").read().split("\n") if l.strip()]
+    assert len(cnt) == W * (K + 1)
+    pos = open(out / "JunD_motif_1.positions").read().strip().split("\n")
+    assert pos[0] == "seq\tlength\tstrand\tstart..end\tpattern"
+    n_hits = 0
+    for n in range(300):
+        L = int(off[n + 1] - off[n])
+        rr = res["r"][int(off[n]):int(off[n + 1])]
+        n_hits += int((rr[: L - W + 1] >= 0.3).sum())
+    assert abs((len(pos) - 1) - n_hits) <= 3                 # r right at the 0.3 cut-off may flip
+    f = pos[1].split("\t")
+    assert f[0].startswith(">") and f[1] == "205" and f[2] in "+-" and len(f[4]) == W
