@@ -72,6 +72,26 @@ __device__ __forceinline__ unsigned long long to_fixed40(float r) {
     return ((unsigned long long)hi << 32) | lo;
 }
 constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
+// 128-bit LDS gather.  hipcc splits a float4 LDS load whose components are consumed under
+// different (even wave-uniform) conditions into b32/b64 pieces, which costs 2-4x the LDS cycles
+// (tools/lds_bench2.hip), so the read is issued by hand; lds_wait() retires all of them and
+// ties the results to the wait so that no consumer can be scheduled above it.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ f32x4 lds_read_b128(uint32_t byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+template <int M>
+__device__ __forceinline__ void lds_wait(f32x4 (&v)[M]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+#pragma unroll
+    for (int m = 1; m < M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
@@ -137,10 +157,14 @@ __device__ __forceinline__ uint32_t pick_sequence(const SeqView& sv, uint32_t t)
 // ---- fused E+M sequence kernel --------------------------------------------------------------
 template <int M, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
-    float* s_lds = lds;                                  // [W][Y+1], row Y = 1.0f
-    const uint32_t n_off = (W * Ys + 1u) & ~1u;          // 8-byte aligned
+    const uint32_t Wq = (W + 3u) >> 2;
+    // odds table as [W/4][Y+1][4]: one ds_read_b128 fetches the row of FOUR motif columns for a
+    // position (2.3 LDS cycles per column instead of 4.2 for ds_read_b32, tools/lds_bench2.hip);
+    // row Y and the padding columns are 1.0f
+    float* s_lds = lds;
+    const uint32_t n_off = Wq * Ys * 4u;                 // 16-byte aligned by construction
     // [W][Y+1][C] 64-bit fixed point (2^-40 units); C = 2^logC private copies, copy = lane mod C,
     // cut the same-address serialisation of ds_add_u64 (tools/lds_bench2.hip: 5.6 -> 2.7 ns).
     // Row Y of every column is never written (positions beyond LW1 are exec-masked off).
@@ -148,7 +172,10 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     const uint32_t logC = ACCUM ? a.logC : 0u;
     double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? (2u * W * Ys) << logC : 0u));  // [waves][3]
 
-    for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s_lds[i] = a.s[i];
+    for (uint32_t i = threadIdx.x; i < Wq * Ys * 4u; i += blockDim.x) {
+        const uint32_t jq = i / (Ys * 4u), rem = i - jq * Ys * 4u, yy = rem >> 2, j = jq * 4u + (rem & 3u);
+        s_lds[i] = (j < W) ? a.s[(size_t)j * Ys + yy] : 1.0f;
+    }
     if (ACCUM)
         for (uint32_t i = threadIdx.x; i < (W * Ys) << logC; i += blockDim.x) n_lds[i] = 0ull;
     __syncthreads();
@@ -177,15 +204,39 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 
         // ---- E-step: U[m] after column j = prod_{j'<=j} s[j'][y(p-j+j')]  (EM.cpp:167-176)
         float U[M];
-        const float* sj = s_lds;
+        uint32_t sa[M];                                  // LDS byte address of row y(p) in the current quad
+        const uint32_t s_base = lds_offset(s_lds);
 #pragma unroll
-        for (int m = 0; m < M; m++) U[m] = sj[y[m]];
-        for (uint32_t j = 1; j < W; j++) {
-            sj += Ys;
-            const float carry = wave_shr1(1.0f, U[M - 1]);
+        for (int m = 0; m < M; m++) sa[m] = s_base + y[m] * 16u;
+        for (uint32_t jq = 0; jq < Wq; jq++) {
+            f32x4 sv[M];
 #pragma unroll
-            for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m]];
-            U[0] = carry * sj[y[0]];
+            for (int m = 0; m < M; m++) sv[m] = lds_read_b128(sa[m]);
+#pragma unroll
+            for (int m = 0; m < M; m++) sa[m] += Ys * 16u;
+            lds_wait<M>(sv);
+            // the padding columns of the last quad hold 1.0f: multiplying by them is exact
+            if (jq == 0) {
+#pragma unroll
+                for (int m = 0; m < M; m++) U[m] = sv[m].x;             // column 0 starts the chain
+            } else {
+                const float c = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+                for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].x;
+                U[0] = c * sv[0].x;
+            }
+            if (jq * 4u + 1u < W) { const float c = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+              for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].y;
+              U[0] = c * sv[0].y; }
+            if (jq * 4u + 2u < W) { const float c = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+              for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].z;
+              U[0] = c * sv[0].z; }
+            if (jq * 4u + 3u < W) { const float c = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+              for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].w;
+              U[0] = c * sv[0].w; }
         }
         // slot p now holds the product of window start i = p-(W-1); valid for W-1 <= p < L
         const float pos_i = q / (float)LW1;              // EM.cpp:160
@@ -647,7 +698,7 @@ void set_em_lds_attr(size_t lds) {
 }  // namespace
 
 size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC) {
-    size_t floats = (((size_t)W * (Y + 1) + 1) & ~size_t(1)) + (accum ? (2 * (size_t)W * (Y + 1)) << logC : 0);
+    size_t floats = (size_t)((W + 3) / 4) * 4 * (Y + 1) + (accum ? (2 * (size_t)W * (Y + 1)) << logC : 0);
     return floats * sizeof(float) + 16 * 3 * sizeof(double);
 }
 

@@ -26,7 +26,7 @@ constexpr int UNR = 8;
 
 template <int WORDS>  // 1: b32, 2: b64, 4: b128 per row
 __global__ void __launch_bounds__(1024) k_read(float* out, int rows) {
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];   // without the alignment hipcc splits the wide reads
     for (int i = threadIdx.x; i < rows * WORDS; i += blockDim.x) lds[i] = 1.0f;
     __syncthreads();
     INIT_ROWS
@@ -71,6 +71,25 @@ __global__ void __launch_bounds__(1024) k_atomic(float* out) {
     }
     __syncthreads();
     out[blockIdx.x * blockDim.x + threadIdx.x] = (float)lds32[threadIdx.x] + carries;
+}
+
+// b64 gather from a [64 rows (+1 pad)][2 floats] column pair, optionally two stages of b32 instead
+template <int MODE>
+__global__ void __launch_bounds__(1024) k_pairread(float* out) {
+    extern __shared__ __align__(16) float lds[];
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) lds[i] = 1.0f;
+    __syncthreads();
+    INIT_ROWS
+    float acc = 0.f;
+    for (int it = 0; it < ITER; it++) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            STEP_ROW(u);
+            if (MODE == 0) { float2 v = reinterpret_cast<float2*>(lds)[r[u]]; acc = acc * v.x + v.y; }
+            if (MODE == 1) { acc = acc * lds[r[u]] + lds[65 + r[u]]; }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
 template <int C, int MODE>  // MODE 0: b32 read, 2: u64 atomic ; 320 rows
@@ -154,6 +173,8 @@ int main() {
         RUNK("atomic u64        C=4", (k_atomic<4, 2>), 16384, d_out);
         RUNK("atomic u64        C=8", (k_atomic<8, 2>), 16384, d_out);
         RUNK("atomic u64        C=16", (k_atomic<16, 2>), 16384, d_out);
+        RUNK("pair: 1 x b64 (2 columns)", (k_pairread<0>), 8192, d_out);
+        RUNK("pair: 2 x b32 (2 columns)", (k_pairread<1>), 8192, d_out);
         RUNK("read b32  rand320", (k_rows320<1, 0>), 320 * 8, d_out);
         RUNK("atomic u64 rand320 C=1", (k_rows320<1, 2>), 320 * 8, d_out);
         RUNK("atomic u64 rand320 C=2", (k_rows320<2, 2>), 320 * 16, d_out);
