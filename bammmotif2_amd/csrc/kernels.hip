@@ -92,6 +92,17 @@ __device__ __forceinline__ void lds_wait(f32x4 (&v)[M]) {
     for (int m = 1; m < M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
 }
 
+// One predicated 64-bit LDS add: exec <- pad & nz (both wave masks in SGPR pairs), ds_add_u64,
+// exec <- all lanes.  Replaces the compiler's v_cmp_u64 / s_nor / s_and_saveexec / s_or sequence
+// per atomic; valid because the call sites run with every lane of the wave active.  The adds are
+// fire-and-forget (no return): lds_drain() must run before anyone reads the table.
+__device__ __forceinline__ void lds_add_u64_masked(uint32_t byte_addr, unsigned long long v,
+                                                   unsigned long long pad_mask, unsigned long long nz_mask) {
+    asm volatile("s_and_b64 exec, %2, %3\n\tds_add_u64 %0, %1\n\ts_mov_b64 exec, -1"
+                 :: "v"(byte_addr), "v"(v), "s"(pad_mask), "s"(nz_mask) : "memory");
+}
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
@@ -271,16 +282,18 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             // Counts are accumulated as 64-bit fixed point (2^-40 units) with ds_add_u64: LDS
             // float atomics (ds_add_f32) run ~25x slower on gfx950 (tools/lds_bench.hip), and
             // integer sums are exact, so the result does not depend on scheduling order.
-            unsigned long long F[M];
-            uint32_t ya[M];
+            unsigned long long F[M], nz[M], padm[M];
+            uint32_t ya[M];                              // byte offset of (row y, private copy) inside a column
             const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 F[m] = to_fixed40(U[m]);
-                ya[m] = (y[m] << logC) + copy;
+                nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
+                padm[m] = __ballot(y[m] != Y);           // positions beyond LW1 take no part (EM.cpp:236)
+                ya[m] = ((y[m] << logC) + copy) * 8u;
             }
-            const uint32_t stride = Ys << logC;
-            unsigned long long* nj = n_lds + (W - 1u) * stride;
+            const uint32_t stride = (Ys << logC) * 8u;
+            uint32_t col = lds_offset(n_lds) + (W - 1u) * stride;
             // F is kept as a ring: after t shifts logical slot m lives in F[(m+t) mod M]; the
             // shift itself is one in-place DPP pair on F[t] (the value leaving becomes the value
             // arriving from the next lane), so no register moves
@@ -289,10 +302,11 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                 for (int t = 0; t < M; t++) {
                     if (jb + t < W) {
 #pragma unroll
-                        for (int m = 0; m < M; m++)   // adding an exact 0 is a no-op: let those lanes sit out
-                            if (y[m] != Y && F[(m + t) % M] != 0ull) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
+                        for (int m = 0; m < M; m++)
+                            lds_add_u64_masked(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M]);
                         F[t] = wave_shl1_u64(F[t]);
-                        nj -= stride;
+                        nz[t] = __ballot(F[t] != 0ull);
+                        col -= stride;
                     }
                 }
             }
@@ -300,6 +314,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     }
 
     // ---- block epilogue: partial table + statistics
+    lds_drain();
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
         stat_lds[wave * 3 + 1] = sumr_acc;
@@ -428,29 +443,33 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
         uint32_t y[M];
         decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
         const uint32_t shift = W - j1;                               // slot offset at column j1-1
-        unsigned long long F[M];
+        unsigned long long F[M], nz[M], padm[M];
         uint32_t ya[M];
 #pragma unroll
         for (int m = 0; m < M; m++) {
             const uint32_t slot = p0 + m + shift;
             F[m] = to_fixed40(slot < L ? rs[slot] : 0.0f);
-            ya[m] = (y[m] << logC) + copy;
+            nz[m] = __ballot(F[m] != 0ull);
+            padm[m] = __ballot(y[m] != Y);
+            ya[m] = ((y[m] << logC) + copy) * 8u;
         }
-        const uint32_t stride = Ys << logC;
-        unsigned long long* nj = n_lds + (nc - 1u) * stride;
+        const uint32_t stride = (Ys << logC) * 8u;
+        uint32_t col = lds_offset(n_lds) + (nc - 1u) * stride;
         for (uint32_t jb = 0; jb < nc; jb += M) {
 #pragma unroll
             for (int t = 0; t < M; t++) {
                 if (jb + t < nc) {
 #pragma unroll
                     for (int m = 0; m < M; m++)
-                        if (y[m] != Y && F[(m + t) % M] != 0ull) atomicAdd(&nj[ya[m]], F[(m + t) % M]);
+                        lds_add_u64_masked(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M]);
                     F[t] = wave_shl1_u64(F[t]);
-                    nj -= stride;
+                    nz[t] = __ballot(F[t] != 0ull);
+                    col -= stride;
                 }
             }
         }
     }
+    lds_drain();
     __syncthreads();
     unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y) + (size_t)j0 * Y;
     for (uint32_t i = threadIdx.x; i < nc * Y; i += blockDim.x) {
