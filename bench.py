@@ -81,6 +81,12 @@ def cpu_baseline(codes, in_off, W, K, v0, alpha, q, sample, iters, ss):
         dt = time.perf_counter() - t0
         positions = int(S.off[-1])
         kind = "reference"
+        # the reference's own default is --threads 4 (Global.cpp:96); its CAS float adds on a
+        # 5 KB table contend badly on many-core hosts, so that figure is reported as well
+        R.set_threads(4)
+        t1 = time.perf_counter()
+        S.R.ref_em_estep(em); S.R.ref_em_mstep(em)
+        extra = {"positions_per_s_at_reference_default_4_threads": positions / (time.perf_counter() - t1)}
     else:
         O = oracle.Oracle()
         O.set_threads(cores)
@@ -94,7 +100,8 @@ def cpu_baseline(codes, in_off, W, K, v0, alpha, q, sample, iters, ss):
         dt = time.perf_counter() - t0
         positions = int(off[-1])
         kind = "port"
-    return {"value": positions * iters / dt, "unit": "positions/s", "cores": cores, "kind": kind,
+        extra = {}
+    return {**extra, "value": positions * iters / dt, "unit": "positions/s", "cores": cores, "kind": kind,
             "iterations_per_s_on_sample": iters / dt,
             "sample": f"first {n} sequences of the same set, {iters} timed EM iterations "
                       f"(EStep+MStep), OpenMP on {cores} host threads, -O2"}
