@@ -42,7 +42,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 HOST = os.path.join(HERE, "host")
 HOST_LIB = os.path.join(HERE, "libbamm_host.so")
 CLI = os.path.join(HERE, "BaMMmotif")
-HOST_SOURCES = ["io.cpp", "hooks.cpp"]
+HOST_SOURCES = ["io.cpp", "fdr.cpp", "hooks.cpp"]
 
 
 def build_host(force: bool = False, verbose: bool = False):
@@ -59,7 +59,7 @@ def build_host(force: bool = False, verbose: bool = False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    cmd = common + [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "io.cpp"), "-lbamm_em", "-o", CLI]
+    cmd = common + [os.path.join(HOST, "main.cpp"), os.path.join(HOST, "io.cpp"), os.path.join(HOST, "fdr.cpp"), "-lbamm_em", "-o", CLI]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

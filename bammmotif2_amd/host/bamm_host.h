@@ -64,3 +64,37 @@ int load_seeds(const std::string& path, const std::string& tag, uint32_t l_flank
 std::string base_name(const std::string& path);   // refinement/utils.h:66-85
 
 }  // namespace bammhost
+
+// ======================= evaluation side: negatives, FDR statistics, occurrences ===================
+namespace bammhost {
+
+// SeqGenerator::sample_bgseqset_by_fold (seq_generator/SeqGenerator.cpp:188-204) incl. the ctor's
+// srand(42) (:35), calculate_kmer_frequency (:63-110), rescale_kmer_frequency (:112-186, hard-wired
+// to s = 2 like the reference), bgseq_on_rescaled_v (:285-348) and bg_sequence (:222-283).
+// y_s: kmer_ mod 4^(s+1) for every position of the reference sequences (as EM sees them).
+int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, uint32_t s_order, size_t m_fold,
+                     bool generic, std::vector<uint8_t>& codes_out, std::vector<uint64_t>& off_out, std::string& err);
+
+struct FdrResult {                      // what FDR::calculatePR / calculatePvalues leave behind (FDR.h:54-84)
+    std::vector<float> zoops_tp, zoops_fp, zoops_fdr, zoops_rec, pn_pvalue, zoops_pvalue;
+    std::vector<float> mops_tp, mops_fp, mops_fdr, mops_rec, mops_pvalue;
+    float occ_frac = 0.f, occ_mult = 0.f;
+};
+// scores may arrive in any order (they are sorted first, FDR.cpp:158-159,203-204)
+void fdr_statistics(std::vector<float> pos_max, std::vector<float> neg_max, std::vector<float> pos_all,
+                    std::vector<float> neg_all, size_t posN, size_t negN, float q, bool mops, bool zoops,
+                    bool with_pvalues, FdrResult& out);
+int fdr_write(const std::string& dir, const std::string& basename, const FdrResult& r, size_t posN, size_t negN,
+              bool mops, bool zoops, bool save_prs, bool save_pvalues, std::string& err);   // FDR.cpp:338-410
+
+// ScoreSeqSet::calcPvalues (seq_scoring/ScoreSeqSet.cpp:70-126): p-/e-values of every window
+void mops_pvalues(const float* pos_scores, size_t n_pos_scores, std::vector<float> neg_all, size_t posN,
+                  std::vector<float>& p_out, std::vector<float>& e_out);
+
+// ScoreSeqSet::write (seq_scoring/ScoreSeqSet.cpp:245-291): <basename>.occurrence, one row per window with
+// p < cutoff.  codes/off: FASTA codes of the forward strands; ss as on the command line.
+int occurrence_write(const std::string& dir, const std::string& basename, const std::vector<std::string>& headers,
+                     const uint8_t* codes, const uint64_t* off, size_t n_seqs, bool ss, uint32_t W, const float* p,
+                     const float* e, float cutoff, std::string& err);
+
+}  // namespace bammhost

@@ -1,0 +1,339 @@
+// Evaluation side of the BaMMmotif drop-in: negative-set sampler, FDR / PR statistics and window
+// p-values.  Restated from the reference lines cited in bamm_host.h; fp32 expression order kept.
+#include <algorithm>
+#include <cassert>
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <functional>
+#include <iomanip>
+
+#include "bamm_host.h"
+
+namespace bammhost {
+
+static inline size_t ipow4(size_t e) { return size_t(1) << (2 * e); }
+static inline size_t bgoff(size_t k) { return (ipow4(k + 1) - 4) / 3; }
+
+namespace {
+
+struct NegSampler {
+    uint32_t s;
+    std::vector<float> v, range_bar, v_seq;      // flat [k][y]
+    std::vector<size_t> n, n_seq;
+    std::vector<float> A;
+
+    explicit NegSampler(uint32_t s_order) : s(s_order) {
+        const size_t tot = bgoff(s + 1);
+        v.assign(tot, 0.f); range_bar.assign(tot, 0.f); v_seq.assign(tot, 0.f);
+        n.assign(tot, 0); n_seq.assign(tot, 0);
+        A.assign(s + 1, 20.f);                    // SeqGenerator.cpp:29-32
+    }
+
+    void kmer_frequency(const uint32_t* y_s, const uint64_t* off, size_t n_seqs) {   // :63-110
+        std::fill(n.begin(), n.end(), 0);
+        for (size_t i = 0; i < n_seqs; i++) {
+            const size_t L = off[i + 1] - off[i];
+            const uint32_t* km = y_s + off[i];
+            for (uint32_t k = 0; k <= s; k++)
+                for (size_t j = k; j < L; j++) n[bgoff(k) + km[j] % ipow4(k + 1)]++;
+        }
+        size_t norm = 0;
+        for (size_t y = 0; y < 4; y++) norm += n[y];
+        float sum = 0.0f;
+        for (size_t y = 0; y < 4; y++) {
+            v[y] = ((float)n[y] + A[0] * 0.25f) / ((float)norm + A[0]);
+            sum += v[y];
+            range_bar[y] = sum;
+        }
+        for (uint32_t k = 1; k <= s; k++) {
+            sum = 0.f;
+            for (size_t y = 0; y < ipow4(k + 1); y++) {
+                const size_t yk = y / 4, y2 = y % ipow4(k);
+                v[bgoff(k) + y] = ((float)n[bgoff(k) + y] + A[k] * v[bgoff(k - 1) + y2]) / ((float)n[bgoff(k - 1) + yk] + A[k]);
+                if (y % 4 == 0) sum = 0.f;
+                sum += v[bgoff(k) + y];
+                range_bar[bgoff(k) + y] = sum;
+            }
+        }
+    }
+
+    void rescale(const uint32_t* km, size_t L) {   // :112-186, written for s = 2
+        std::fill(n_seq.begin(), n_seq.end(), 0);
+        for (uint32_t k = 0; k <= s; k++)
+            for (size_t j = k; j < L; j++) n_seq[bgoff(k) + km[j] % ipow4(k + 1)]++;
+        float sum = 0.f;
+        for (size_t y = 0; y < 4; y++) {
+            v_seq[y] = v[y];
+            sum += v_seq[y];
+            range_bar[y] = sum;
+        }
+        {
+            const uint32_t k = 1;
+            const size_t o1 = bgoff(1), o0 = bgoff(0);
+            for (size_t y = 0; y < 16; y++) {
+                const size_t y2 = y % 4;
+                v_seq[o1 + y] = v[o1 + y] * ((float)n_seq[o1 + y] + A[k - 1] * v[o0 + y2]) / v[o0 + y2] / ((float)L + A[k - 1]);
+            }
+            float norm[4] = {0.f, 0.f, 0.f, 0.f};
+            for (size_t y = 0; y < 16; y++) {
+                const size_t yk = y / 4;
+                v_seq[o1 + y] = ((float)n_seq[o1 + y] + A[k] * v_seq[o1 + y]) / ((float)n_seq[o0 + yk] + A[k]);
+                norm[yk] += v_seq[o1 + y];
+            }
+            for (size_t y = 0; y < 16; y++) v_seq[o1 + y] /= norm[y / 4];
+            for (size_t y = 0; y < 16; y++) {
+                if (y % 4 == 0) sum = 0.0f;
+                sum += v_seq[o1 + y];
+                range_bar[o1 + y] = sum;
+            }
+        }
+        {
+            const uint32_t k = 2;
+            const size_t o2 = bgoff(2), o1 = bgoff(1);
+            for (size_t y = 0; y < 64; y++) {
+                const size_t y2 = y % 16, yk = y / 4;
+                v_seq[o2 + y] = ((float)n_seq[o2 + y] + A[k] * v_seq[o1 + y2]) / ((float)n_seq[o1 + yk] + A[k]);
+                if (y % 4 == 0) sum = 0.0f;
+                sum += v_seq[o2 + y];
+                range_bar[o2 + y] = sum;
+            }
+        }
+    }
+
+    void draw(size_t L, uint8_t* seq) {             // :222-283 == :296-341 (same sampling loop)
+        float random = (float)rand() / (float)RAND_MAX;
+        for (uint8_t y = 0; y < 4; y++)
+            if (random <= range_bar[y]) { seq[0] = y + 1; break; }
+        for (size_t i = 1; i < s && i < L; i++) {
+            size_t yk = 0;
+            for (size_t k = i; k > 0; k--) yk += (size_t)(seq[i - k] - 1) * ipow4(k);
+            random = (float)rand() / (float)RAND_MAX;
+            for (size_t y = yk, a = 1; y < yk + 4; y++, a++) {
+                seq[i] = (uint8_t)a;
+                if (random <= range_bar[bgoff(i) + y]) break;
+            }
+        }
+        for (size_t i = s; i < L; i++) {
+            size_t yk = 0;
+            for (size_t k = s; k > 0; k--) yk += (size_t)(seq[i - k] - 1) * ipow4(k);
+            random = (float)rand() / (float)RAND_MAX;
+            for (size_t y = yk, a = 1; y < yk + 4; y++, a++) {
+                seq[i] = (uint8_t)a;
+                if (random <= range_bar[bgoff(s) + y]) break;
+            }
+        }
+    }
+};
+
+}  // namespace
+
+int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, uint32_t s_order, size_t m_fold,
+                     bool generic, std::vector<uint8_t>& codes_out, std::vector<uint64_t>& off_out, std::string& err) {
+    if (!generic && s_order != 2) {
+        err = "Error: the sequence-specific negative sampler is written for -s 2 (SeqGenerator.cpp:112-186); use --genericNeg";
+        return 1;
+    }
+    srand(42);                                         // SeqGenerator.cpp:35
+    NegSampler g(s_order);
+    g.kmer_frequency(y_s, off, n_seqs);
+    codes_out.clear();
+    off_out.assign(1, 0);
+    for (size_t i = 0; i < n_seqs; i++) {
+        const size_t L = off[i + 1] - off[i];
+        for (size_t f = 0; f < m_fold; f++) {
+            if (!generic) g.rescale(y_s + off[i], L);
+            const size_t o = codes_out.size();
+            codes_out.resize(o + L, 0);
+            g.draw(L, codes_out.data() + o);
+            off_out.push_back(codes_out.size());
+        }
+    }
+    return 0;
+}
+
+void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::vector<float> posAll,
+                    std::vector<float> negAll, size_t posN, size_t negN, float q, bool mops, bool zoops,
+                    bool with_pvalues, FdrResult& r) {
+    r = FdrResult();
+    const float mFold = (float)negN / (float)posN;
+    srand(42);                                         // FDR.cpp:153
+    if (mops) {                                        // FDR.cpp:156-196
+        std::sort(posAll.begin(), posAll.end(), std::greater<float>());
+        std::sort(negAll.begin(), negAll.end(), std::greater<float>());
+        size_t ip = 0, in = 0;
+        float E_TP = 0.0f;
+        size_t idx_max = posN + negN;
+        const size_t len_all = posAll.size() + negAll.size();
+        for (size_t i = 0; i < len_all; i++) {
+            // the reference indexes past the end of both vectors here (FDR.cpp:174); an exhausted
+            // list is treated as "-inf" instead of reading stale heap memory
+            const bool take_pos = (ip < posAll.size()) && (in >= negAll.size() || posAll[ip] > negAll[in]);
+            if (take_pos) ip++; else in++;
+            r.mops_tp.push_back((float)ip - (float)in / mFold);
+            r.mops_fp.push_back((float)in / mFold);
+            if (E_TP == r.mops_tp[i]) idx_max = i;
+            if (E_TP < r.mops_tp[i]) E_TP = r.mops_tp[i];
+        }
+        for (size_t i = 0; i < idx_max && i < len_all; i++) {
+            r.mops_fdr.push_back(r.mops_fp[i] / (r.mops_tp[i] + r.mops_fp[i]));
+            r.mops_rec.push_back(r.mops_tp[i] / E_TP);
+        }
+        r.occ_mult = E_TP / (float)posN;
+    }
+    if (zoops) {                                       // FDR.cpp:199-275
+        std::sort(posMax.begin(), posMax.end(), std::greater<float>());
+        std::sort(negMax.begin(), negMax.end(), std::greater<float>());
+        size_t ip = 0, in = 0, min_idx_pos = 0;
+        const size_t posN_est = static_cast<size_t>(q * (float)posN);
+        const size_t n_top = (size_t)std::fmin(100, negN / 10);
+        float lambda = 1e-16f;
+        for (size_t l = 0; l < n_top; l++) lambda += negMax[l] - negMax[n_top];
+        lambda /= n_top;
+        float Sl = 0.f;
+        auto P = [&](size_t i) { return i < posMax.size() ? posMax[i] : -INFINITY; };
+        auto N = [&](size_t i) { return i < negMax.size() ? negMax[i] : -INFINITY; };
+        for (size_t i = 0; i < posN + negN; i++) {
+            if ((P(ip) > N(in) || ip == 0 || in == negN) && ip < posN) {
+                Sl = posMax[ip];
+                ip++;
+            } else if (P(ip) == N(in) && rand() % 2 == 0 && ip < posN) {     // same evaluation order: rand() drawn on every tie
+                Sl = posMax[ip];
+                ip++;
+            } else {
+                Sl = N(in);
+                in++;
+            }
+            const float TP = (float)ip, FP = (float)in / mFold;
+            r.zoops_tp.push_back(TP);
+            r.zoops_fp.push_back(FP);
+            float p_value;
+            if (Sl <= negMax[n_top]) {
+                auto lo = std::lower_bound(negMax.begin(), negMax.end(), Sl, std::greater<float>());
+                auto up = std::upper_bound(negMax.begin(), negMax.end(), Sl, std::greater<float>());
+                const float Sl_upper = (lo == negMax.begin()) ? Sl : *(lo - 1);
+                // for scores at or below the lowest negative the reference dereferences end() (FDR.cpp:244);
+                // with its vectors that is untouched zero-filled heap, so 0 is what it computes with
+                const float Sl_lower = (up == negMax.end()) ? 0.0f : *up;
+                p_value = (in + (Sl_upper - Sl) / (Sl_upper - Sl_lower + 1e-5)) / (float)negN;
+            } else {
+                p_value = n_top * expf((negMax[n_top] - Sl) / lambda) / negN;
+            }
+            r.pn_pvalue.push_back(p_value);
+            if (ip == posN_est) min_idx_pos = i;
+            r.zoops_fdr.push_back(FP / (TP + FP));
+            r.zoops_rec.push_back(TP / (float)posN);
+        }
+        r.occ_frac = 1.0f - r.zoops_fp[min_idx_pos] / (float)posN;
+    }
+    if (with_pvalues) {                                // FDR.cpp:278-333
+        auto pv = [](std::vector<float>& pos, std::vector<float>& neg, std::vector<float>& out) {
+            std::sort(neg.begin(), neg.end(), std::less<float>());
+            std::sort(pos.begin(), pos.end(), std::less<float>());
+            for (size_t i = 0; i < pos.size(); i++) {
+                const size_t low = std::lower_bound(neg.begin(), neg.end(), pos[i]) - neg.begin();
+                const size_t up = std::upper_bound(neg.begin(), neg.end(), pos[i]) - neg.begin();
+                float p = 1.0f - (float)(up + low) / (2.0f * (float)neg.size());
+                if (p < 1.e-6) p = 1.e-6;
+                if (p > 1.0f) p = 1.0f;
+                out.push_back(p);
+            }
+        };
+        if (mops) pv(posAll, negAll, r.mops_pvalue);
+        if (zoops) pv(posMax, negMax, r.zoops_pvalue);
+    }
+}
+
+int fdr_write(const std::string& dir, const std::string& basename, const FdrResult& r, size_t posN, size_t negN,
+              bool mops, bool zoops, bool save_prs, bool save_pvalues, std::string& err) {
+    const std::string opath = dir + '/' + basename;
+    if (save_prs) {
+        if (zoops) {
+            std::ofstream f(opath + ".zoops.stats");
+            if (!f.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+            f << "TP" << '\t' << "FP" << '\t' << "FDR" << '\t' << "Recall" << '\t' << "p-value" << '\t'
+              << (float)negN / (float)posN << '\t' << r.occ_frac << std::endl;
+            for (size_t i = 0; i < r.zoops_fdr.size(); i++)
+                f << r.zoops_tp[i] << '\t' << r.zoops_fp[i] << '\t' << r.zoops_fdr[i] << '\t' << r.zoops_rec[i] << '\t'
+                  << r.pn_pvalue[i] << '\t' << std::endl;
+        }
+        if (mops) {
+            std::ofstream f(opath + ".mops.stats");
+            f << "TP" << '\t' << "FP" << '\t' << "FDR" << '\t' << "Recall" << '\t' << r.occ_mult << std::endl;
+            for (size_t i = 0; i < r.mops_fdr.size(); i++)
+                f << r.mops_tp[i] << '\t' << r.mops_fp[i] << '\t' << r.mops_fdr[i] << '\t' << r.mops_rec[i] << '\t' << std::endl;
+        }
+    }
+    if (save_pvalues) {
+        if (zoops) {
+            std::ofstream f(opath + ".zoops.pvalues");
+            for (float p : r.zoops_pvalue) f << std::setprecision(3) << p << std::endl;
+        }
+        if (mops) {
+            std::ofstream f(opath + ".mops.pvalues");
+            for (float p : r.mops_pvalue) f << std::setprecision(3) << p << std::endl;
+        }
+    }
+    return 0;
+}
+
+void mops_pvalues(const float* pos_scores, size_t n_pos_scores, std::vector<float> neg, size_t posN,
+                  std::vector<float>& p_out, std::vector<float>& e_out) {
+    const size_t negN = neg.size();                    // ScoreSeqSet.cpp:75-93
+    const float eps = 1.0e-5;
+    std::sort(neg.begin(), neg.end(), std::less<float>());
+    const size_t nTop = std::min(100, (int)negN / 10);
+    const float S_ntop = neg[nTop];
+    float lambda = 0.f;
+    for (size_t n = 0; n < nTop; n++) lambda += (neg[n] - S_ntop);
+    lambda = lambda / (float)nTop;
+    p_out.resize(n_pos_scores);
+    e_out.resize(n_pos_scores);
+    for (size_t i = 0; i < n_pos_scores; i++) {        // ScoreSeqSet.cpp:97-125
+        const float Sl = pos_scores[i];
+        const size_t FPl = neg.end() - std::upper_bound(neg.begin(), neg.end(), Sl);
+        float p;
+        if (FPl == negN) {
+            p = 1.f;
+        } else if (FPl < 10 && fabs(lambda) > eps) {
+            p = float(nTop) / (float)negN * expf(-(Sl - S_ntop) / lambda);
+        } else {
+            const float SlHigher = neg[negN - FPl - 1], SlLower = neg[negN - FPl];
+            p = ((float)FPl + (SlHigher - Sl + eps) / (SlHigher - SlLower + eps)) / (float)negN;
+        }
+        p_out[i] = p;
+        e_out[i] = p * (float)posN;
+    }
+}
+
+int occurrence_write(const std::string& dir, const std::string& basename, const std::vector<std::string>& headers,
+                     const uint8_t* codes, const uint64_t* off, size_t n_seqs, bool ss, uint32_t W, const float* p,
+                     const float* e, float cutoff, std::string& err) {
+    std::ofstream f(dir + '/' + basename + ".occurrence");
+    if (!f.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+    f << "seq\tlength\tstrand\tstart..end\tpattern\tp-value\te-value" << std::endl;
+    static const char B[] = "NACGT";
+    size_t o = 0;
+    for (size_t n = 0; n < n_seqs; n++) {
+        const size_t L0 = off[n + 1] - off[n], L = ss ? L0 : 2 * L0 + 1, seqlen = ss ? L : (L - 1) / 2;
+        const uint8_t* c = codes + off[n];
+        auto base_at = [&](size_t b) -> char {             // Sequence::getSequence(): forward, N, reverse complement
+            if (b < L0) return B[c[b] <= 4 ? c[b] : 0];
+            if (ss || b == L0) return 'N';
+            const uint8_t x = c[2 * L0 - b];
+            return (x >= 1 && x <= 4) ? B[5 - x] : 'N';
+        };
+        const size_t LW1 = L - W + 1;
+        for (size_t i = 0; i < LW1; i++) {
+            if (p[o + i] < cutoff) {
+                f << headers[n] << '\t' << seqlen << '\t' << ((i < seqlen) ? '+' : '-') << '\t' << i + 1 << ".." << i + W << '\t';
+                for (size_t m = i; m < i + W; m++) f << base_at(m);
+                f << '\t' << std::setprecision(3) << p[o + i] << '\t' << e[o + i] << std::endl;
+            }
+        }
+        o += LW1;
+    }
+    return 0;
+}
+
+}  // namespace bammhost

@@ -86,3 +86,54 @@ const char* bh_base_name(const char* path) {
 }
 
 }  // extern "C"
+
+// ---- evaluation-side hooks ---------------------------------------------------------------
+extern "C" {
+
+// negatives for a packed (positive) set; two-call protocol (codes == NULL -> sizes only)
+int bh_sample_negatives(const bamm_packed* packed, uint32_t s_order, uint64_t m_fold, int generic, uint64_t* n_out,
+                        uint64_t* n_codes, uint8_t* codes, uint64_t* off) {
+    static thread_local std::vector<uint8_t> c;
+    static thread_local std::vector<uint64_t> o;
+    if (!codes) {
+        std::vector<uint32_t> ys(packed->total_len ? packed->total_len : 1);
+        if (bamm_unpack_y(packed, s_order, ys.data())) { g_err = bamm_last_error(); return 1; }
+        std::vector<uint64_t> poff(packed->n_seqs + 1, 0);
+        for (uint64_t n = 0; n < packed->n_seqs; n++) poff[n + 1] = poff[n] + packed->len[n];
+        if (sample_negatives(ys.data(), poff.data(), packed->n_seqs, s_order, m_fold, generic != 0, c, o, g_err)) return 1;
+        *n_out = o.size() - 1;
+        *n_codes = c.size();
+        return 0;
+    }
+    memcpy(codes, c.data(), c.size());
+    memcpy(off, o.data(), o.size() * sizeof(uint64_t));
+    return 0;
+}
+
+int bh_fdr_stats(const float* pos_max, uint64_t n_pos_max, const float* neg_max, uint64_t n_neg_max, const float* pos_all,
+                 uint64_t n_pos_all, const float* neg_all, uint64_t n_neg_all, uint64_t posN, uint64_t negN, float q, int mops,
+                 int zoops, int save_pvalues, const char* dir, const char* base) {
+    FdrResult r;
+    fdr_statistics(std::vector<float>(pos_max, pos_max + n_pos_max), std::vector<float>(neg_max, neg_max + n_neg_max),
+                   std::vector<float>(pos_all, pos_all + n_pos_all), std::vector<float>(neg_all, neg_all + n_neg_all), posN, negN,
+                   q, mops != 0, zoops != 0, save_pvalues != 0, r);
+    return fdr_write(dir, base, r, posN, negN, mops != 0, zoops != 0, true, save_pvalues != 0, g_err);
+}
+
+int bh_mops_pvalues(const float* pos_scores, uint64_t n_pos, const float* neg_all, uint64_t n_neg, uint64_t posN, float* p_out,
+                    float* e_out) {
+    std::vector<float> p, e;
+    mops_pvalues(pos_scores, n_pos, std::vector<float>(neg_all, neg_all + n_neg), posN, p, e);
+    memcpy(p_out, p.data(), p.size() * sizeof(float));
+    memcpy(e_out, e.data(), e.size() * sizeof(float));
+    return 0;
+}
+
+int bh_occurrence(const char* dir, const char* base, const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int ss,
+                  uint32_t W, const float* p, const float* e, float cutoff) {
+    std::vector<std::string> headers;
+    for (uint64_t n = 0; n < n_seqs; n++) headers.push_back("seq" + std::to_string(n));
+    return occurrence_write(dir, base, headers, codes, off, n_seqs, ss != 0, W, p, e, cutoff, g_err);
+}
+
+}  // extern "C"

@@ -1,8 +1,9 @@
 // BaMMmotif OUTDIR FASTA [options] -- MI355X drop-in for the reference driver
 // (/root/reference/src/refinement/mainBaMM.cpp, Global.cpp).  The EM itself runs on the GPU
 // through the C ABI (include/bamm_em.h); everything here is host plumbing with the reference's
-// flags, defaults, messages and output files.  Not ported (exit with a clear message): --CGS,
-// --FDR, --scoreSeqset, --advanceEM, non-STANDARD alphabets.
+// flags, defaults, messages and output files, including --scoreSeqset (.occurrence) and --FDR
+// (cross-validated .zoops.stats).  Not ported (exit with a clear message): --CGS, --advanceEM,
+// --saveLogOdds, non-STANDARD alphabets.
 #include <sys/stat.h>
 
 #include <chrono>
@@ -122,6 +123,8 @@ struct Options {                       // Global.cpp:6-96 defaults
     std::string seed_file, seed_tag, bg_file;
     bool ss = false, EM = false, CGS = false, FDR = false, score = false, verbose = false;
     bool optimizeQ = false, advanceEM = false, saveBaMMs = true, saveInitial = false, mops = false, zoops = true;
+    bool genericNeg = false, savePRs = true, savePvalues = false, saveLogOdds = false;
+    float pvalCutoff = 0.0001f;
     size_t maxPWM = std::numeric_limits<size_t>::max();
     uint32_t K = 2, Kbg = 2;
     std::vector<float> alpha{1.f, 1.f, 1.f}, alpha_bg{1.f, 1.f, 1.f};
@@ -160,7 +163,7 @@ Options parse(int nargs, char** args) {
     if (!a.get_str(0, "basename", o.basename)) o.basename = base_name(o.fasta);
     a.present(0, "maskPosSequenceSet");
     if (!a.get_str(0, "negSeqFile", o.neg_fasta)) o.neg_fasta = o.fasta;
-    a.present(0, "genericNeg");
+    o.genericNeg = a.present(0, "genericNeg");
     a.get_str(0, "alphabet", o.alphabet);
     o.ss = a.present(0, "ss");
     { std::string tmp; a.get_str(0, "intensityFile", tmp); }
@@ -212,13 +215,15 @@ Options parse(int nargs, char** args) {
         a.get('s', "sOrder", o.sOrder);
     }
     o.score = a.present(0, "scoreSeqset");
-    { float x; a.get(0, "pvalCutoff", x); }
+    a.get(0, "pvalCutoff", o.pvalCutoff);
     o.verbose = a.present(0, "verbose");
     a.present(0, "debug");
     o.saveBaMMs = a.present(0, "saveBaMMs");                  // presence overwrites the default (getopt_pp.h:497)
     o.saveInitial = a.present(0, "saveInitialBaMMs");
-    { bool x; a.get(0, "savePRs", x); }
-    for (const char* n : {"savePvalues", "saveLogOdds", "saveBgModel", "makeMovie", "B2", "B3", "B3prime"}) a.present(0, n);
+    a.get(0, "savePRs", o.savePRs);
+    o.savePvalues = a.present(0, "savePvalues");
+    o.saveLogOdds = a.present(0, "saveLogOdds");
+    for (const char* n : {"saveBgModel", "makeMovie", "B2", "B3", "B3prime"}) a.present(0, n);
     o.optimizeQ = a.present(0, "optimizeQ");
     o.advanceEM = a.present(0, "advanceEM");
     a.get(0, "threads", o.threads);
@@ -248,7 +253,7 @@ int main(int nargs, char* args[]) {
     Options o = parse(nargs, args);
     if (o.alphabet != "STANDARD") die("Error: this build supports --alphabet STANDARD only.");
     if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
-    if (o.FDR || o.score) die("Error: --FDR / --scoreSeqset are not ported yet (SURVEY.md section 8f).");
+    if (o.saveLogOdds) die("Error: --saveLogOdds is not ported.");
     if (o.advanceEM) die("Error: --advanceEM is not ported.");
     if (o.K > BAMM_MAX_ORDER) die("Error: model order above 10 is not supported (kmer_ spans 11 bases).");
 
@@ -287,7 +292,12 @@ int main(int nargs, char* args[]) {
     if (o.verbose) std::cout << std::endl << "*********************" << std::endl << "*   BaMM Training   *" << std::endl << "*********************" << std::endl;
     bamm_ctx* ctx = nullptr;
     bamm_seqs* dseqs = nullptr;
-    if (o.EM) {
+    const bool need_gpu = o.EM || o.score || o.FDR;
+    bamm_seqs* dneg = nullptr;
+    std::vector<uint8_t> neg_codes;
+    std::vector<uint64_t> neg_off{0};
+    std::vector<uint32_t> kept_len;
+    if (need_gpu) {
         if (bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
         bamm_packed* use = packed;
         bamm_packed* filtered = nullptr;
@@ -302,8 +312,49 @@ int main(int nargs, char* args[]) {
             use = filtered;
         }
         if (bamm_seqs_upload(ctx, use, 0, use->n_seqs, &dseqs)) die_abi("upload");
+        kept_len.assign(use->len, use->len + use->n_seqs);
+        if (o.score || o.FDR) {
+            // negative set sampled from the s-mer statistics of the (kept) positives, mainBaMM.cpp:97-116
+            size_t mFold = o.mFold;
+            const size_t minSeqN = 5000;
+            if (posN < minSeqN) mFold = minSeqN / posN + (minSeqN % posN ? 1 : 0);
+            std::vector<uint32_t> ys(use->total_len ? use->total_len : 1);
+            if (bamm_unpack_y(use, (uint32_t)o.sOrder, ys.data())) die_abi("unpack");
+            std::vector<uint64_t> uoff(use->n_seqs + 1, 0);
+            for (uint64_t n = 0; n < use->n_seqs; n++) uoff[n + 1] = uoff[n] + use->len[n];
+            if (sample_negatives(ys.data(), uoff.data(), use->n_seqs, (uint32_t)o.sOrder, mFold, o.genericNeg, neg_codes, neg_off, err)) die(err);
+            bamm_packed* npk = nullptr;
+            if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) die_abi("packing negatives");
+            if (bamm_seqs_upload(ctx, npk, 0, npk->n_seqs, &dneg)) die_abi("upload negatives");
+            bamm_packed_free(npk);
+        }
         if (filtered) bamm_packed_free(filtered);
     }
+    const size_t negN = neg_off.size() - 1;
+    // scorer over a resident set: MOPS scores (concatenated), ZOOPS maxima
+    auto score_set = [&](bamm_seqs* set, const std::vector<uint32_t>& lens, const Motif& m, std::vector<float>& mops,
+                         std::vector<float>& zoops) {
+        size_t total = 0;
+        for (uint32_t L : lens) total += L - m.W + 1;
+        mops.assign(total ? total : 1, 0.f);
+        zoops.assign(lens.size() ? lens.size() : 1, 0.f);
+        std::vector<uint64_t> z(lens.size() ? lens.size() : 1);
+        if (bamm_logodds(ctx, set, m.K, m.W, bg.K, m.v.data(), bg.v.data(), mops.data(), total, zoops.data(), z.data())) die_abi("calcLogOdds");
+        mops.resize(total);
+        zoops.resize(lens.size());
+    };
+    std::vector<uint32_t> neg_len;
+    for (size_t n = 0; n < negN; n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
+    // kept positives: FASTA codes / headers in the same order as the resident set
+    std::vector<std::string> kept_headers;
+    std::vector<uint8_t> kept_codes;
+    std::vector<uint64_t> kept_off{0};
+    for (size_t n = 0; n < pos.size(); n++)
+        if (keep[n]) {
+            kept_headers.push_back(pos.headers[n]);
+            kept_codes.insert(kept_codes.end(), pos.codes.begin() + pos.off[n], pos.codes.begin() + pos.off[n + 1]);
+            kept_off.push_back(kept_codes.size());
+        }
 
     for (size_t n = 0; n < seeds.motifs.size(); n++) {
         Motif motif = seeds.motifs[n];                       // deep copy (mainBaMM.cpp:121)
@@ -382,6 +433,73 @@ int main(int nargs, char* args[]) {
             std::cout << "Note: the model is not optimized!\n";
         }
         if (motif_write(o.out_dir, mbase, motif, err)) die(err);
+        if (o.score) {                                       // mainBaMM.cpp:171-236
+            if (o.verbose) std::cout << std::endl << "*************************" << std::endl << "*    Score Sequences    *" << std::endl << "*************************" << std::endl << std::endl;
+            Motif sm = motif;
+            if (!o.EM && o.seed_tag == "BaMM" && o.bg_file.empty()) die("No background Model file provided for initial search motif!");
+            std::vector<float> neg_mops, neg_zoops, pos_mops, pos_zoops, pv, ev;
+            score_set(dneg, neg_len, sm, neg_mops, neg_zoops);
+            score_set(dseqs, kept_len, sm, pos_mops, pos_zoops);
+            mops_pvalues(pos_mops.data(), pos_mops.size(), neg_mops, kept_len.size(), pv, ev);
+            if (occurrence_write(o.out_dir, mbase, kept_headers, kept_codes.data(), kept_off.data(), kept_len.size(), o.ss, sm.W,
+                                 pv.data(), ev.data(), o.pvalCutoff, err)) die(err);
+        }
+    }
+
+    if (o.FDR) {                                             // mainBaMM.cpp:243-265, FDR.cpp:28-145
+        if (o.verbose) std::cout << std::endl << "***********************" << std::endl << "*   BaMM validation   *" << std::endl << "***********************" << std::endl;
+        const size_t cv = o.cvFold, P = kept_len.size();
+        for (size_t n = 0; n < seeds.motifs.size(); n++) {
+            const Motif& seed = seeds.motifs[n];
+            std::vector<float> posMax, negMax, posAll, negAll;
+            float updatedQ = seed.q;
+            for (size_t fold = 0; fold < cv; fold++) {
+                Motif m = seed;
+                std::vector<uint8_t> train(P, 0), test(P, 0);
+                for (size_t i = 0; i + cv <= P; i += cv)     // strided split; the last P mod cv records are unused
+                    for (size_t f = 0; f < cv; f++) (f != fold ? train : test)[i + f] = 1;
+                if (o.EM) {
+                    bamm_em_params p;
+                    bamm_em_default_params(&p);
+                    p.K = m.K; p.W = m.W; p.bg_order = bg.K; p.q = m.q; p.optimize_q = o.optimizeQ;
+                    p.epsilon = o.epsilon; p.max_iterations = o.max_iter;
+                    bamm_em* em = nullptr;
+                    if (bamm_em_create(ctx, dseqs, &p, bg.v.data(), m.A.data(), m.v.data(), train.data(), &em)) die_abi("EM (fold)");
+                    uint32_t it = 0;
+                    auto t0 = std::chrono::high_resolution_clock::now();
+                    if (bamm_em_optimize(em, &it)) die_abi("EM::optimize (fold)");
+                    bamm_em_get_v(em, m.v.data());
+                    bamm_em_get_q(em, &updatedQ);
+                    bamm_em_destroy(em);
+                    std::cout << "\n--- Runtime for EM: " << std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() << " seconds ---\n";
+                }
+                std::vector<float> mops, zoops;
+                score_set(dseqs, kept_len, m, mops, zoops);
+                size_t o_m = 0;
+                for (size_t i = 0; i < P; i++) {
+                    const size_t nw = kept_len[i] - m.W + 1;
+                    if (test[i]) {
+                        if (o.mops) posAll.insert(posAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
+                        if (o.zoops) posMax.push_back(zoops[i]);
+                    }
+                    o_m += nw;
+                }
+                score_set(dneg, neg_len, m, mops, zoops);
+                o_m = 0;
+                for (size_t i = 0; i < negN; i++) {
+                    const size_t nw = neg_len[i] - m.W + 1;
+                    if (i % cv == 0 && i + cv <= negN) {       // negSet = every cv-th negative (FDR.cpp:58-60)
+                        if (o.mops) negAll.insert(negAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
+                        if (o.zoops) negMax.push_back(zoops[i]);
+                    }
+                    o_m += nw;
+                }
+            }
+            FdrResult res;
+            fdr_statistics(posMax, negMax, posAll, negAll, P, negN, updatedQ, o.mops, o.zoops, o.savePvalues, res);
+            if (fdr_write(o.out_dir, o.basename + "_motif_" + std::to_string(n + 1), res, P, negN, o.mops, o.zoops, o.savePRs,
+                          o.savePvalues, err)) die(err);
+        }
     }
 
     std::cout << std::endl << "******************" << std::endl << "*   Statistics   *" << std::endl << "******************" << std::endl;
@@ -392,9 +510,11 @@ int main(int nargs, char* args[]) {
               << ", min.length: " << pos.min_len << "\n	base frequencies:";
     for (int i = 0; i < 4; i++) std::cout << ' ' << pos.base_freq[i] << "(" << "ACGT"[i] << ")";
     std::cout << "\nThe background model is generated based on cond.prob of " << o.sOrder << "-mers.";
+    if (o.FDR) std::cout << "\nFolds for cross-validation (FDR estimation): " << o.cvFold;
     auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0_wall);
     std::cout << std::endl << "------ Runtime: " << dt.count() << " seconds -------" << std::endl;
 
+    if (dneg) bamm_seqs_destroy(dneg);
     if (dseqs) bamm_seqs_destroy(dseqs);
     if (ctx) bamm_ctx_destroy(ctx);
     bamm_packed_free(packed);

@@ -244,6 +244,21 @@ class Reference:
         R.ref_em_get_n.argtypes = [vp, _f32p]
         R.ref_em_write.argtypes = [vp, C.c_char_p, C.c_char_p, i]
         R.ref_logodds.argtypes = [vp, vp, vp, _f32p, _f32p, _u64p]
+        R.ref_negset_create.argtypes = [vp, u64, u64, i]
+        R.ref_negset_create.restype = vp
+        R.ref_session_size.argtypes = [vp]
+        R.ref_session_size.restype = u64
+        R.ref_occurrence.argtypes = [vp, vp, vp, _f32p, u64, f, i, C.c_char_p, C.c_char_p, _f32p]
+        R.ref_fdr_create.argtypes = [vp, vp, vp, vp, u64, i, i, i, i, i]
+        R.ref_fdr_create.restype = vp
+        R.ref_fdr_destroy.argtypes = [vp]
+        R.ref_fdr_evaluate.argtypes = [vp, i, i, f, u64]
+        R.ref_fdr_write.argtypes = [vp, C.c_char_p, C.c_char_p]
+        R.ref_fdr_scores.argtypes = [vp, i, _f32p, u64]
+        R.ref_fdr_scores.restype = u64
+        R.ref_fdr_q.argtypes = [vp]
+        R.ref_fdr_q.restype = f
+        R.ref_fdr_stats_only.argtypes = [vp, _f32p, u64, _f32p, u64, _f32p, u64, _f32p, u64, i]
 
     def set_threads(self, n):
         self.R.ref_set_threads(int(n))
@@ -254,12 +269,16 @@ class Reference:
 
 
 class RefSession:
-    def __init__(self, ref: Reference, codes, in_off, single_strand, seed, do_srand):
+    def __init__(self, ref: Reference, codes, in_off, single_strand, seed, do_srand, handle=None):
         self.ref, self.R = ref, ref.R
-        in_off = _u64(in_off)
-        self.N = len(in_off) - 1
-        self.h = self.R.ref_session_create(np.ascontiguousarray(codes, np.uint8), in_off, self.N,
-                                           int(single_strand), int(do_srand), seed)
+        if handle is None:
+            in_off = _u64(in_off)
+            self.N = len(in_off) - 1
+            self.h = self.R.ref_session_create(np.ascontiguousarray(codes, np.uint8), in_off, self.N,
+                                               int(single_strand), int(do_srand), seed)
+        else:
+            self.h = handle
+            self.N = int(self.R.ref_session_size(handle))
         self.L = np.array([self.R.ref_seq_L(self.h, n) for n in range(self.N)], np.int64)
         self.off = np.concatenate([[0], np.cumsum(self.L)]).astype(np.uint64)
         self._keep = []
@@ -323,6 +342,37 @@ class RefSession:
         z = np.zeros(self.N, np.uint64)
         self.R.ref_logodds(m, bg, self.h, mops, zoops, z)
         return mops, zoops, z
+
+    def negset(self, s_order=2, m_fold=1, generic=False):
+        """SeqGenerator(posSet, NULL, sOrder, 1, genericNeg).sample_bgseqset_by_fold(mFold)"""
+        h = self.R.ref_negset_create(self.h, s_order, m_fold, int(generic))
+        return RefSession(self.ref, None, None, True, 0, False, handle=h)
+
+    def fdr(self, neg, m, bg, cv_fold, mops, zoops, em=True, optimizeQ=False, frac=0.05, threads=1,
+            save_pvalues=True, base="x"):
+        f = self.R.ref_fdr_create(self.h, neg.h, m, bg, cv_fold, int(mops), int(zoops), 1, int(save_pvalues), 0)
+        self.R.ref_fdr_evaluate(f, int(em), int(optimizeQ), frac, threads)
+        files = {}
+        with tempfile.TemporaryDirectory() as d:
+            self.R.ref_fdr_write(f, d.encode(), base.encode())
+            for name in os.listdir(d):
+                files[name[len(base) + 1:]] = open(os.path.join(d, name), "rb").read()
+        scores = []
+        for which in range(4):
+            n = int(self.R.ref_fdr_scores(f, which, np.zeros(1, np.float32), 0))
+            buf = np.zeros(max(n, 1), np.float32)
+            self.R.ref_fdr_scores(f, which, buf, n)
+            scores.append(buf[:n].copy())
+        q = float(self.R.ref_fdr_q(f))
+        self.R.ref_fdr_destroy(f)
+        return files, scores, q
+
+    def occurrence(self, m, bg, W, neg_all, pval_cutoff, ss, base="x"):
+        pv = np.zeros(int((self.L - W + 1).sum()), np.float32)
+        with tempfile.TemporaryDirectory() as d:
+            self.R.ref_occurrence(m, bg, self.h, _f32(neg_all), len(neg_all), pval_cutoff, int(ss), d.encode(),
+                                  base.encode(), pv)
+            return open(os.path.join(d, base + ".occurrence"), "rb").read(), pv
 
     def write_motif(self, m, base="m"):
         with tempfile.TemporaryDirectory() as d:

@@ -46,6 +46,8 @@
 #define private public
 #include "refinement/EM.h"
 #include "seq_scoring/ScoreSeqSet.h"
+#include "seq_generator/SeqGenerator.h"
+#include "evaluation/FDR.h"
 #undef private
 
 namespace {
@@ -220,6 +222,68 @@ void ref_logodds(void* m, void* bg, void* h, float* mops_out, float* zoops_out, 
         zoops_out[n] = zoops[n];
         z_out[n] = sc.z_[n];
     }
+}
+
+// ---- negative set (SeqGenerator.cpp:3-42 ctor incl. srand(42), :188-204 sample_bgseqset_by_fold) ----
+void* ref_negset_create(void* h, uint64_t sOrder, uint64_t mFold, int genericNeg) {
+    Session* s = static_cast<Session*>(h);
+    SeqGenerator gen(s->seqs, NULL, sOrder, 1.0f, genericNeg != 0);
+    std::vector<std::unique_ptr<Sequence>> neg = gen.sample_bgseqset_by_fold(mFold);
+    Session* out = new Session();
+    for (auto& q : neg) out->seqs.push_back(q.release());
+    return out;
+}
+uint64_t ref_session_size(void* h) { return static_cast<Session*>(h)->seqs.size(); }
+
+// ---- ScoreSeqSet::calcPvalues + write (.occurrence)  (ScoreSeqSet.cpp:70-126, :245-291) ----
+// neg_all: all MOPS scores of the negative set (mainBaMM.cpp:215-221)
+void ref_occurrence(void* m, void* bg, void* h, const float* neg_all, uint64_t n_neg, float pval_cutoff, int ss,
+                    const char* dir, const char* base, float* pvalues_out) {
+    Session* s = static_cast<Session*>(h);
+    ScoreSeqSet sc(static_cast<Motif*>(m), static_cast<BackgroundModel*>(bg), s->seqs);
+    sc.calcLogOdds();
+    std::vector<float> neg(neg_all, neg_all + n_neg);
+    sc.calcPvalues(sc.getMopsScores(), neg);
+    std::string d(dir);
+    sc.write(&d[0], base, pval_cutoff, ss != 0);
+    size_t o = 0;
+    for (auto& v : sc.mops_p_values_) for (float x : v) pvalues_out[o++] = x;
+}
+
+// ---- FDR (FDR.cpp:3-27 ctor, :28-145 evaluateMotif, :147-276 calculatePR, :278-333 calculatePvalues, :338-450 write) ----
+void* ref_fdr_create(void* pos, void* neg, void* m, void* bg, uint64_t cvFold, int mops, int zoops, int savePRs,
+                     int savePvalues, int saveLogOdds) {
+    return new FDR(static_cast<Session*>(pos)->seqs, static_cast<Session*>(neg)->seqs, static_cast<Motif*>(m),
+                   static_cast<BackgroundModel*>(bg), cvFold, mops != 0, zoops != 0, savePRs != 0, savePvalues != 0,
+                   saveLogOdds != 0);
+}
+void ref_fdr_destroy(void* f) { delete static_cast<FDR*>(f); }
+void ref_fdr_evaluate(void* f, int em, int optimizeQ, float frac, uint64_t threads) {
+    static_cast<FDR*>(f)->evaluateMotif(em != 0, false, optimizeQ != 0, false, frac, threads);
+}
+void ref_fdr_write(void* f, const char* dir, const char* base) {
+    std::string d(dir);
+    static_cast<FDR*>(f)->write(&d[0], base);
+}
+// which: 0 posScoreMax_, 1 negScoreMax_, 2 posScoreAll_, 3 negScoreAll_ (as left by calculatePR/Pvalues: sorted)
+uint64_t ref_fdr_scores(void* f, int which, float* out, uint64_t cap) {
+    FDR* fd = static_cast<FDR*>(f);
+    std::vector<float>& v = which == 0 ? fd->posScoreMax_ : which == 1 ? fd->negScoreMax_ : which == 2 ? fd->posScoreAll_ : fd->negScoreAll_;
+    for (size_t i = 0; i < v.size() && i < cap; i++) out[i] = v[i];
+    return v.size();
+}
+float ref_fdr_q(void* f) { return static_cast<FDR*>(f)->q_; }
+// run only the statistics on caller-provided scores (unit-test entry for the host restatement)
+void ref_fdr_stats_only(void* f, const float* pos_max, uint64_t n_pos_max, const float* neg_max, uint64_t n_neg_max,
+                        const float* pos_all, uint64_t n_pos_all, const float* neg_all, uint64_t n_neg_all,
+                        int with_pvalues) {
+    FDR* fd = static_cast<FDR*>(f);
+    fd->posScoreMax_.assign(pos_max, pos_max + n_pos_max);
+    fd->negScoreMax_.assign(neg_max, neg_max + n_neg_max);
+    fd->posScoreAll_.assign(pos_all, pos_all + n_pos_all);
+    fd->negScoreAll_.assign(neg_all, neg_all + n_neg_all);
+    fd->calculatePR();
+    if (with_pvalues) fd->calculatePvalues();
 }
 
 }  // extern "C"

@@ -101,11 +101,83 @@ def run_case(R, c, store_inputs, n_iter=3, r_seqs=None, with_optimize=True):
     return out
 
 
+def run_eval_case(R):
+    """Evaluation side (config 5 / the Travis smoke line): negative sampler, 4-fold CV with EM per
+    fold, PR / p-value statistics, window p-values and the .occurrence writer -- all reference code."""
+    c = Case("eval", N=120, L0=50, W=8, K=1, seed=11, n_frac=0.01)
+    S = R.session(c.codes, c.in_off, c.ss, 42)
+    out = dict(codes=c.codes, in_off=c.in_off, W=c.W, K=c.K, q=np.float32(c.q), v0=c.v0, alpha=c.alpha,
+               alpha_bg=c.alpha_bg, A=c.A)
+    bg, vbg = S.bg(c.bg_order, c.alpha_bg)
+    out["vbg"] = vbg
+    for tag, generic in (("neg", False), ("gneg", True)):
+        neg = S.negset(2, 2, generic)
+        out[tag + "_codes"] = neg.seq_codes()
+        out[tag + "_off"] = neg.off
+        if not generic:
+            keep = neg
+    m = S.motif(c.W, c.K, c.alpha, bg, c.q, c.v0)
+    files, scores, q = S.fdr(keep, m, bg, 4, True, True, em=True, optimizeQ=False, threads=1)
+    for name, data in files.items():
+        out["fdr_file_" + name.replace(".", "_")] = np.frombuffer(data, np.uint8)
+    for name, sc in zip(("pos_max", "neg_max", "pos_all", "neg_all"), scores):
+        out["fdr_" + name] = sc
+    out["fdr_q"] = np.float32(q)
+    # occurrences: positives scored with a model refined by 3 EM passes, negatives = sampled set
+    e = S.em(m, bg, False, False)
+    for _ in range(3):
+        S.R.ref_em_estep(e); S.R.ref_em_mstep(e)
+    out["occ_v"] = S.motif_v(m)
+    neg_mops, _, _ = keep.logodds(m, bg, c.W)
+    pos_mops, _, _ = S.logodds(m, bg, c.W)
+    out["occ_neg_mops"], out["occ_pos_mops"] = neg_mops, pos_mops
+    data, pv = S.occurrence(m, bg, c.W, neg_mops, 0.02, c.ss)
+    out["occ_file"] = np.frombuffer(data, np.uint8)
+    out["occ_pvalues"] = pv
+    np.savez_compressed(os.path.join(HERE, "eval_small.npz"), **out)
+    print("wrote eval_small")
+
+
+def run_travis_case(R):
+    """The reference's CI smoke line (.travis.yml:21): JunD.fasta + PWM_peng10.meme, --EM -k 0 --FDR
+    --scoreSeqset --maxPWM 1.  FASTA parsing and the PWM seeding go through our pinned restatements
+    (the reference's reader needs Boost); everything from there on is reference code."""
+    from tests.test_host_io_cpu import FASTA, MEME, read_fasta_py
+    codes, off = read_fasta_py(FASTA)
+    O = oracle.Oracle()
+    O.set_threads(1)
+    S = R.session(codes, off, False, 42)
+    kmer = S.kmers()
+    alpha_bg = np.array([1, 10, 10], np.float32)
+    bg, vbg = S.bg(2, alpha_bg)
+    lines = open(MEME).read().split("\n")
+    i = [k for k, l in enumerate(lines) if "letter-probability matrix" in l][0]
+    W, K = 12, 0
+    pwm = np.array([[float(x) for x in lines[i + 1 + j].split()] for j in range(W)], np.float32).T.copy()
+    alpha = np.array([1.0], np.float32)
+    v0 = O.init_from_pwm(pwm, W, K, np.repeat(alpha, W), vbg, kmer, S.off, 0.3)
+    neg = S.negset(2, 5000 // 300 + 1, False)                  # mainBaMM.cpp:100-106
+    m = S.motif(W, K, alpha, bg, 0.3, v0)
+    e = S.em(m, bg, False, False)
+    S.R.ref_em_optimize(e)
+    out = dict(v0=v0, v_final=S.motif_v(m), vbg=vbg, neg_n=neg.N, neg_len=neg.L[:4])
+    neg_mops, _, _ = neg.logodds(m, bg, W)
+    occ, _ = S.occurrence(m, bg, W, neg_mops, 1e-4, False, base="JunD_motif_1")
+    out["occurrence"] = np.frombuffer(occ, np.uint8)
+    m2 = S.motif(W, K, alpha, bg, 0.3, v0)
+    files, scores, q = S.fdr(neg, m2, bg, 4, False, True, em=True, optimizeQ=False, threads=1, save_pvalues=False)
+    out["zoops_stats"] = np.frombuffer(files["zoops.stats"], np.uint8)
+    np.savez_compressed(os.path.join(HERE, "travis_jund.npz"), **out)
+    print("wrote travis_jund", neg.N, len(occ), len(files["zoops.stats"]))
+
+
 def main():
     if not oracle.have_reference():
         raise SystemExit("oracle/_ref/libbammref.so missing: run `make -C oracle ref` in the dev container")
     R = oracle.Reference()
     R.set_threads(1)
+    run_eval_case(R)
+    run_travis_case(R)
     for spec in SMALL_CASES:
         c = Case(**spec)
         big = c.N * c.L0 > 20000

@@ -75,3 +75,47 @@ def test_cli_em_on_jund(K, tmp_path, orc, gpu_ctx):
     assert abs((len(pos) - 1) - n_hits) <= 3                 # r right at the 0.3 cut-off may flip
     f = pos[1].split("\t")
     assert f[0].startswith(">") and f[1] == "205" and f[2] in "+-" and len(f[4]) == W
+
+
+def test_cli_travis_smoke_line(tmp_path, gpu_ctx):
+    """The reference's own CI command (.travis.yml:21) through the drop-in CLI:
+    --EM -k 0 --FDR --scoreSeqset --maxPWM 1; outputs against what the reference's EM / FDR /
+    ScoreSeqSet / SeqGenerator produced for the same inputs (tests/golden/travis_jund.npz)."""
+    from tests import golden_util as gu
+    build.build_host()
+    g = dict(np.load(os.path.join(gu.GOLDEN_DIR, "travis_jund.npz")))
+    out = tmp_path / "o"
+    r = subprocess.run([build.CLI, str(out), FASTA, "--PWMFile", MEME, "--EM", "-k", "0", "--FDR", "--scoreSeqset",
+                        "--maxPWM", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    assert sorted(os.listdir(out)) == ["JunD.hbcp", "JunD.hbp", "JunD_motif_1.ihbcp", "JunD_motif_1.ihbp",
+                                       "JunD_motif_1.occurrence", "JunD_motif_1.zoops.stats"]
+    assert r.stdout.count("--- Runtime for EM:") == 5                    # 1 full run + 4 folds (SURVEY section 6)
+    v = parse_ihbcp(out / "JunD_motif_1.ihbcp", 0, 12)
+    np.testing.assert_allclose(v, g["v_final"], rtol=2e-3, atol=1e-6)
+
+    def rows(b):
+        lines = b.decode().strip().split("\n")
+        return lines[0], [l.rstrip("\t").split("\t") for l in lines[1:]]
+
+    h_ref, ref = rows(g["zoops_stats"].tobytes())
+    h_mine, mine = rows(open(out / "JunD_motif_1.zoops.stats", "rb").read())
+    assert h_mine.split("\t")[:6] == h_ref.split("\t")[:6]               # TP FP FDR Recall p-value mFold=17
+    assert float(h_mine.split("\t")[6]) == pytest.approx(float(h_ref.split("\t")[6]), abs=5e-3)   # occ_frac
+    assert len(mine) == len(ref) == 300 + 5100
+    a = np.array(mine, float)
+    b = np.array(ref, float)
+    assert np.mean(np.all(a[:, :2] == b[:, :2], axis=1)) > 0.98          # TP/FP ranks: ties may swap
+    np.testing.assert_allclose(a[:, 4], b[:, 4], rtol=0.05, atol=2e-4)   # p-values along the ranking
+
+    def hits(bts):
+        return {tuple(l.split("\t")[:4]) for l in bts.decode().strip().split("\n")[1:]}
+
+    ref_hits = {(("&gt;" if False else ">") + k[0][3:] if False else k) for k in hits(g["occurrence"].tobytes())}
+    my_hits = hits(open(out / "JunD_motif_1.occurrence", "rb").read())
+    # the golden used synthetic headers (seqN); compare on (index-free) length/strand/start..end per row count
+    assert abs(len(my_hits) - len(ref_hits)) <= max(3, 0.02 * len(ref_hits))
+    ref_pos = sorted((k[1], k[2], k[3]) for k in ref_hits)
+    my_pos = sorted((k[1], k[2], k[3]) for k in my_hits)
+    common = len(set(ref_pos) & set(my_pos))
+    assert common >= 0.95 * len(set(ref_pos))
