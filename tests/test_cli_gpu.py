@@ -108,14 +108,12 @@ def test_cli_travis_smoke_line(tmp_path, gpu_ctx):
     assert np.mean(np.all(a[:, :2] == b[:, :2], axis=1)) > 0.98          # TP/FP ranks: ties may swap
     np.testing.assert_allclose(a[:, 4], b[:, 4], rtol=0.05, atol=2e-4)   # p-values along the ranking
 
-    def hits(bts):
-        return {tuple(l.split("\t")[:4]) for l in bts.decode().strip().split("\n")[1:]}
+    def hits(bts):                      # golden rows carry synthetic headers (seqN): compare strand + range
+        return sorted(tuple(l.split("\t")[1:4]) for l in bts.decode().strip().split("\n")[1:])
 
-    ref_hits = {(("&gt;" if False else ">") + k[0][3:] if False else k) for k in hits(g["occurrence"].tobytes())}
+    ref_hits = hits(g["occurrence"].tobytes())
     my_hits = hits(open(out / "JunD_motif_1.occurrence", "rb").read())
-    # the golden used synthetic headers (seqN); compare on (index-free) length/strand/start..end per row count
-    assert abs(len(my_hits) - len(ref_hits)) <= max(3, 0.02 * len(ref_hits))
-    ref_pos = sorted((k[1], k[2], k[3]) for k in ref_hits)
-    my_pos = sorted((k[1], k[2], k[3]) for k in my_hits)
-    common = len(set(ref_pos) & set(my_pos))
-    assert common >= 0.95 * len(set(ref_pos))
+    assert abs(len(my_hits) - len(ref_hits)) <= max(3, 0.02 * len(ref_hits))    # p right at the cut-off may flip
+    from collections import Counter
+    common = sum((Counter(ref_hits) & Counter(my_hits)).values())
+    assert common >= 0.97 * len(ref_hits)
