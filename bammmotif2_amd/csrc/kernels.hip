@@ -165,6 +165,62 @@ __device__ __forceinline__ uint32_t pick_sequence(const SeqView& sv, uint32_t t)
     return sv.idx ? sv.idx[t] : t;
 }
 
+// The same decode split in two so that the HBM loads of sequence t+1 are in flight while
+// sequence t is being processed (a wave owns one sequence at a time; without this every
+// sequence starts with a chain of dependent global loads).
+template <int M>
+struct RawSeq {
+    static constexpr int NSEL = (M + 14) / 16 + 1;
+    uint32_t seq, L;
+    uint32_t w[NSEL + 1];
+    uint64_t e0, e1;
+    bool ok;
+};
+template <int M>
+__device__ __forceinline__ RawSeq<M> fetch_seq(const SeqView& sv, uint32_t t, int lane) {
+    RawSeq<M> r;
+    r.seq = pick_sequence(sv, t);
+    r.ok = !(sv.mask && !sv.mask[r.seq]);
+    r.L = sv.len[r.seq];
+    const uint32_t* wp = sv.words + sv.word_off[r.seq];
+    const uint32_t nw = (r.L + 15u) >> 4;
+    const uint32_t wi0 = ((uint32_t)lane * M) >> 4;
+    r.w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+    for (int i = 0; i < RawSeq<M>::NSEL; i++) r.w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+    r.e0 = sv.exc_off[r.seq];
+    r.e1 = sv.exc_off[r.seq + 1];
+    return r;
+}
+template <int M>
+__device__ __forceinline__ void decode_raw(const RawSeq<M>& r, const SeqView& sv, uint32_t Y, uint32_t limit, int lane,
+                                           uint32_t (&y)[M]) {
+    constexpr int NSEL = RawSeq<M>::NSEL;
+    const uint32_t p0 = (uint32_t)lane * M;
+    const uint32_t wi0 = p0 >> 4;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const uint32_t p = p0 + m;
+        const uint32_t sel = (p >> 4) - wi0;
+        uint32_t lo = r.w[1], hi = r.w[0];
+#pragma unroll
+        for (int c = 1; c < NSEL; c++) {
+            lo = (sel == (uint32_t)c) ? r.w[c + 1] : lo;
+            hi = (sel == (uint32_t)c) ? r.w[c] : hi;
+        }
+        const uint32_t sh = 30u - 2u * (p & 15u);
+        y[m] = __builtin_amdgcn_alignbit(hi, lo, sh) & (Y - 1u);
+    }
+    for (uint64_t e = r.e0; e < r.e1; e++) {             // N exceptions (Sequence.cpp:38)
+        const uint2 x = sv.exc[e];
+        const int mm = (int)x.x - (int)p0;
+#pragma unroll
+        for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) y[m] = (p0 + m < limit) ? y[m] : Y;
+}
+
 // ---- fused E+M sequence kernel --------------------------------------------------------------
 template <int M, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
@@ -201,17 +257,22 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0;
 
-    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
-        const uint32_t seq = pick_sequence(a.sv, t);
+    uint32_t t = blockIdx.x * waves_per_block + wave;
+    RawSeq<M> nxt{};
+    if (t < a.sv.count) nxt = fetch_seq<M>(a.sv, t, lane);
+    for (; t < a.sv.count; t += total_waves) {
+        const RawSeq<M> cur = nxt;
+        if (t + total_waves < a.sv.count) nxt = fetch_seq<M>(a.sv, t + total_waves, lane);   // prefetch
+        const uint32_t seq = cur.seq;
         if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
-        if (a.sv.mask && !a.sv.mask[seq]) continue;
-        const uint32_t L = a.sv.len[seq];
+        if (!cur.ok) continue;
+        const uint32_t L = cur.L;
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
 
         uint32_t y[M];
         // EM.cpp:167: only positions ij < LW1 take part; everything beyond reads the neutral row
-        decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
+        decode_raw<M>(cur, a.sv, Y, LW1, lane, y);
 
         // ---- E-step: U[m] after column j = prod_{j'<=j} s[j'][y(p-j+j')]  (EM.cpp:167-176)
         float U[M];
