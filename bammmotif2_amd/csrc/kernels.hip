@@ -102,6 +102,21 @@ __device__ __forceinline__ void lds_add_u64_masked(uint32_t byte_addr, unsigned 
                  :: "v"(byte_addr), "v"(v), "s"(pad_mask), "s"(nz_mask) : "memory");
 }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// One slot of one column.  The long-sequence classes (M > 16) keep 2*M wave masks, more than the
+// SGPR file holds; there the predication is left to the compiler (hipcc's spill code around the
+// hand-written exec sequence miscounted at M = 28).
+template <int M>
+__device__ __forceinline__ void lds_add_slot(uint32_t byte_addr, unsigned long long v, unsigned long long pad_mask,
+                                             unsigned long long nz_mask, bool pad_ok) {
+    if constexpr (M <= 16) {
+        lds_add_u64_masked(byte_addr, v, pad_mask, nz_mask);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+        if (pad_ok && v != 0ull) atomicAdd((unsigned long long*)(lds_u64*)(size_t)byte_addr, v);
+#endif
+    }
+}
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float x) {
@@ -276,6 +291,19 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 
         // ---- E-step: U[m] after column j = prod_{j'<=j} s[j'][y(p-j+j')]  (EM.cpp:167-176)
         float U[M];
+        if constexpr (M > 16) {
+            // long-sequence classes: 4*M live floats per quad would spill (256 VGPRs); read the
+            // same [W/4][Y+1][4] table one column at a time instead
+#pragma unroll
+            for (int m = 0; m < M; m++) U[m] = s_lds[y[m] * 4u];
+            for (uint32_t j = 1; j < W; j++) {
+                const float* sj = s_lds + (size_t)(j >> 2) * Ys * 4u + (j & 3u);
+                const float carry = wave_shr1(1.0f, U[M - 1]);
+#pragma unroll
+                for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m] * 4u];
+                U[0] = carry * sj[y[0] * 4u];
+            }
+        } else {
         uint32_t sa[M];                                  // LDS byte address of row y(p) in the current quad
         const uint32_t s_base = lds_offset(s_lds);
 #pragma unroll
@@ -309,6 +337,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 #pragma unroll
               for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].w;
               U[0] = c * sv[0].w; }
+        }
         }
         // slot p now holds the product of window start i = p-(W-1); valid for W-1 <= p < L
         const float pos_i = q / (float)LW1;              // EM.cpp:160
@@ -364,7 +393,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                     if (jb + t < W) {
 #pragma unroll
                         for (int m = 0; m < M; m++)
-                            lds_add_u64_masked(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M]);
+                            lds_add_slot<M>(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M], y[m] != Y);
                         F[t] = wave_shl1_u64(F[t]);
                         nz[t] = __ballot(F[t] != 0ull);
                         col -= stride;
@@ -522,7 +551,7 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
                 if (jb + t < nc) {
 #pragma unroll
                     for (int m = 0; m < M; m++)
-                        lds_add_u64_masked(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M]);
+                        lds_add_slot<M>(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M], y[m] != Y);
                     F[t] = wave_shl1_u64(F[t]);
                     nz[t] = __ballot(F[t] != 0ull);
                     col -= stride;

@@ -244,3 +244,54 @@ def test_empty_set_and_errors(gpu_ctx, orc):
         bm.EM(gpu_ctx, ss2, c2.K, c2.W, vbg2, c2.A, c2.v0, c2.q)
     assert e.value.code == bm.abi.ERR_ARG
     ss2.close()
+
+
+EXTRA_SHAPES = [
+    dict(name="x_long_M32", N=6, L0=1900, W=25, K=2, ss=True, ragged=140, n_frac=0.002),      # M classes 28/32
+    dict(name="x_long_ds_M24", N=8, L0=720, W=17, K=1, ragged=60),                             # ds -> L ~ 1441: M = 24
+    dict(name="x_w_odd_k3", N=40, L0=90, W=13, K=3, ragged=20, n_frac=0.01),                   # W not a multiple of 4
+    dict(name="x_w3_k0", N=50, L0=30, W=3, K=0, ss=True, ragged=5),
+    dict(name="x_w_gt_L", N=20, L0=24, W=24, K=2, ss=True),                                    # exactly one window
+    dict(name="x_bg_order0", N=60, L0=64, W=9, K=2, bg_order=0),
+    dict(name="x_bg_order3_k1", N=60, L0=64, W=9, K=1, bg_order=3),                            # K_bg = min(3, 1)
+    dict(name="x_all_lengths", N=130, L0=330, W=10, K=2, ss=True, ragged=300),                 # many M buckets in one set
+    dict(name="x_M12_14_16", N=40, L0=820, W=21, K=2, ss=True, ragged=110, n_frac=0.003),      # 512-thread classes
+    dict(name="x_M20_28_ds", N=24, L0=760, W=20, K=2, ragged=130),                             # ds: L 1261..1781
+]
+
+
+@pytest.mark.parametrize("spec", EXTRA_SHAPES, ids=[d["name"] for d in EXTRA_SHAPES])
+def test_shapes_and_length_buckets(spec, gpu_ctx, orc):
+    """Every kernel instantiation (M = 1..32 positions per lane), odd widths, bg orders above and
+    below the motif order, single-window sequences, mixed-length sets."""
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+    Kb = min(c.bg_order, c.K)
+    em.EStep()
+    s_o = orc.linear_s(c.v0, vbg, c.K, c.W, Kb)
+    r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, c.q)
+    np.testing.assert_allclose(em.getR(), r_o, rtol=2e-5, atol=R_ATOL)
+    np.testing.assert_allclose(em.getLLH(), llh_o, rtol=LLH_RTOL, atol=5e-7 * c.N)
+    em.MStep()
+    n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
+    np.testing.assert_allclose(em.getCounts(), n_o, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(em.getV(), orc.update_v(n_o, c.A, vbg, c.K, c.W), rtol=2e-5, atol=1e-9)
+    em.iterate(3)
+    res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, em.getV() * 0 + c.v0, c.q, optimizeQ=True,
+                       epsilon=0.0, max_iter=4)
+    # 1 (EStep/MStep without q update) + 3 fused passes vs 4 oracle passes differ only in the
+    # first pass's q update; compare the scorer instead on the device's own model
+    v = em.getV()
+    s_log = orc.log_s(v, vbg, c.K, c.W, Kb)
+    mops_o, zoops_o, z_o = orc.logodds(kmer, off, c.K, c.W, s_log)
+    mops, zoops, z = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, v, vbg)
+    assert np.array_equal(mops, mops_o) and np.array_equal(zoops, zoops_o) and np.array_equal(z, z_o)
+    em.close(); ss.close()
+
+
+def test_sequence_longer_than_envelope_is_refused(gpu_ctx, orc):
+    c = Case("toolong", N=2, L0=2100, W=8, K=1, ss=True)
+    _, kmer, off, _ = c.encode(orc)
+    with pytest.raises(bm.abi.BammError) as e:
+        bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
+    assert e.value.code == bm.abi.ERR_UNSUPPORTED
