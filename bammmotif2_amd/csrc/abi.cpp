@@ -765,6 +765,11 @@ int bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches) {
 // ------------------------------------------------------------------------------ scorer -----
 int bamm_logodds(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, uint32_t bg_order, const float* v, const float* vbg,
                  float* mops, uint64_t mops_cap, float* zoops, uint64_t* z) {
+    return bamm_logodds_subset(c, s, nullptr, K, W, bg_order, v, vbg, mops, mops_cap, zoops, z);
+}
+
+int bamm_logodds_subset(bamm_ctx* c, bamm_seqs* s, const uint8_t* seq_mask, uint32_t K, uint32_t W, uint32_t bg_order,
+                        const float* v, const float* vbg, float* mops, uint64_t mops_cap, float* zoops, uint64_t* z) {
     if (!c || !s || !v || !vbg || !zoops || !z) { set_error("bamm_logodds: null argument"); return BAMM_ERR_ARG; }
     if (K > BAMM_MAX_ORDER || W == 0) { set_error("bamm_logodds: bad K/W"); return BAMM_ERR_ARG; }
     if (s->n && s->min_len < W) { set_error("a sequence is shorter than the motif (W=%u)", W); return BAMM_ERR_ARG; }
@@ -789,16 +794,24 @@ int bamm_logodds(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, uint32_t bg_
     float *d_tab = nullptr, *d_mops = nullptr, *d_zoops = nullptr;
     uint64_t* d_moff = nullptr;
     uint32_t* d_z = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_tab); (void)hipFree(d_mops); (void)hipFree(d_zoops); (void)hipFree(d_moff); (void)hipFree(d_z); };
+    uint8_t* d_smask = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_tab); (void)hipFree(d_mops); (void)hipFree(d_zoops); (void)hipFree(d_moff); (void)hipFree(d_z); (void)hipFree(d_smask); };
     if ((rc = dev_upload(&d_tab, tab.data(), tab.size(), st)) || (rc = dev_upload(&d_moff, moff.data(), moff.size(), st)) ||
-        (rc = dev_alloc(&d_zoops, s->n)) || (rc = dev_alloc(&d_z, s->n)) || (mops && (rc = dev_alloc(&d_mops, moff[s->n])))) {
+        (rc = dev_alloc(&d_zoops, s->n)) || (rc = dev_alloc(&d_z, s->n)) || (mops && (rc = dev_alloc(&d_mops, moff[s->n]))) ||
+        (seq_mask && (rc = dev_upload(&d_smask, seq_mask, s->n, st)))) {
         cleanup();
         return rc;
+    }
+    if (seq_mask) {                                          // sequences outside the subset report zeros
+        hipError_t e = hipMemsetAsync(d_zoops, 0, s->n * sizeof(float), st);
+        if (e == hipSuccess) e = hipMemsetAsync(d_z, 0, s->n * sizeof(uint32_t), st);
+        if (e == hipSuccess && mops) e = hipMemsetAsync(d_mops, 0, moff[s->n] * sizeof(float), st);
+        if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); cleanup(); return BAMM_ERR_HIP; }
     }
     for (size_t bi = 0; bi < s->buckets.size() && !rc; bi++) {
         const Bucket& bk = s->buckets[bi];
         ScoreKernelArgs a{};
-        a.sv = make_view(s, exc, bk, nullptr);
+        a.sv = make_view(s, exc, bk, d_smask);
         a.K = K; a.W = W; a.Y = Y; a.s = d_tab; a.mops = d_mops; a.mops_off = d_moff; a.zoops = d_zoops; a.z = d_z;
         const uint32_t threads = default_threads(c, bk.mclass);
         uint32_t blocks = default_blocks(c, threads);

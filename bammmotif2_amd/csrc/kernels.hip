@@ -586,6 +586,7 @@ __global__ void __launch_bounds__(THREADS) k_score(ScoreKernelArgs a) {
 
     for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
         const uint32_t seq = pick_sequence(a.sv, t);
+        if (a.sv.mask && !a.sv.mask[seq]) continue;
         const uint32_t L = a.sv.len[seq];
         const uint32_t p0 = (uint32_t)lane * M;
         uint32_t y[M];

@@ -312,8 +312,10 @@ class EM:
             self.h = None
 
 
-def logodds(ctx: Context, seqs: SeqSet, K: int, W: int, bg_order: int, v, vbg, want_mops: bool = True):
-    """ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67): returns (mops or None, zoops, z)."""
+def logodds(ctx: Context, seqs: SeqSet, K: int, W: int, bg_order: int, v, vbg, want_mops: bool = True, mask=None):
+    """ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67): returns (mops or None, zoops, z).
+
+    mask: optional per-sequence bytes; sequences with 0 are skipped and report zeros."""
     lib = ctx.lib
     N = seqs.n_seqs
     total = int((seqs.lengths.astype(np.int64) - W + 1).sum()) if N else 0
@@ -321,7 +323,13 @@ def logodds(ctx: Context, seqs: SeqSet, K: int, W: int, bg_order: int, v, vbg, w
     zoops = np.zeros(max(N, 1), np.float32)
     z = np.zeros(max(N, 1), np.uint64)
     mptr = mops.ctypes.data_as(C.c_void_p) if want_mops else None
-    check(lib.bamm_logodds(ctx.h, seqs.h, K, W, bg_order, _f32(v), _f32(vbg), mptr, total, zoops, z))
+    if mask is None:
+        check(lib.bamm_logodds(ctx.h, seqs.h, K, W, bg_order, _f32(v), _f32(vbg), mptr, total, zoops, z))
+    else:
+        mk = np.ascontiguousarray(mask, np.uint8)
+        assert len(mk) == N
+        check(lib.bamm_logodds_subset(ctx.h, seqs.h, mk.ctypes.data_as(C.c_void_p), K, W, bg_order, _f32(v), _f32(vbg),
+                                      mptr, total, zoops, z))
     return (mops[:total] if want_mops else None), zoops[:N], z[:N]
 
 

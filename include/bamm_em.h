@@ -182,6 +182,12 @@ int  bamm_logodds(bamm_ctx* ctx, bamm_seqs* seqs, uint32_t K, uint32_t W, uint32
                   const float* v_flat, const float* vbg, float* mops, uint64_t mops_cap,
                   float* zoops, uint64_t* z);
 
+/* same, restricted to the sequences with seq_mask[n] != 0 (the others report 0): the test /
+ * negative subsets of one CV fold over a shared resident set (FDR.cpp:49-60,84-89).          */
+int  bamm_logodds_subset(bamm_ctx* ctx, bamm_seqs* seqs, const uint8_t* seq_mask, uint32_t K, uint32_t W,
+                         uint32_t bg_order, const float* v_flat, const float* vbg, float* mops,
+                         uint64_t mops_cap, float* zoops, uint64_t* z);
+
 /* ------------------------------------------------------------------ small host helpers -- */
 /* BackgroundModel ctor + calculateV (BackgroundModel.cpp:3-46, :441-473): interpolated
  * order-K conditionals learned from a packed set; alpha[K+1]; vbg_out[bamm_bg_size(K)].     */

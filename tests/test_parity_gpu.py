@@ -295,3 +295,21 @@ def test_sequence_longer_than_envelope_is_refused(gpu_ctx, orc):
     with pytest.raises(bm.abi.BammError) as e:
         bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
     assert e.value.code == bm.abi.ERR_UNSUPPORTED
+
+
+def test_logodds_subset(gpu_ctx, orc):
+    c = Case(**SMALL_CASES[0])
+    seq, kmer, off, vbg = c.encode(orc)
+    ss = bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
+    mask = (np.arange(c.N) % 4 == 2).astype(np.uint8)
+    full = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, c.v0, vbg)
+    sub = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, c.v0, vbg, mask=mask)
+    sel = mask.astype(bool)
+    assert np.array_equal(sub[1][sel], full[1][sel]) and np.array_equal(sub[2][sel], full[2][sel])
+    assert np.all(sub[1][~sel] == 0) and np.all(sub[2][~sel] == 0)
+    lens = np.diff(off.astype(np.int64)) - c.W + 1
+    moff = np.concatenate([[0], np.cumsum(lens)])
+    for n in range(c.N):
+        a, b = sub[0][moff[n]:moff[n + 1]], full[0][moff[n]:moff[n + 1]]
+        assert np.array_equal(a, b) if sel[n] else np.all(a == 0)
+    ss.close()
