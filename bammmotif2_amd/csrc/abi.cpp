@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -69,6 +70,15 @@ struct bamm_seqs {
     std::vector<uint32_t> h_exc_pos, h_exc_kmer, h_exc_clean;
     std::vector<Bucket> buckets;
     std::map<uint32_t, ExcK> exc_by_order;
+
+    ~bamm_seqs() {                               // also runs on every error path of bamm_seqs_upload
+        (void)hipFree(d_words);
+        (void)hipFree(d_word_off);
+        (void)hipFree(d_len);
+        (void)hipFree(d_pos_off);
+        for (auto& b : buckets) (void)hipFree(b.d_idx);
+        for (auto& kv : exc_by_order) { (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc); }
+    }
 };
 
 struct bamm_em {
@@ -90,7 +100,7 @@ struct bamm_em {
     float* h_status = nullptr;                  // pinned, 8 floats
     uint32_t total_blocks = 0;
     std::vector<uint32_t> bucket_blocks;
-    std::vector<uint32_t> bucket_logc;
+    std::vector<uint32_t> bucket_logc, bucket_sparse_cap, bucket_sparse_bytes;
     uint32_t threads = 0;
     // column-sliced path (tables beyond the fused kernel's LDS budget)
     bool sliced = false;
@@ -143,8 +153,12 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
     int rc = dev_upload(&k.d_off, off.data(), off.size(), s->ctx->stream);
     if (rc) return rc;
     rc = dev_upload(&k.d_exc, ex.data(), ex.size(), s->ctx->stream);
-    if (rc) return rc;
-    BAMM_HIP(hipStreamSynchronize(s->ctx->stream));   // host vectors go out of scope
+    if (rc) { (void)hipFree(k.d_off); return rc; }
+    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {   // host vectors go out of scope
+        (void)hipFree(k.d_off); (void)hipFree(k.d_exc);
+        set_error("stream sync failed while uploading the exception list");
+        return BAMM_ERR_HIP;
+    }
     auto ins = s->exc_by_order.emplace(K, k);
     *out = &ins.first->second;
     return BAMM_OK;
@@ -159,6 +173,12 @@ uint32_t default_blocks(const bamm_ctx* c, uint32_t threads) {
     if (c->blocks) return c->blocks;
     const uint32_t cus = c->num_cus > 0 ? (uint32_t)c->num_cus : 256u;
     return cus * std::max(1u, 2048u / threads);       // fill 32 waves per CU
+}
+
+// a process may drive several devices (one context each): make the context's device current
+int use_device(const bamm_ctx* c) {
+    BAMM_HIP(hipSetDevice(c->device));
+    return BAMM_OK;
 }
 
 int record_event(bamm_em* em, bool start) {
@@ -181,8 +201,9 @@ int record_event(bamm_em* em, bool start) {
 int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
     bamm_seqs* s = em->seqs;
     hipStream_t st = em->ctx->stream;
-    int rc = record_event(em, true);
+    int rc = use_device(em->ctx);
     if (rc) return rc;
+    if ((rc = record_event(em, true))) return rc;
     uint32_t block_base = 0;
     for (size_t b = 0; b < s->buckets.size(); b++) {
         const Bucket& bk = s->buckets[b];
@@ -190,6 +211,8 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
         a.sv = make_view(s, em->exc, bk, em->d_mask);
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
         a.logC = em->bucket_logc[b];
+        a.sparse_cap = accum ? em->bucket_sparse_cap[b] : 0u;
+        a.sparse_wave_bytes = accum ? em->bucket_sparse_bytes[b] : 0u;
         a.s = replay_last ? em->s_last : em->d_s;
         a.q = replay_last ? em->q_last : em->d_q;
         a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
@@ -239,7 +262,8 @@ int run_update(bamm_em* em) {
     u.q = em->d_q; u.q_out = em->d_q_alt; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
     u.iteration = em->d_iteration; u.optimize_q = em->prm.optimize_q;
     u.n_seqs_override = (double)em->prm.n_seqs_global;
-    int rc = launch_update(u, em->ctx->stream);
+    int rc = use_device(em->ctx);
+    if (!rc) rc = launch_update(u, em->ctx->stream);
     if (rc) return rc;
     std::swap(em->d_s, em->d_s_alt);
     std::swap(em->d_q, em->d_q_alt);
@@ -249,6 +273,7 @@ int run_update(bamm_em* em) {
 }
 
 int fetch_status(bamm_em* em) {
+    BAMM_HIP(hipSetDevice(em->ctx->device));
     BAMM_HIP(hipMemcpyAsync(em->h_status, em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
     return BAMM_OK;
@@ -382,9 +407,9 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
         b.mclass = mc;
         b.count = (uint32_t)members[mc].size();
         b.work = (double)b.count * kMClasses[mc];
-        if (used > 1)
-            if ((rc = dev_upload(&b.d_idx, members[mc].data(), members[mc].size(), c->stream))) return rc;
         s->buckets.push_back(b);
+        if (used > 1)
+            if ((rc = dev_upload(&s->buckets.back().d_idx, members[mc].data(), members[mc].size(), c->stream))) return rc;
     }
     BAMM_HIP(hipStreamSynchronize(c->stream));
     s->hbm_bytes = (w1 - w0) * 4 + (s->n + 1) * 8 * 2 + s->n * 4;
@@ -395,12 +420,7 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
 int bamm_seqs_destroy(bamm_seqs* s) {
     if (!s) return BAMM_OK;
     if (--s->refs > 0) return BAMM_OK;
-    (void)hipFree(s->d_words);
-    (void)hipFree(s->d_word_off);
-    (void)hipFree(s->d_len);
-    (void)hipFree(s->d_pos_off);
-    for (auto& b : s->buckets) (void)hipFree(b.d_idx);
-    for (auto& kv : s->exc_by_order) { (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc); }
+    (void)hipSetDevice(s->ctx->device);
     delete s;
     return BAMM_OK;
 }
@@ -417,6 +437,7 @@ int bamm_seqs_info(const bamm_seqs* s, uint64_t* n_seqs, uint64_t* total_len, ui
 // ------------------------------------------------------------------------------ EM ---------
 int bamm_em_destroy(bamm_em* em) {
     if (!em) return BAMM_OK;
+    (void)hipSetDevice(em->ctx->device);
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_q,
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_red,
@@ -443,7 +464,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     }
     const uint32_t Y = (uint32_t)ipow4(prm->K + 1);
     const size_t kLds = 160 * 1024;
-    const bool sliced = em_lds_bytes(prm->W, Y, true, 0) > kLds;
+    const bool sliced = em_lds_bytes(prm->W, Y, true, 0, 0) > kLds;
     uint32_t e_cols = 0, m_cols = 0;
     if (sliced) {
         while (e_cols < prm->W && e_slice_lds_bytes(e_cols + 1, Y) <= kLds) e_cols++;
@@ -515,7 +536,20 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         // 16 waves per CU saturate the LDS pipe (tools/lds_bench2.hip); the LDS left over goes
         // into private copies of the count table
         const uint32_t blocks_per_cu = sliced ? 1u : std::max(1u, 1024u / threads);
-        em->bucket_logc.push_back(sliced ? 0u : pick_log_copies(prm->W, Y, blocks_per_cu));
+        // sparse M-step scratch (per wave) competes with the private copies for LDS; it is only
+        // enabled when at least 4 copies survive next to it
+        const int Mcls = kMClasses[b.mclass];
+        size_t scratch = sliced ? 0 : sparse_wave_bytes(Mcls) * (threads / 64u);
+        uint32_t cap = sliced ? 0u : sparse_cap_for(Mcls);
+        if (getenv("BAMM_NO_SPARSE")) { cap = 0; scratch = 0; }
+        if (cap && (em_lds_bytes(prm->W, Y, true, 0, scratch) > kLds / blocks_per_cu ||
+                    pick_log_copies(prm->W, Y, blocks_per_cu, scratch) + 1 < pick_log_copies(prm->W, Y, blocks_per_cu, 0))) {
+            cap = 0;
+            scratch = 0;
+        }
+        em->bucket_sparse_cap.push_back(cap);
+        em->bucket_sparse_bytes.push_back((uint32_t)(cap ? sparse_wave_bytes(Mcls) : 0));
+        em->bucket_logc.push_back(sliced ? 0u : pick_log_copies(prm->W, Y, blocks_per_cu, scratch));
         const uint32_t all = c->blocks ? c->blocks : (uint32_t)std::max(1, c->num_cus) * blocks_per_cu;
         uint32_t nb = (uint32_t)std::max(1.0, std::floor(all * (b.work / total_work) + 0.5));
         const uint32_t waves_per_block = threads / 64u;
@@ -635,6 +669,7 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
 
 static int copy_out(bamm_em* em, float* dst, const float* src, size_t count) {
     if (!em || !dst) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipSetDevice(em->ctx->device));
     BAMM_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
     return BAMM_OK;
@@ -684,6 +719,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
     const uint64_t base = s->h_pos_off[begin], total = s->h_pos_off[end] - base;
     if (out_cap < total) { set_error("bamm_em_get_r: output holds %llu floats, %llu needed", (unsigned long long)out_cap, (unsigned long long)total); return BAMM_ERR_ARG; }
     if (total == 0) return BAMM_OK;
+    BAMM_HIP(hipSetDevice(em->ctx->device));
     hipStream_t st = em->ctx->stream;
     if (em->sliced) {
         // the sliced E pass leaves r per position slot p (window start i = p-W+1) in d_state;

@@ -53,6 +53,8 @@ struct EmKernelArgs {
     SeqView  sv;
     uint32_t K, W, Y;            // Y = 4^(K+1)
     uint32_t logC;               // log2 of the private count-table copies per block
+    uint32_t sparse_cap;         // max non-zero windows handled by the sparse M-step (0 = always dense)
+    uint32_t sparse_wave_bytes;  // per-wave LDS scratch of the sparse M-step
     const float* s;              // device, [W][Y+1], last row entry = neutral element
     const float* q;              // device scalar
     unsigned long long* partial_n;  // [blocks][W*Y] in [j][y] order, 2^-40 fixed point
@@ -91,8 +93,10 @@ struct UpdateArgs {
 };
 
 // launchers (kernels.hip)
-size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC);
-uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu);
+size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC, size_t scratch);
+uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu, size_t scratch);
+uint32_t sparse_cap_for(int M);
+size_t sparse_wave_bytes(int M);
 int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
                   uint32_t threads, hipStream_t st);
 size_t e_slice_lds_bytes(uint32_t cols, uint32_t Y);

@@ -25,6 +25,7 @@
 
 #include "common.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace bamm {
@@ -372,17 +373,60 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             // Counts are accumulated as 64-bit fixed point (2^-40 units) with ds_add_u64: LDS
             // float atomics (ds_add_f32) run ~25x slower on gfx950 (tools/lds_bench.hip), and
             // integer sums are exact, so the result does not depend on scheduling order.
-            unsigned long long F[M], nz[M], padm[M];
-            uint32_t ya[M];                              // byte offset of (row y, private copy) inside a column
+            unsigned long long F[M];
             const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+            const uint32_t stride = (Ys << logC) * 8u;
+#pragma unroll
+            for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
+
+            // ---- sparse path: once the model is informative most windows have r < 2^-41, i.e. an
+            // addend of exactly 0.  The non-zero windows are compacted into a per-wave list and each
+            // lane then walks the W columns of ~nnz/64 windows: nnz*W/64 dense adds instead of M*W
+            // mostly-idle ones.  Identical sums (integer adds commute), chosen per sequence.
+            bool dense = true;
+            if (a.sparse_cap != 0u) {
+                uint32_t nnz = 0, lpos[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const unsigned long long mask = __ballot(F[m] != 0ull);
+                    lpos[m] = nnz + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    nnz += (uint32_t)__popcll(mask);
+                }
+                if (nnz <= a.sparse_cap) {
+                    dense = false;
+                    const uint32_t cap = a.sparse_cap;
+                    unsigned long long* listF = reinterpret_cast<unsigned long long*>(
+                        reinterpret_cast<char*>(stat_lds) + 16u * 3u * sizeof(double) + (size_t)wave * a.sparse_wave_bytes);
+                    unsigned short* listP = reinterpret_cast<unsigned short*>(listF + cap);
+                    unsigned short* ybuf = listP + cap;
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        if (F[m] != 0ull) { listF[lpos[m]] = F[m]; listP[lpos[m]] = (unsigned short)(p0 + m); }
+                        ybuf[p0 + m] = (unsigned short)y[m];
+                    }
+                    const uint32_t ecnt = (nnz + 63u) >> 6;
+                    for (uint32_t e = 0; e < ecnt; e++) {
+                        const uint32_t idx = e * 64u + (uint32_t)lane;
+                        const bool ok = idx < nnz;
+                        const unsigned long long Fe = ok ? listF[idx] : 0ull;
+                        uint32_t q = ok ? (uint32_t)listP[idx] - (W - 1u) : 0u;     // window start i
+                        unsigned long long* ncol = n_lds + copy;
+                        for (uint32_t j = 0; j < W; j++, q++, ncol += (Ys << logC)) {
+                            const uint32_t yq = ybuf[q];
+                            if (ok && yq != Y) atomicAdd(&ncol[yq << logC], Fe);
+                        }
+                    }
+                }
+            }
+            if (dense) {
+            unsigned long long nz[M], padm[M];
+            uint32_t ya[M];                              // byte offset of (row y, private copy) inside a column
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                F[m] = to_fixed40(U[m]);
                 nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
                 padm[m] = __ballot(y[m] != Y);           // positions beyond LW1 take no part (EM.cpp:236)
                 ya[m] = ((y[m] << logC) + copy) * 8u;
             }
-            const uint32_t stride = (Ys << logC) * 8u;
             uint32_t col = lds_offset(n_lds) + (W - 1u) * stride;
             // F is kept as a ring: after t shifts logical slot m lives in F[(m+t) mod M]; the
             // shift itself is one in-place DPP pair on F[t] (the value leaving becomes the value
@@ -399,6 +443,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                         col -= stride;
                     }
                 }
+            }
             }
         }
     }
@@ -807,17 +852,24 @@ void set_em_lds_attr(size_t lds) {
 
 }  // namespace
 
-size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC) {
+size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC, size_t scratch) {
     size_t floats = (size_t)((W + 3) / 4) * 4 * (Y + 1) + (accum ? (2 * (size_t)W * (Y + 1)) << logC : 0);
-    return floats * sizeof(float) + 16 * 3 * sizeof(double);
+    return floats * sizeof(float) + 16 * 3 * sizeof(double) + (accum ? scratch : 0);
+}
+
+// per-wave LDS scratch of the sparse M-step: [cap x u64 addend][cap x u16 slot][64*M x u16 y]
+uint32_t sparse_cap_for(int M) { return M <= 16 ? (uint32_t)std::min(192, 64 * M) : 0u; }
+size_t sparse_wave_bytes(int M) {
+    const size_t cap = sparse_cap_for(M);
+    return cap ? ((cap * 8 + cap * 2 + (size_t)64 * M * 2 + 7) & ~size_t(7)) : 0;
 }
 
 // largest number of private count-table copies (power of two <= 16) that still lets
 // `blocks_per_cu` blocks share the 160 KiB of a CU
-uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu) {
+uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu, size_t scratch) {
     const size_t budget = (160 * 1024) / (blocks_per_cu ? blocks_per_cu : 1);
     uint32_t logC = 0;
-    while (logC < 4 && em_lds_bytes(W, Y, true, logC + 1) <= budget) logC++;
+    while (logC < 4 && em_lds_bytes(W, Y, true, logC + 1, scratch) <= budget) logC++;
     return logC;
 }
 
@@ -828,7 +880,7 @@ uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu) {
 
 int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
                   uint32_t threads, hipStream_t st) {
-    const size_t lds = em_lds_bytes(a.W, a.Y, accum, a.logC);
+    const size_t lds = em_lds_bytes(a.W, a.Y, accum, a.logC, (size_t)a.sparse_wave_bytes * (threads / 64u));
     if (lds > 160 * 1024) {
         set_error("odds/count tables need %zu bytes of LDS (> 160 KiB): K=%u W=%u is outside the fused kernel's envelope",
                   lds, a.K, a.W);
