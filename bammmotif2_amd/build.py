@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libbamm_em.so")
 SOURCES = ["kernels.hip", "abi.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "bamm_em.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-result"]
+         "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
 
 
 def is_stale() -> bool:

@@ -257,6 +257,7 @@ EXTRA_SHAPES = [
     dict(name="x_all_lengths", N=130, L0=330, W=10, K=2, ss=True, ragged=300),                 # many M buckets in one set
     dict(name="x_M12_14_16", N=40, L0=820, W=21, K=2, ss=True, ragged=110, n_frac=0.003),      # 512-thread classes
     dict(name="x_M20_28_ds", N=24, L0=760, W=20, K=2, ragged=130),                             # ds: L 1261..1781
+    dict(name="x_M40_64", N=12, L0=3300, W=18, K=2, ss=True, ragged=790, n_frac=0.001),        # L 2510..4090
 ]
 
 
@@ -271,7 +272,8 @@ def test_shapes_and_length_buckets(spec, gpu_ctx, orc):
     s_o = orc.linear_s(c.v0, vbg, c.K, c.W, Kb)
     r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, c.q)
     np.testing.assert_allclose(em.getR(), r_o, rtol=2e-5, atol=R_ATOL)
-    np.testing.assert_allclose(em.getLLH(), llh_o, rtol=LLH_RTOL, atol=5e-7 * c.N)
+    # the oracle sums Z sequentially in fp32: ~sqrt(L)*6e-8 relative noise per sequence
+    np.testing.assert_allclose(em.getLLH(), llh_o, rtol=LLH_RTOL, atol=1e-8 * float(off[-1]))
     em.MStep()
     n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
     np.testing.assert_allclose(em.getCounts(), n_o, rtol=2e-5, atol=1e-6)
@@ -290,7 +292,7 @@ def test_shapes_and_length_buckets(spec, gpu_ctx, orc):
 
 
 def test_sequence_longer_than_envelope_is_refused(gpu_ctx, orc):
-    c = Case("toolong", N=2, L0=2100, W=8, K=1, ss=True)
+    c = Case("toolong", N=2, L0=4100, W=8, K=1, ss=True)
     _, kmer, off, _ = c.encode(orc)
     with pytest.raises(bm.abi.BammError) as e:
         bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
