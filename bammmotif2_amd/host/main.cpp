@@ -333,13 +333,14 @@ int main(int nargs, char* args[]) {
     const size_t negN = neg_off.size() - 1;
     // scorer over a resident set: MOPS scores (concatenated), ZOOPS maxima
     auto score_set = [&](bamm_seqs* set, const std::vector<uint32_t>& lens, const Motif& m, std::vector<float>& mops,
-                         std::vector<float>& zoops, const uint8_t* subset = nullptr) {
+                         std::vector<float>& zoops, const uint8_t* subset = nullptr, bool want_mops = true) {
         size_t total = 0;
-        for (uint32_t L : lens) total += L - m.W + 1;
+        if (want_mops) for (uint32_t L : lens) total += L - m.W + 1;
         mops.assign(total ? total : 1, 0.f);
         zoops.assign(lens.size() ? lens.size() : 1, 0.f);
         std::vector<uint64_t> z(lens.size() ? lens.size() : 1);
-        if (bamm_logodds_subset(ctx, set, subset, m.K, m.W, bg.K, m.v.data(), bg.v.data(), mops.data(), total, zoops.data(), z.data())) die_abi("calcLogOdds");
+        if (bamm_logodds_subset(ctx, set, subset, m.K, m.W, bg.K, m.v.data(), bg.v.data(), want_mops ? mops.data() : nullptr, total,
+                                zoops.data(), z.data())) die_abi("calcLogOdds");
         mops.resize(total);
         zoops.resize(lens.size());
     };
@@ -474,7 +475,7 @@ int main(int nargs, char* args[]) {
                     std::cout << "\n--- Runtime for EM: " << std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() << " seconds ---\n";
                 }
                 std::vector<float> mops, zoops;
-                score_set(dseqs, kept_len, m, mops, zoops, test.data());
+                score_set(dseqs, kept_len, m, mops, zoops, test.data(), o.mops);
                 size_t o_m = 0;
                 for (size_t i = 0; i < P; i++) {
                     const size_t nw = kept_len[i] - m.W + 1;
@@ -486,7 +487,7 @@ int main(int nargs, char* args[]) {
                 }
                 std::vector<uint8_t> neg_sel(negN ? negN : 1, 0);
                 for (size_t i = 0; i + cv <= negN; i += cv) neg_sel[i] = 1;
-                score_set(dneg, neg_len, m, mops, zoops, neg_sel.data());
+                score_set(dneg, neg_len, m, mops, zoops, neg_sel.data(), o.mops);
                 o_m = 0;
                 for (size_t i = 0; i < negN; i++) {
                     const size_t nw = neg_len[i] - m.W + 1;
