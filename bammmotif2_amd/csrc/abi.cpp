@@ -95,6 +95,7 @@ struct bamm_em {
     uint32_t* d_iteration = nullptr;
     uint8_t* d_mask = nullptr;
     double* d_red = nullptr;
+    bool red_external = false;                 // caller-owned reduce buffer (bamm_em_set_reduce_buffer)
     unsigned long long* d_partial_n = nullptr;
     double* d_partial_stat = nullptr;
     float* h_status = nullptr;                  // pinned, 8 floats
@@ -440,7 +441,7 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipSetDevice(em->ctx->device);
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_q,
-                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_red,
+                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->red_external ? nullptr : em->d_red),
                     (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt, (void*)em->d_q_alt})
         (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
@@ -623,6 +624,21 @@ int bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_doubles) {
     if (!em || !dev_ptr || !n_doubles) { set_error("bad argument"); return BAMM_ERR_ARG; }
     *dev_ptr = em->d_red;
     *n_doubles = em->cells + 3;
+    return BAMM_OK;
+}
+
+int bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_doubles) {
+    if (!em || !dev_ptr) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    if (n_doubles < em->cells + 3) {
+        set_error("reduce buffer holds %llu doubles, %llu needed", (unsigned long long)n_doubles, (unsigned long long)(em->cells + 3));
+        return BAMM_ERR_ARG;
+    }
+    BAMM_HIP(hipSetDevice(em->ctx->device));
+    BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
+    if (!em->red_external) (void)hipFree(em->d_red);
+    em->d_red = static_cast<double*>(dev_ptr);
+    em->red_external = true;
+    BAMM_HIP(hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), em->ctx->stream));
     return BAMM_OK;
 }
 

@@ -247,6 +247,10 @@ class EM:
         check(self.lib.bamm_em_reduce_buffer(self.h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
 
+    def set_reduce_buffer(self, dev_ptr: int, n_doubles: int):
+        """Use caller-owned device memory (e.g. a torch float64 tensor) as the fused reduce buffer."""
+        check(self.lib.bamm_em_set_reduce_buffer(self.h, C.c_void_p(dev_ptr), n_doubles))
+
     def set_allreduce(self, fn: Optional[Callable[[int, int, int], int]]):
         """fn(dev_ptr, n_doubles, hip_stream) -> 0 on success; called between the local
         accumulation and the model update of every pass."""

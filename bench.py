@@ -52,13 +52,6 @@ def parse():
     return ap.parse_args()
 
 
-class _DevBuf:
-    """Expose a raw device pointer to torch (for dist.all_reduce) without copying."""
-
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline(codes, in_off, W, K, v0, alpha, q, sample, iters, ss):
     """The reference's EM::EStep/MStep (compiled in place into oracle/_ref) on the host cores."""
     import oracle
@@ -150,9 +143,12 @@ def main():
 
     keep = []
     if use_dist:
-        ptr, n = em.reduce_buffer()
-        red = torch.as_tensor(_DevBuf(ptr, n), device=torch.device("cuda", local_rank))
-        assert red.data_ptr() == ptr and red.dtype == torch.float64 and red.numel() == n
+        _, n = em.reduce_buffer()
+        # the fused [n_K | llh | sum_r | N] buffer lives in a torch tensor, so RCCL sees ordinary
+        # torch memory of this rank's device
+        red = torch.zeros(n, dtype=torch.float64, device=torch.device("cuda", local_rank))
+        torch.cuda.synchronize()
+        em.set_reduce_buffer(red.data_ptr(), n)
         keep.append(red)
 
         def allreduce(_ptr, _n, _stream):

@@ -152,6 +152,9 @@ int  bamm_em_optimize(bamm_em* em, uint32_t* iterations);
 int  bamm_em_accumulate(bamm_em* em);
 int  bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_doubles);
 int  bamm_em_update(bamm_em* em);
+/* let the fused buffer live in memory the caller allocated (e.g. a torch tensor that is handed
+ * to torch.distributed.all_reduce): n_doubles >= 4^(K+1)*W + 3; the caller keeps ownership.   */
+int  bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_doubles);
 /* ... or install a callback that bamm_em_iterate/optimize/mstep invoke at that point.        */
 typedef int (*bamm_allreduce_fn)(void* user, void* dev_ptr, uint64_t n_doubles, void* hip_stream);
 int  bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user);

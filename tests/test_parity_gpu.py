@@ -315,3 +315,26 @@ def test_logodds_subset(gpu_ctx, orc):
         a, b = sub[0][moff[n]:moff[n + 1]], full[0][moff[n]:moff[n + 1]]
         assert np.array_equal(a, b) if sel[n] else np.all(a == 0)
     ss.close()
+
+
+def test_external_reduce_buffer(gpu_ctx, orc):
+    """The fused buffer can live in caller-owned device memory (what bench.py does with a torch
+    tensor for RCCL)."""
+    import torch
+    c = Case(**SMALL_CASES[0])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    _, n = em.reduce_buffer()
+    red = torch.zeros(n + 5, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    em.set_reduce_buffer(red.data_ptr(), n + 5)
+    em.iterate(2)
+    gpu_ctx.sync()
+    res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, epsilon=0.0, max_iter=2)
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
+    host = red.cpu().numpy()
+    cells = 4 ** (c.K + 1) * c.W
+    np.testing.assert_allclose(host[cells], res["llh"], rtol=1e-5)          # llh of the last pass
+    assert host[cells + 2] == c.N and np.all(host[n:] == 0)
+    with pytest.raises(bm.abi.BammError):
+        em.set_reduce_buffer(red.data_ptr(), 3)
+    em.close(); ss.close()
