@@ -120,3 +120,24 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(root, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "bamm_oracle" not in txt, f
+
+
+def test_argument_errors_do_not_crash(lib):
+    """Bad arguments come back as BAMM_ERR_ARG with a message; nothing exits or segfaults."""
+    import ctypes as C
+    out = C.POINTER(abi.Packed)()
+    assert lib.bamm_pack_kmers(np.zeros(1, np.uint64), np.zeros(2, np.uint64), 1, None) == abi.ERR_ARG
+    assert b"null" in lib.bamm_last_error()
+    b, e = C.c_uint64(), C.c_uint64()
+    assert lib.bamm_shard_range(np.zeros(1, np.uint32), 1, 4, 3, 2, C.byref(b), C.byref(e)) == abi.ERR_ARG
+    p = np.zeros(4, np.float32)
+    assert lib.bamm_calculate_p(p, p, 0, 99, 1, p) == abi.ERR_ARG
+    for name in ("bamm_em_estep", "bamm_em_mstep", "bamm_em_optimize_q", "bamm_em_accumulate", "bamm_em_update"):
+        assert getattr(lib, name)(None) == abi.ERR_ARG, name
+    assert lib.bamm_em_iterate(None, 1) == abi.ERR_ARG
+    assert lib.bamm_em_destroy(None) == abi.OK and lib.bamm_seqs_destroy(None) == abi.OK and lib.bamm_ctx_destroy(None) == abi.OK
+    assert lib.bamm_seqs_upload(None, None, 0, 0, None) == abi.ERR_ARG
+    prm = abi.EmParams()
+    lib.bamm_em_default_params(C.byref(prm))
+    assert (prm.K, prm.bg_order, prm.max_iterations) == (2, 2, 1000) and abs(prm.q - 0.3) < 1e-7 and abs(prm.epsilon - 0.01) < 1e-9
+    assert lib.bamm_v_size(2, 20) == 1680 and lib.bamm_v_offset(2, 20) == 400 and lib.bamm_bg_size(2) == 84
