@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the RCCL all-reduce path even with one rank (self-test)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo stages the fused buffer through the host: lets 2 ranks share ONE GPU (self-test of "
+                         "the N>1 logic on a 1-GPU box; never used for reported numbers)")
     return ap.parse_args()
 
 
@@ -114,12 +117,17 @@ def main():
     from bammmotif2_amd import synth, build
 
     build.build_library()
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     W, K, L0 = args.width, args.order, args.L0
     pwm = synth.make_pwm(W, 1234)
@@ -153,7 +161,12 @@ def main():
 
         def allreduce(_ptr, _n, _stream):
             with torch.cuda.stream(tstream):   # RCCL waits for the count kernels, the update waits for RCCL
-                dist.all_reduce(red)
+                if args.dist_backend == "nccl":
+                    dist.all_reduce(red)
+                else:                          # self-test path: through the host
+                    host = red.cpu()
+                    dist.all_reduce(host)
+                    red.copy_(host)
             return 0
 
         em.set_allreduce(allreduce)
@@ -170,7 +183,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
