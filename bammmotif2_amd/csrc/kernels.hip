@@ -12,16 +12,20 @@
 //                   Motif::calculateLinearS init/Motif.cpp:485-494
 //   k_score         ScoreSeqSet::calcLogOdds seq_scoring/ScoreSeqSet.cpp:41-66
 //
-// Design: one 64-lane wavefront owns one sequence at a time.  Lane l holds M
-// consecutive positions p = l*M+m in registers.  The odds table s[j][y] (plus a neutral pad
-// row) lives in LDS; window products are built as a systolic chain
+//   k_e_slice / k_m_slice  the same two chains cut into column ranges for tables beyond one
+//                   CU's LDS (k >= 4), chain state and r in HBM
+//
+// Design: one 64-lane wavefront owns one sequence at a time.  Lane l
+// holds M consecutive positions p = l*M+m in registers.  The odds table lives in LDS as
+// [W/4][Y+1][4] (row Y and padding columns = 1.0f); window products are a systolic chain
 //       U_j(p) = U_{j-1}(p-1) * s[j][y(p)]
-// whose only cross-lane traffic is ONE `wave_shr:1` DPP move per motif column (the value
-// leaving lane l-1's last slot).  The M-step is the adjoint chain: the normalised
-// responsibilities are shifted one slot towards lower p per column (`wave_shl:1`) and added
-// into the block's count table n[j][y] in LDS with ds_add_f32.  Nothing but the 2-bit sequence
-// stream (+ the N exceptions) is read from HBM; per block one partial table is written.
-// No MFMA: this is gather/scatter, not a contraction.
+// whose only cross-lane traffic is ONE `wave_shr:1` DPP move per motif column; a position's
+// four columns arrive with one hand-issued ds_read_b128.  The M-step is the adjoint chain on
+// 64-bit fixed-point addends (ds_add_u64 into n[j][y][copy]; ds_add_f32 is ~25x slower on
+// gfx950): dense form = register ring shifted with `wave_shl:1`, predicated by precomputed
+// wave masks; sparse form = the non-zero windows compacted into a per-wave LDS list.  Nothing
+// but the 2-bit sequence stream (+ the N exceptions) is read from HBM; per block one partial
+// table is written.  No MFMA: this is gather/scatter, not a contraction.
 
 #include "common.h"
 
@@ -46,17 +50,11 @@ uint32_t max_threads_for_mclass(int mclass) {
 namespace {
 
 // ---- cross-lane helpers ------------------------------------------------------------------
-// DPP wave shifts exist on the GFX9 family (incl. gfx950).  `oldv` is what lane 0 (shr) /
-// lane 63 (shl) keeps.
+// DPP wave shifts exist on the GFX9 family (incl. gfx950).  `oldv` is what lane 0 keeps.
 __device__ __forceinline__ float wave_shr1(float oldv, float x) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
                                            0x138, 0xf, 0xf, false));
-}
-[[maybe_unused]] __device__ __forceinline__ float wave_shl1(float oldv, float x) {
-    return __builtin_bit_cast(
-        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
-                                           0x130, 0xf, 0xf, false));
 }
 __device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x) {   // lane 63 receives 0
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x & 0xffffffffull), 0x130, 0xf, 0xf, false);
