@@ -8,7 +8,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 import bammmotif2_amd as bm  # noqa: E402
 import oracle  # noqa: E402
 from bammmotif2_amd import synth  # noqa: E402
