@@ -54,7 +54,7 @@ def build_host(force: bool = False, verbose: bool = False):
             min(os.path.getmtime(o) for o in outs) >= max(os.path.getmtime(d) for d in deps):
         return outs
     cxx = shutil.which("g++") or "g++"
-    common = [cxx, "-std=c++17", "-O2", "-Wall", "-fPIC", "-L" + HERE, "-Wl,-rpath,$ORIGIN"]
+    common = [cxx, "-std=c++17", "-O2", "-fopenmp", "-Wall", "-fPIC", "-L" + HERE, "-Wl,-rpath,$ORIGIN"]
     cmd = common + ["-shared"] + [os.path.join(HOST, f) for f in HOST_SOURCES] + ["-lbamm_em", "-o", HOST_LIB]
     if verbose:
         print(" ".join(cmd))

@@ -221,29 +221,43 @@ void motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel&
     for (size_t y = 0; y < 4; y++)
         for (uint32_t j = 0; j < W; j++) score[y * W + j] = m.v[y * W + j] / bg.v[y];
     std::mt19937 rngx;                                        // default-seeded on purpose (Motif.cpp:237)
-    std::vector<float> r;
-    for (size_t s = 0; s < n_seqs; s++) {                     // serial: the reference's omp loop shares one RNG
-        const size_t L = off[s + 1] - off[s];
-        if (L < W) continue;                                  // Motif.cpp:240-248
-        const size_t LW1 = L - W + 1;
-        const uint32_t* km = yK + off[s];
-        r.assign(LW1 + 1, 0.f);
-        float normFactor = 0.0f;
-        const float pos0 = 1.0f - q, pos1 = q / (float)LW1;
-        for (size_t i = 1; i <= LW1; i++) {
-            r[i] = 1.0f;
-            for (uint32_t j = 0; j < W; j++) r[i] *= score[(km[i - 1 + j] % 4) * W + j];
-            r[i] *= pos1;
-            normFactor += r[i];
+    // The posteriors of different sequences are independent, the draws are not (one RNG stream, in
+    // sequence order): posteriors are computed for a block of sequences in parallel, then sampled
+    // serially -- same results as the reference's loop run with one thread.
+    const size_t kBlock = 2048;
+    std::vector<std::vector<float>> post(kBlock);
+    for (size_t s0 = 0; s0 < n_seqs; s0 += kBlock) {
+        const size_t s1 = std::min(n_seqs, s0 + kBlock);
+#pragma omp parallel for schedule(dynamic, 16)
+        for (size_t s = s0; s < s1; s++) {
+            std::vector<float>& r = post[s - s0];
+            const size_t L = off[s + 1] - off[s];
+            if (L < W) { r.clear(); continue; }                   // Motif.cpp:240-248
+            const size_t LW1 = L - W + 1;
+            const uint32_t* km = yK + off[s];
+            r.assign(LW1 + 1, 0.f);
+            float normFactor = 0.0f;
+            const float pos0 = 1.0f - q, pos1 = q / (float)LW1;
+            for (size_t i = 1; i <= LW1; i++) {
+                r[i] = 1.0f;
+                for (uint32_t j = 0; j < W; j++) r[i] *= score[(km[i - 1 + j] % 4) * W + j];
+                r[i] *= pos1;
+                normFactor += r[i];
+            }
+            r[0] = pos0;
+            normFactor += r[0];
+            for (size_t i = 0; i <= LW1; i++) r[i] /= normFactor;
         }
-        r[0] = pos0;
-        normFactor += r[0];
-        for (size_t i = 0; i <= LW1; i++) r[i] /= normFactor;
-        std::discrete_distribution<size_t> dist(r.begin(), r.end());
-        const size_t z = dist(rngx);
-        if (z > 0)
-            for (uint32_t k = 0; k <= K; k++)
-                for (uint32_t j = 0; j < W; j++) n[voff(k, W) + (km[z - 1 + j] % ipow4(k + 1)) * W + j]++;
+        for (size_t s = s0; s < s1; s++) {
+            const std::vector<float>& r = post[s - s0];
+            if (r.empty()) continue;
+            const uint32_t* km = yK + off[s];
+            std::discrete_distribution<size_t> dist(r.begin(), r.end());
+            const size_t z = dist(rngx);
+            if (z > 0)
+                for (uint32_t k = 0; k <= K; k++)
+                    for (uint32_t j = 0; j < W; j++) n[voff(k, W) + (km[z - 1 + j] % ipow4(k + 1)) * W + j]++;
+        }
     }
     orders_from_counts(m, n, false, 0, bg);
     motif_calculate_p(m, bg);
