@@ -47,7 +47,7 @@ SYMBOLS = [
     "bamm_ctx_sync", "bamm_ctx_device_name", "bamm_ctx_set_launch", "bamm_seqs_upload",
     "bamm_seqs_destroy", "bamm_seqs_info", "bamm_em_default_params", "bamm_em_create",
     "bamm_em_destroy", "bamm_em_estep", "bamm_em_mstep", "bamm_em_optimize_q", "bamm_em_iterate",
-    "bamm_em_optimize", "bamm_em_accumulate", "bamm_em_reduce_buffer", "bamm_em_update", "bamm_em_set_reduce_buffer",
+    "bamm_em_optimize", "bamm_em_mask", "bamm_em_accumulate", "bamm_em_reduce_buffer", "bamm_em_update", "bamm_em_set_reduce_buffer",
     "bamm_em_set_allreduce", "bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s", "bamm_em_get_q",
     "bamm_em_get_llh", "bamm_em_get_vdiff", "bamm_em_get_iteration", "bamm_em_get_r",
     "bamm_em_get_trace", "bamm_em_kernel_time", "bamm_logodds", "bamm_logodds_subset", "bamm_bg_model", "bamm_calculate_p", "bamm_v_size",
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
         getattr(L, name).argtypes = [vp]
     L.bamm_em_iterate.argtypes = [vp, u32]
     L.bamm_em_optimize.argtypes = [vp, P(u32)]
+    L.bamm_em_mask.argtypes = [vp, C.c_float, P(u32), P(C.c_float), P(u64)]
     L.bamm_em_reduce_buffer.argtypes = [vp, P(vp), P(u64)]
     L.bamm_em_set_reduce_buffer.argtypes = [vp, vp, u64]
     L.bamm_em_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]

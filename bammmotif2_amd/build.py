@@ -11,7 +11,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbamm_em.so")
-SOURCES = ["kernels.hip", "abi.cpp", "pack.cpp"]
+SOURCES = ["kernels.hip", "mask.hip", "abi.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "bamm_em.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]

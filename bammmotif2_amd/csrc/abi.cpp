@@ -116,6 +116,17 @@ struct bamm_em {
     void* allreduce_user = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     uint32_t events_used = 0;
+    // EM::mask state (allocated on first use)
+    uint64_t n_active = 0;                      // sequences the handle trains on (mask applied)
+    float* d_mask_r = nullptr;                  // responsibilities in the reference layout
+    uint32_t* d_mask_bits = nullptr;
+    double* d_mask_hist = nullptr;
+    MaskSelect* d_mask_sel = nullptr;
+    float* d_mask_qseq = nullptr;
+    unsigned long long* d_mask_partial_n = nullptr;
+    double* d_mask_partial_stat = nullptr;
+    uint32_t mask_blocks = 0;
+    bool mask_done = false;                     // getR() serves d_mask_r
 };
 
 namespace {
@@ -237,7 +248,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
     }
     rc = record_event(em, false);
     if (rc) return rc;
-    if (!replay_last) { em->s_last = em->d_s; em->q_last = em->d_q; }
+    if (!replay_last) { em->s_last = em->d_s; em->q_last = em->d_q; em->mask_done = false; }
     if (em->total_blocks == 0) {
         BAMM_HIP(hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), st));
         return BAMM_OK;
@@ -442,7 +453,9 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_q,
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->red_external ? nullptr : em->d_red),
-                    (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt, (void*)em->d_q_alt})
+                    (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt, (void*)em->d_q_alt,
+                    (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
+                    (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})
         (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
     for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -523,6 +536,8 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     }
     if (seq_mask && seqs->n)
         if ((rc = dev_upload(&em->d_mask, seq_mask, seqs->n, st))) return fail(rc);
+    em->n_active = seqs->n;
+    if (seq_mask) em->n_active = (uint64_t)std::count_if(seq_mask, seq_mask + seqs->n, [](uint8_t m) { return m != 0; });
     if (hipHostMalloc((void**)&em->h_status, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         return fail(BAMM_ERR_HIP);
@@ -683,6 +698,139 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
     return BAMM_OK;
 }
 
+int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint64_t* listed) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    bamm_seqs* s = em->seqs;
+    if (!(f > 0.0f && f < 1.0f)) { set_error("bamm_em_mask: fraction %g outside (0,1)", (double)f); return BAMM_ERR_ARG; }
+    if (em->n_active == 0) { set_error("bamm_em_mask: no sequences (the reference indexes an empty array, EM.cpp:343)"); return BAMM_ERR_ARG; }
+    if (em->prm.W < 2) { set_error("bamm_em_mask: W=1 reads past pos_[n] in the reference (EM.cpp:416)"); return BAMM_ERR_UNSUPPORTED; }
+    if (em->prm.optimize_q && em->allreduce) {
+        set_error("bamm_em_mask: optimize_q re-estimates q after every sequence (EM.cpp:321), a serial chain that cannot be sharded");
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    if (em->host_iteration != 0 || em->estep_done) {
+        set_error("bamm_em_mask: the handle has already run E/M passes; the reference calls mask() on a fresh EM only");
+        return BAMM_ERR_STATE;
+    }
+    const size_t kLds = 160 * 1024;
+    const uint32_t W = em->prm.W, Y = em->Y;
+    const size_t wave_bytes = mask_wave_bytes(s->max_len);
+    auto round16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t s_bytes = round16((size_t)W * (Y + 1) * sizeof(float));
+    const bool s_in_lds = s_bytes <= 64 * 1024 && s_bytes + wave_bytes <= kLds;
+    const size_t e_table = s_in_lds ? s_bytes : 0;
+    // M-step: as many columns per launch as fit next to one wave's arrays
+    if (wave_bytes + round16((size_t)Y * 8) > kLds || s->max_len > 65535u) {
+        set_error("bamm_em_mask: sequences of %u positions / order %u exceed the LDS plan of the masked kernels", s->max_len, em->prm.K);
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    uint32_t m_cols = std::min<size_t>(W, (std::min(kLds / 2, kLds - wave_bytes)) / ((size_t)Y * 8));
+    m_cols = std::max(1u, m_cols);
+    const size_t m_table = round16((size_t)m_cols * Y * 8);
+    auto waves_for = [&](size_t table) { return (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (kLds - table) / wave_bytes)); };
+    const uint32_t init_table = (uint32_t)round16((size_t)W * 4 * sizeof(float));
+    int rc = use_device(em->ctx);
+    if (rc) return rc;
+    hipStream_t st = em->ctx->stream;
+    const uint32_t e_waves = waves_for(e_table), m_waves = waves_for(m_table);
+    // 16 waves per CU (as the fused kernel), but no more partial tables than 64 MiB worth
+    const uint32_t cus = (uint32_t)std::max(1, em->ctx->num_cus);
+    const uint32_t per_cu = std::max(1u, 16u / std::min(e_waves, m_waves));
+    const uint32_t cap_blocks = (uint32_t)std::max<size_t>(cus, std::min<size_t>((size_t)cus * per_cu, ((size_t)64 << 20) / (em->cells * 8)));
+    const uint32_t mblocks = std::max(1u, std::min(((uint32_t)s->n + std::min(e_waves, m_waves) - 1) / std::min(e_waves, m_waves), cap_blocks));
+    if (!em->d_mask_r) {
+        em->mask_blocks = mblocks;
+        if ((rc = dev_alloc(&em->d_mask_partial_n, (size_t)mblocks * em->cells)) ||
+            (rc = dev_alloc(&em->d_mask_partial_stat, (size_t)mblocks * 4)) ||
+            (rc = dev_alloc(&em->d_mask_r, (size_t)s->total_len)) ||
+            (rc = dev_alloc(&em->d_mask_bits, (size_t)s->total_len / 32 + 2)) ||
+            (rc = dev_alloc(&em->d_mask_hist, 2049)) || (rc = dev_alloc(&em->d_mask_sel, 1)) ||
+            (em->prm.optimize_q && (rc = dev_alloc(&em->d_mask_qseq, (size_t)s->n))))
+            return rc;
+    }
+    BAMM_HIP(hipMemsetAsync(em->d_mask_r, 0, (size_t)s->total_len * sizeof(float), st));
+    BAMM_HIP(hipMemsetAsync(em->d_mask_bits, 0, ((size_t)s->total_len / 32 + 2) * sizeof(uint32_t), st));
+    BAMM_HIP(hipMemsetAsync(em->d_mask_hist, 0, 2049 * sizeof(double), st));
+    BAMM_HIP(hipMemsetAsync(em->d_mask_sel, 0, sizeof(MaskSelect), st));
+
+    Bucket all;                                              // every sequence in natural order
+    all.count = (uint32_t)s->n;
+    MaskKernelArgs a{};
+    a.sv = make_view(s, em->exc, all, em->d_mask);
+    a.K = em->prm.K; a.W = W; a.Y = Y;
+    a.max_len = s->max_len;
+    a.wave_bytes = (uint32_t)wave_bytes;
+    a.v0 = em->d_v; a.vbg0 = em->d_vbg;
+    a.q = em->d_q;
+    a.q_seq = em->prm.optimize_q ? em->d_mask_qseq : nullptr;
+    a.n_total = (float)em->n_active;
+    a.r = em->d_mask_r; a.bits = em->d_mask_bits; a.hist = em->d_mask_hist; a.sel = em->d_mask_sel;
+    a.partial_n = em->d_mask_partial_n; a.partial_stat = em->d_mask_partial_stat;
+
+    auto blocks_for = [&](uint32_t waves, uint32_t cap) {
+        const uint32_t need = ((uint32_t)s->n + waves - 1) / waves;
+        return std::max(1u, std::min(need, cap));
+    };
+    // order-0 pass (EM.cpp:266-323)
+    {
+        a.table_bytes = init_table;
+        const uint32_t waves = waves_for(init_table);
+        if ((rc = launch_mask_init(a, em->prm.optimize_q != 0, blocks_for(waves, cus * 8), waves * 64, st))) return rc;
+    }
+    // cut-off (EM.cpp:329-343)
+    for (int pass = 0; pass < 3; pass++) {
+        if ((rc = launch_mask_hist(a, pass, blocks_for(4, cus * 8), st))) return rc;
+        if (em->allreduce && em->allreduce(em->allreduce_user, em->d_mask_hist, 2049, (void*)st) != 0) {
+            set_error("all-reduce callback failed in bamm_em_mask");
+            return BAMM_ERR_COMM;
+        }
+        if ((rc = launch_mask_pick(a, pass, f, st))) return rc;
+    }
+    if ((rc = launch_mask_bits(a, blocks_for(4, cus * 8), st))) return rc;     // EM.cpp:345-356
+
+    // EM over the listed windows (EM.cpp:373-494)
+    const int32_t oq = em->prm.optimize_q;
+    em->prm.optimize_q = 0;                                  // q is not touched inside this loop
+    em->events_used = 0;
+    bool iterate = true;
+    uint32_t iteration = 0;
+    float llh = em->llh_prev;
+    while (iterate && iteration < em->prm.max_iterations && !rc) {
+        iteration++;
+        const float llh_prev = llh;
+        a.s = em->d_s;
+        a.q = em->d_q;
+        if ((rc = record_event(em, true))) break;
+        a.table_bytes = (uint32_t)e_table;
+        rc = launch_mask_e(a, s_in_lds, mblocks, e_waves * 64, st);
+        a.table_bytes = (uint32_t)m_table;
+        for (uint32_t j0 = 0; j0 < W && !rc; j0 += m_cols) {
+            a.j0 = j0; a.j1 = std::min(W, j0 + m_cols);
+            rc = launch_mask_m(a, mblocks, m_waves * 64, st);
+        }
+        if (!rc) rc = record_event(em, false);
+        if (!rc) rc = launch_reduce_partials(em->d_mask_partial_n, em->d_mask_partial_stat, mblocks, W, Y, em->d_red, st);
+        if (!rc) rc = run_allreduce(em);
+        if (!rc) rc = run_update(em);
+        if (!rc) rc = fetch_status(em);
+        if (rc) break;
+        llh = em->h_status[0];
+        if (em->h_status[1] < em->prm.epsilon) iterate = false;            // EM.cpp:488
+        if (llh - llh_prev < 0 && iteration > 10) iterate = false;         // EM.cpp:489
+    }
+    em->prm.optimize_q = oq;
+    if (rc) return rc;
+    em->llh_prev = llh;
+    em->mask_done = true;
+    MaskSelect sel;
+    BAMM_HIP(hipMemcpyAsync(&sel, em->d_mask_sel, sizeof(sel), hipMemcpyDeviceToHost, st));
+    BAMM_HIP(hipStreamSynchronize(st));
+    if (iterations) *iterations = iteration;
+    if (cutoff) *cutoff = sel.cutoff;
+    if (listed) *listed = sel.listed;
+    return BAMM_OK;
+}
+
 static int copy_out(bamm_em* em, float* dst, const float* src, size_t count) {
     if (!em || !dst) { set_error("bad argument"); return BAMM_ERR_ARG; }
     BAMM_HIP(hipSetDevice(em->ctx->device));
@@ -737,6 +885,11 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
     if (total == 0) return BAMM_OK;
     BAMM_HIP(hipSetDevice(em->ctx->device));
     hipStream_t st = em->ctx->stream;
+    if (em->mask_done) {                                    // EM::mask keeps r_ materialised (EM.cpp:409-430)
+        BAMM_HIP(hipMemcpyAsync(out, em->d_mask_r + base, total * sizeof(float), hipMemcpyDeviceToHost, st));
+        BAMM_HIP(hipStreamSynchronize(st));
+        return BAMM_OK;
+    }
     if (em->sliced) {
         // the sliced E pass leaves r per position slot p (window start i = p-W+1) in d_state;
         // the reference's index is L-W-i = L-1-p (EM.cpp:173)

@@ -92,6 +92,44 @@ struct UpdateArgs {
     double n_seqs_override;      // >0: use instead of red[..+2]
 };
 
+struct MaskSelect {              // device state of the radix select (EM.cpp:329-343)
+    double   pos_count;          // number of windows (all ranks)
+    double   rank;               // remaining 0-based rank in the descending order
+    unsigned long long listed;   // windows at or above the cut-off (this rank)
+    uint32_t prefix;             // bit-pattern prefix chosen so far
+    float    cutoff;
+};
+
+struct MaskKernelArgs {          // EM::mask kernels (mask.hip)
+    SeqView  sv;                 // every resident sequence, exceptions of order K
+    uint32_t K, W, Y;
+    uint32_t max_len;            // sizes the per-wave LDS arrays
+    uint32_t wave_bytes;         // mask_wave_bytes(max_len)
+    uint32_t table_bytes;        // block-shared table in front of the per-wave arrays
+    const float* v0;             // order-0 conditionals [4][W]
+    const float* vbg0;           // order-0 background [4]
+    const float* s;              // [W][Y+1] linear odds of the current model
+    float*   q;                  // device scalar
+    float*   q_seq;              // nullable: q each sequence saw in the order-0 pass (optimizeQ)
+    float    n_total;            // number of training sequences (optimize_q's N)
+    float*   r;                  // responsibilities, reference layout (pos_off[n] + r-index)
+    uint32_t* bits;              // 1 bit per r slot: window belongs to the top-f set
+    double*  hist;               // [2049]
+    MaskSelect* sel;
+    unsigned long long* partial_n;
+    double*  partial_stat;
+    uint32_t j0, j1;             // column range of k_mask_m
+};
+
+// launchers (mask.hip)
+size_t mask_wave_bytes(uint32_t max_len);
+int launch_mask_init(const MaskKernelArgs& a, bool serial, uint32_t blocks, uint32_t threads, hipStream_t st);
+int launch_mask_hist(const MaskKernelArgs& a, int pass, uint32_t blocks, hipStream_t st);
+int launch_mask_pick(const MaskKernelArgs& a, int pass, float f, hipStream_t st);
+int launch_mask_bits(const MaskKernelArgs& a, uint32_t blocks, hipStream_t st);
+int launch_mask_e(const MaskKernelArgs& a, bool s_in_lds, uint32_t blocks, uint32_t threads, hipStream_t st);
+int launch_mask_m(const MaskKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st);
+
 // launchers (kernels.hip)
 size_t em_lds_bytes(uint32_t W, uint32_t Y, bool accum, uint32_t logC, size_t scratch);
 uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu, size_t scratch);

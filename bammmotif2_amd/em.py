@@ -220,6 +220,13 @@ class EM:
         check(self.lib.bamm_em_optimize(self.h, C.byref(it)))
         return int(it.value)
 
+    def mask(self, f: float = 0.05) -> int:
+        """EM::mask (EM.cpp:261-503, --advanceEM); the cut-off and list size land in last_mask."""
+        it, cut, listed = C.c_uint32(), C.c_float(), C.c_uint64()
+        check(self.lib.bamm_em_mask(self.h, f, C.byref(it), C.byref(cut), C.byref(listed)))
+        self.last_mask = dict(cutoff=float(cut.value), listed=int(listed.value))
+        return int(it.value)
+
     def getQ(self) -> float:
         q = C.c_float()
         check(self.lib.bamm_em_get_q(self.h, C.byref(q)))

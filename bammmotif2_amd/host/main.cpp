@@ -2,8 +2,8 @@
 // (/root/reference/src/refinement/mainBaMM.cpp, Global.cpp).  The EM itself runs on the GPU
 // through the C ABI (include/bamm_em.h); everything here is host plumbing with the reference's
 // flags, defaults, messages and output files, including --scoreSeqset (.occurrence) and --FDR
-// (cross-validated .zoops.stats).  Not ported (exit with a clear message): --CGS, --advanceEM,
-// --saveLogOdds, non-STANDARD alphabets.
+// (cross-validated .zoops.stats) and --advanceEM (EM::mask).  Not ported (exit with a clear
+// message): --CGS, --saveLogOdds, non-STANDARD alphabets.
 #include <sys/stat.h>
 
 #include <chrono>
@@ -254,7 +254,6 @@ int main(int nargs, char* args[]) {
     if (o.alphabet != "STANDARD") die("Error: this build supports --alphabet STANDARD only.");
     if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
     if (o.saveLogOdds) die("Error: --saveLogOdds is not ported.");
-    if (o.advanceEM) die("Error: --advanceEM is not ported.");
     if (o.K > BAMM_MAX_ORDER) die("Error: model order above 10 is not supported (kmer_ spans 11 bases).");
 
     std::string err;
@@ -370,7 +369,8 @@ int main(int nargs, char* args[]) {
             bamm_em* em = nullptr;
             if (bamm_em_create(ctx, dseqs, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &em)) die_abi("EM");
             uint32_t it = 0;
-            if (bamm_em_optimize(em, &it)) die_abi("EM::optimize");
+            if (!o.advanceEM) { if (bamm_em_optimize(em, &it)) die_abi("EM::optimize"); }      // mainBaMM.cpp:133-137
+            else if (bamm_em_mask(em, o.f, &it, nullptr, nullptr)) die_abi("EM::mask");
             if (bamm_em_get_v(em, motif.v.data())) die_abi("get_v");
             float q = 0;
             bamm_em_get_q(em, &q);
@@ -380,6 +380,10 @@ int main(int nargs, char* args[]) {
                 uint32_t cnt = 0;
                 bamm_em_get_trace(em, llh.data(), vd.data(), qq.data(), it, &cnt);
                 for (uint32_t i = 0; i < cnt && i < it; i++) {
+                    if (o.advanceEM) {                        // EM.cpp:487
+                        std::cout << i + 1 << "th iteration, delta_llikelihood=" << llh[i] - (i ? llh[i - 1] : 0.f) << std::endl;
+                        continue;
+                    }
                     if (o.optimizeQ && i < 5) std::cout << "optimized q=" << qq[i] << std::endl;
                     std::cout << i + 1 << " iter, llh=" << llh[i] << ", diff_llh=" << llh[i] - (i ? llh[i - 1] : 0.f)
                               << ", v_diff=" << vd[i] << std::endl;
@@ -468,7 +472,8 @@ int main(int nargs, char* args[]) {
                     if (bamm_em_create(ctx, dseqs, &p, bg.v.data(), m.A.data(), m.v.data(), train.data(), &em)) die_abi("EM (fold)");
                     uint32_t it = 0;
                     auto t0 = std::chrono::high_resolution_clock::now();
-                    if (bamm_em_optimize(em, &it)) die_abi("EM::optimize (fold)");
+                    if (!o.advanceEM) { if (bamm_em_optimize(em, &it)) die_abi("EM::optimize (fold)"); }   // FDR.cpp:67-72
+                    else if (bamm_em_mask(em, o.f, &it, nullptr, nullptr)) die_abi("EM::mask (fold)");
                     bamm_em_get_v(em, m.v.data());
                     bamm_em_get_q(em, &updatedQ);
                     bamm_em_destroy(em);
@@ -512,6 +517,7 @@ int main(int nargs, char* args[]) {
     std::cout << "\nGiven positive sequence set is " << o.basename << ".\n	" << pos.size() << " sequences, max.length: " << pos.max_len
               << ", min.length: " << pos.min_len << "\n	base frequencies:";
     for (int i = 0; i < 4; i++) std::cout << ' ' << pos.base_freq[i] << "(" << "ACGT"[i] << ")";
+    if (o.advanceEM) std::cout << "\n    " << o.f * 100 << "% of the sequences are used for EM after masking.";   // Global.cpp:370-372
     std::cout << "\nThe background model is generated based on cond.prob of " << o.sOrder << "-mers.";
     if (o.FDR) std::cout << "\nFolds for cross-validation (FDR estimation): " << o.cvFold;
     auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0_wall);

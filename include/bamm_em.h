@@ -145,6 +145,15 @@ int  bamm_em_optimize_q(bamm_em* em);
 int  bamm_em_iterate(bamm_em* em, uint32_t n);
 /* EM::optimize (EM.cpp:62-137) including the stopping rule; *iterations = passes executed.   */
 int  bamm_em_optimize(bamm_em* em, uint32_t* iterations);
+/* EM::mask (EM.cpp:261-503, the `--advanceEM` path; f = Global::f, Global.cpp:54): an order-0
+ * pass over every window, the global cut-off at the f-quantile of the responsibilities, then EM
+ * restricted to the windows at or above it until the stopping rule fires.  Like both reference
+ * call sites (mainBaMM.cpp:131-137, FDR.cpp:67-70) it expects a handle that has not run an
+ * E-step yet.  With optimize_q the reference re-estimates q after every sequence of the first
+ * pass (EM.cpp:321); that chain is inherently serial and is not offered across ranks
+ * (BAMM_ERR_UNSUPPORTED when an all-reduce is installed).  W = 1 is refused: the reference
+ * reads one float past its allocation there (EM.cpp:416).  *cutoff / *listed are optional.     */
+int  bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint64_t* listed);
 
 /* multi-GPU: between the local accumulation and the model update the fused buffer
  * [n_K (4^(K+1)*W) | llh | sum_r | n_seqs] (doubles, on the device, on the context's stream)

@@ -85,6 +85,9 @@ class Oracle:
         L.orc_optimize.argtypes = [_u64p, _u64p, sz, sz, sz, sz, _f32p, _f32p, _f32p,
                                    C.POINTER(f), i, f, sz, _f32p, _f32p, _f32p, _f32p, C.POINTER(f)]
         L.orc_optimize.restype = sz
+        L.orc_mask.argtypes = [_u64p, _u64p, sz, sz, sz, sz, _f32p, _f32p, _f32p, C.POINTER(f), i, f, f, sz,
+                               _f32p, _f32p, _f32p, _f32p, C.POINTER(f), C.POINTER(f), C.POINTER(C.c_uint64)]
+        L.orc_mask.restype = sz
         L.orc_logodds.argtypes = [_u64p, _u64p, sz, sz, sz, _f32p, _f32p, _f32p, _u64p]
         L.orc_init_from_pwm.argtypes = [_f32p, sz, sz, _f32p, _f32p, _u64p, _u64p, sz, f, _f32p]
         L.orc_em_step_f64.argtypes = [_u64p, _u64p, sz, sz, sz, sz, _f32p, _f32p, _f32p, f,
@@ -159,6 +162,23 @@ class Oracle:
                                  C.byref(qv), int(optimizeQ), epsilon, max_iter, r, n, tl, tv, C.byref(llh))
         return dict(iterations=int(it), v=v, q=float(qv.value), llh=float(llh.value), r=r, n=n,
                     trace_llh=tl[:it].copy(), trace_vdiff=tv[:it].copy())
+
+    def mask(self, kmer, off, K, W, bg_order, vbg, A, v0, q, optimizeQ=False, f=0.05,
+             epsilon=0.01, max_iter=1000):
+        off = _u64(off)
+        v = _f32(v0).copy()
+        qv, llh, cut = C.c_float(q), C.c_float(0), C.c_float(0)
+        listed = C.c_uint64(0)
+        r = np.zeros(int(off[-1]), np.float32)
+        n = np.zeros(v_size(K, W), np.float32)
+        tl = np.zeros(max_iter, np.float32)
+        tv = np.zeros(max_iter, np.float32)
+        it = self.L.orc_mask(_u64(kmer), off, len(off) - 1, K, W, bg_order, _f32(vbg), _f32(A), v,
+                             C.byref(qv), int(optimizeQ), f, epsilon, max_iter, r, n, tl, tv, C.byref(llh),
+                             C.byref(cut), C.byref(listed))
+        return dict(iterations=int(it), v=v, q=float(qv.value), llh=float(llh.value), r=r, n=n,
+                    trace_llh=tl[:it].copy(), trace_vdiff=tv[:it].copy(), cutoff=float(cut.value),
+                    listed=int(listed.value))
 
     def logodds(self, kmer, off, K, W, s_log):
         off = _u64(off)
@@ -235,6 +255,8 @@ class Reference:
             getattr(R, name).argtypes = [vp]
         R.ref_em_optimize.argtypes = [vp]
         R.ref_em_optimize.restype = i
+        R.ref_em_mask.argtypes = [vp]
+        R.ref_em_mask.restype = i
         R.ref_em_q.argtypes = [vp]
         R.ref_em_q.restype = f
         R.ref_em_llh.argtypes = [vp]

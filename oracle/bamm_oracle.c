@@ -308,6 +308,147 @@ size_t orc_optimize(const uint64_t* kmer, const uint64_t* off, size_t N, size_t 
     return iteration;
 }
 
+/* ---------------------------------------------------------------- masked EM (--advanceEM) -- */
+
+static int cmp_float_desc(const void* a, const void* b) {
+    float x = *(const float*)a, y = *(const float*)b;
+    return (x < y) - (x > y);
+}
+
+size_t orc_mask(const uint64_t* kmer, const uint64_t* off, size_t N, size_t K, size_t W,
+                size_t bg_order, const float* vbg, const float* A, float* v, float* q_io,
+                int optimizeQ, float f, float epsilon, size_t max_iter, float* r, float* n,
+                float* trace_llh, float* trace_vdiff, float* llh_out, float* cutoff_out,
+                uint64_t* listed_out) {
+    size_t Y = ipow4(K + 1);
+    size_t K_bg = bg_order < K ? bg_order : K;
+    float* s = (float*)calloc(Y * W, sizeof(float));
+    float* pos = (float*)calloc((size_t)off[N] + 1, sizeof(float));    /* EM.cpp:26-32: calloc'ed [N][L] */
+    float* v_before = (float*)malloc(Y * W * sizeof(float));
+    float* vK = v + orc_v_offset(K, W);
+    float q = *q_io;
+    memset(r, 0, (size_t)off[N] * sizeof(float));
+
+    /* EM.cpp:270-274: order-0 odds into the first four rows of s */
+    for (size_t y = 0; y < 4; y++)
+        for (size_t j = 0; j < W; j++) s[y * W + j] = v[y * W + j] / vbg[y];
+
+    size_t pos_count = 0;
+    for (size_t sq = 0; sq < N; sq++) {               /* EM.cpp:279-323 */
+        size_t L = (size_t)(off[sq + 1] - off[sq]);
+        size_t LW1 = L - W + 1;
+        const uint64_t* km = kmer + off[sq];
+        float* rn = r + off[sq];
+        float* pn = pos + off[sq];
+        float normFactor = 1.0f - q;
+        float pos_i = q / (float)LW1;
+        for (size_t i = 0; i < LW1; i++) { rn[i] = 1.0f; pn[i] = pos_i; }
+        for (size_t ij = 0; ij < L; ij++) {           /* :295-305: window 0 never receives a factor */
+            size_t y = km[ij] % 4;
+            size_t padding = ((int)(ij - L + W) > 0) * (ij - L + W);
+            for (size_t j = padding; j < (W < ij ? W : ij); j++) rn[L - W - ij + j] *= s[y * W + j];
+        }
+        for (size_t i = 0; i < LW1; i++) { rn[i] *= pn[L - W - i]; normFactor += rn[i]; }
+        for (size_t i = 0; i < LW1; i++) rn[i] /= normFactor;
+        if (optimizeQ) q = orc_optimize_q(r, off, N, W);   /* :321: inside the sequence loop */
+        pos_count += LW1;
+    }
+
+    /* EM.cpp:329-343: full descending sort, cut-off at index size_t(float(count) * f) */
+    float* r_all = (float*)malloc(pos_count * sizeof(float));
+    size_t o = 0;
+    for (size_t sq = 0; sq < N; sq++) {
+        size_t LW1 = (size_t)(off[sq + 1] - off[sq]) - W + 1;
+        memcpy(r_all + o, r + off[sq], LW1 * sizeof(float));
+        o += LW1;
+    }
+    qsort(r_all, pos_count, sizeof(float), cmp_float_desc);
+    float r_cutoff = r_all[(size_t)((float)pos_count * f)];
+    free(r_all);
+    if (cutoff_out) *cutoff_out = r_cutoff;
+
+    /* EM.cpp:345-356: index lists (r-index, i.e. window start L-W-ri) */
+    uint64_t* ri_off = (uint64_t*)calloc(N + 1, sizeof(uint64_t));
+    for (size_t sq = 0; sq < N; sq++) {
+        size_t LW1 = (size_t)(off[sq + 1] - off[sq]) - W + 1;
+        uint64_t c = 0;
+        for (size_t i = 0; i < LW1; i++) c += r[off[sq] + i] >= r_cutoff;
+        ri_off[sq + 1] = ri_off[sq] + c;
+    }
+    uint32_t* ri = (uint32_t*)malloc((ri_off[N] + 1) * sizeof(uint32_t));
+    for (size_t sq = 0; sq < N; sq++) {
+        size_t LW1 = (size_t)(off[sq + 1] - off[sq]) - W + 1;
+        uint64_t c = ri_off[sq];
+        for (size_t i = 0; i < LW1; i++)
+            if (r[off[sq] + i] >= r_cutoff) ri[c++] = (uint32_t)i;
+    }
+    if (listed_out) *listed_out = ri_off[N];
+
+    float llikelihood_ = 0.0f;                        /* EM.h:61 */
+    int iterate = 1;
+    size_t iteration = 0;
+    while (iterate && iteration < max_iter) {         /* EM.cpp:373-494 */
+        iteration++;
+        float llikelihood_prev = llikelihood_;
+        memcpy(v_before, vK, Y * W * sizeof(float));
+        float llikelihood = 0.0f;
+        orc_linear_s(v, vbg, K, W, K_bg, s);
+        for (size_t sq = 0; sq < N; sq++) {           /* :395-433 */
+            size_t L = (size_t)(off[sq + 1] - off[sq]);
+            size_t LW1 = L - W + 1;
+            const uint64_t* km = kmer + off[sq];
+            float* rn = r + off[sq];
+            float* pn = pos + off[sq];
+            const uint32_t* l = ri + ri_off[sq];
+            size_t cnt = (size_t)(ri_off[sq + 1] - ri_off[sq]);
+            float normFactor = 1.0f - q;
+            float pos_i = q / (float)LW1;
+            for (size_t idx = 0; idx < cnt; idx++) { rn[l[idx]] = 1.0f; pn[l[idx]] = pos_i; }
+            for (size_t idx = 0; idx < cnt; idx++) {
+                for (size_t j = 0; j < W; j++) {
+                    size_t y = km[L - W - l[idx] + j] % Y;
+                    rn[l[idx]] *= s[y * W + j];
+                }
+                rn[l[idx]] *= pn[LW1 - l[idx]];       /* :416: index LW1 (never written) for ri == 0 */
+                normFactor += rn[l[idx]];
+            }
+            rn[0] /= normFactor;                      /* :421 */
+            for (size_t idx = 0; idx < cnt; idx++) rn[l[idx]] /= normFactor;
+            for (size_t i = LW1; i < L; i++) rn[i] = 0.0f;
+            llikelihood += logf(normFactor);
+        }
+        llikelihood_ = llikelihood;
+        memset(n, 0, orc_v_size(K, W) * sizeof(float));
+        float* nK = n + orc_v_offset(K, W);
+        for (size_t sq = 0; sq < N; sq++) {           /* :452-461, serial */
+            size_t L = (size_t)(off[sq + 1] - off[sq]);
+            const uint64_t* km = kmer + off[sq];
+            const float* rn = r + off[sq];
+            for (uint64_t c = ri_off[sq]; c < ri_off[sq + 1]; c++)
+                for (size_t j = 0; j < W; j++) nK[(km[L - W - ri[c] + j] % Y) * W + j] += rn[ri[c]];
+        }
+        for (size_t k = K; k > 0; k--) {              /* :465-472 */
+            float* nk = n + orc_v_offset(k, W);
+            float* nk1 = n + orc_v_offset(k - 1, W);
+            for (size_t y = 0; y < ipow4(k + 1); y++)
+                for (size_t j = 0; j < W; j++) nk1[(y % ipow4(k)) * W + j] += nk[y * W + j];
+        }
+        orc_update_v(n, A, vbg, K, W, v);             /* :475 */
+        float v_diff = 0.0f;
+        for (size_t y = 0; y < Y; y++)
+            for (size_t j = 0; j < W; j++) v_diff += fabsf(vK[y * W + j] - v_before[y * W + j]);
+        float llikelihood_diff = llikelihood_ - llikelihood_prev;
+        if (trace_llh) trace_llh[iteration - 1] = llikelihood_;
+        if (trace_vdiff) trace_vdiff[iteration - 1] = v_diff;
+        if (v_diff < epsilon) iterate = 0;                          /* :488 */
+        if (llikelihood_diff < 0 && iteration > 10) iterate = 0;    /* :489 */
+    }
+    *q_io = q;
+    if (llh_out) *llh_out = llikelihood_;
+    free(s); free(pos); free(v_before); free(ri_off); free(ri);
+    return iteration;
+}
+
 /* ---------------------------------------------------------------- scorer -- */
 
 void orc_logodds(const uint64_t* kmer, const uint64_t* off, size_t N, size_t K, size_t W,

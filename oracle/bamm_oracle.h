@@ -87,6 +87,18 @@ size_t orc_optimize(const uint64_t* kmer, const uint64_t* off, size_t N, size_t 
                     int optimizeQ, float epsilon, size_t max_iter, float* r, float* n,
                     float* trace_llh, float* trace_vdiff, float* llh_out);
 
+/* EM.cpp:261-503 (--advanceEM): order-0 pass over all windows (own boundary rule, :295-305, and
+ * optimize_q() inside the sequence loop, :321), global cut-off at the f-quantile of r by a full
+ * descending sort (:329-343), then EM restricted to the listed windows (full-width products, no
+ * truncation, serial M-step), with the reference's indexing as written (:416 pos_[n][LW1-ri],
+ * :421 r_[n][0] /= normFactor).  r (off[N] floats) is treated as freshly calloc'ed, as at both
+ * reference call sites (mainBaMM.cpp:131-137, FDR.cpp:67-70).  Returns the iteration count. */
+size_t orc_mask(const uint64_t* kmer, const uint64_t* off, size_t N, size_t K, size_t W,
+                size_t bg_order, const float* vbg, const float* A, float* v, float* q_io,
+                int optimizeQ, float f, float epsilon, size_t max_iter, float* r, float* n,
+                float* trace_llh, float* trace_vdiff, float* llh_out, float* cutoff_out,
+                uint64_t* listed_out);
+
 /* ScoreSeqSet.cpp:25-67.  mops: concatenated LW1 scores per sequence (mops_off[n] =
  * sum_{m<n} (L_m-W+1)); zoops[N]; z[N] (first arg-max). */
 void   orc_logodds(const uint64_t* kmer, const uint64_t* off, size_t N, size_t K, size_t W,

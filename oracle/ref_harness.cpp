@@ -196,6 +196,7 @@ void ref_em_estep(void* e) { static_cast<EM*>(e)->EStep(); }
 void ref_em_mstep(void* e) { static_cast<EM*>(e)->MStep(); }
 void ref_em_optimize_q(void* e) { static_cast<EM*>(e)->optimize_q(); }
 int ref_em_optimize(void* e) { return static_cast<EM*>(e)->optimize(); }
+int ref_em_mask(void* e) { return static_cast<EM*>(e)->mask(); }          // EM.cpp:261-503 (--advanceEM)
 float ref_em_q(void* e) { return static_cast<EM*>(e)->getQ(); }
 float ref_em_llh(void* e) { return static_cast<EM*>(e)->llikelihood_; }
 const float* ref_em_r(void* e, uint64_t n) { return static_cast<EM*>(e)->getR()[n]; }

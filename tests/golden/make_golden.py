@@ -171,11 +171,59 @@ def run_travis_case(R):
     print("wrote travis_jund", neg.N, len(occ), len(files["zoops.stats"]))
 
 
+def run_mask_cases(R):
+    """EM::mask (--advanceEM, EM.cpp:261-503) run by the reference itself on the small cases; W=1 is
+    left out (the reference reads pos_[n][L], one float past its allocation, EM.cpp:416)."""
+    O = oracle.Oracle()
+    O.set_threads(1)
+    for spec in SMALL_CASES:
+        c = Case(**spec)
+        if c.W < 2:
+            continue
+        S = R.session(c.codes, c.in_off, c.ss, 42)
+        kmer = S.kmers()
+        bg, vbg = S.bg(c.bg_order, c.alpha_bg)
+        out = dict(vbg=vbg, kmer_sha256=digest(kmer))
+        nr = min(16, S.N)
+        rlen = int(S.off[nr])
+        for oq in (0, 1):
+            for f in (0.05, 0.2):
+                tag = f"oq{oq}_f{int(f * 100)}"
+                m = S.motif(c.W, c.K, c.alpha, bg, c.q, c.v0)
+                e = S.em(m, bg, bool(oq), False, f)
+                S.R.ref_em_mask(e)
+                out[tag + "_v"] = S.motif_v(m)
+                out[tag + "_p"] = S.motif_p(m)
+                out[tag + "_q"] = np.float32(S.R.ref_em_q(e))
+                out[tag + "_llh"] = np.float32(S.R.ref_em_llh(e))
+                out[tag + "_n"] = S.em_n(e, c.K, c.W)
+                r = S.em_r(e)
+                out[tag + "_r"] = r[:rlen]
+                out[tag + "_r_sha256"] = digest(r)
+                # iteration count / cut-off are not exposed by the reference: taken from the C
+                # restatement after checking that it reproduces every exposed value bit for bit
+                res = O.mask(kmer, S.off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=bool(oq), f=f)
+                assert np.array_equal(res["v"], out[tag + "_v"]) and np.array_equal(res["r"], r)
+                assert np.float32(res["q"]) == out[tag + "_q"] and np.float32(res["llh"]) == out[tag + "_llh"]
+                out[tag + "_iterations"] = res["iterations"]
+                out[tag + "_cutoff"] = np.float32(res["cutoff"])
+                out[tag + "_listed"] = res["listed"]
+                out[tag + "_trace_llh"] = res["trace_llh"]
+                out[tag + "_trace_vdiff"] = res["trace_vdiff"]
+        S.close()
+        np.savez_compressed(os.path.join(HERE, f"mask_{c.name}.npz"), **out)
+        print("wrote mask", c.name)
+
+
 def main():
     if not oracle.have_reference():
         raise SystemExit("oracle/_ref/libbammref.so missing: run `make -C oracle ref` in the dev container")
     R = oracle.Reference()
     R.set_threads(1)
+    if sys.argv[1:] == ["mask"]:
+        run_mask_cases(R)
+        return
+    run_mask_cases(R)
     run_eval_case(R)
     run_travis_case(R)
     for spec in SMALL_CASES:

@@ -117,3 +117,42 @@ def test_cli_travis_smoke_line(tmp_path, gpu_ctx):
     from collections import Counter
     common = sum((Counter(ref_hits) & Counter(my_hits)).values())
     assert common >= 0.97 * len(ref_hits)
+
+
+@pytest.mark.parametrize("oq", [False, True], ids=["fixq", "optq"])
+def test_cli_advance_em_on_jund(oq, tmp_path, orc, gpu_ctx):
+    """`--EM --advanceEM -f 0.1` (mainBaMM.cpp:133-137 -> EM::mask) against the pinned restatement."""
+    build.build_host()
+    K, f = 1, 0.1
+    out = tmp_path / "o"
+    cmd = [build.CLI, str(out), FASTA, "--PWMFile", MEME, "--EM", "--advanceEM", "-f", str(f), "-k", str(K), "--maxPWM", "1",
+           "--verbose", "--saveBaMMs"] + (["--optimizeQ"] if oq else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    assert "10% of the sequences are used for EM after masking." in r.stdout           # Global.cpp:370-372
+    codes, off = read_fasta_py(FASTA)
+    _, kmer, o = orc.encode_set(codes, off, False, 42)
+    vbg = orc.bg_model(kmer, o, 2, np.array([1, 10, 10], np.float32))
+    lines = open(MEME).read().split("\n")
+    i = [k for k, l in enumerate(lines) if "letter-probability matrix" in l][0]
+    W = 12
+    pwm = np.array([[float(x) for x in lines[i + 1 + j].split()] for j in range(W)], np.float32).T.copy()
+    A = bm.synth.alpha_matrix(bm.synth.default_alpha(K), W)
+    v0 = orc.init_from_pwm(pwm, W, K, A, vbg, kmer, o, 0.3)
+    res = orc.mask(kmer, o, K, W, 2, vbg, A, v0, 0.3, optimizeQ=oq, f=f)
+    d = [float(x) for x in re.findall(r"^\d+th iteration, delta_llikelihood=([-\d.e+]+)$", r.stdout, re.M)]
+    assert abs(len(d) - res["iterations"]) <= 1
+    m = min(len(d), res["iterations"], 8)
+    ref_d = np.diff(np.concatenate([[0.0], res["trace_llh"]]))
+    np.testing.assert_allclose(d[:m], ref_d[:m], rtol=1e-3, atol=2e-3)
+    q_line = re.search(r"optimized q = ([\d.e+-]+)", r.stdout)                           # mainBaMM.cpp:147
+    assert float(q_line.group(1)) == pytest.approx(res["q"], rel=1e-5)
+    if len(d) == res["iterations"]:
+        v = parse_ihbcp(out / "JunD_motif_1.ihbcp", K, W)
+        np.testing.assert_allclose(v, res["v"], rtol=5e-3, atol=1e-6)
+        pos = open(out / "JunD_motif_1.positions").read().strip().split("\n")           # r_ after mask (EM.cpp:583-601)
+        n_hits = 0
+        for n in range(300):
+            L = int(o[n + 1] - o[n])
+            n_hits += int((res["r"][int(o[n]):int(o[n]) + L - W + 1] >= 0.3).sum())
+        assert abs((len(pos) - 1) - n_hits) <= 3

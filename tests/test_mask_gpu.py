@@ -1,0 +1,130 @@
+"""EM::mask (`--advanceEM`, EM.cpp:261-503) on the device against the oracle's restatement, which is
+bit-identical to the reference's own mask() (tests/test_mask_cpu.py).
+
+The order-0 pass sums in the reference's sequential fp32 order, so the cut-off, the list of
+windows and (with optimizeQ) the per-sequence q chain must match EXACTLY; the masked iterations
+carry summation-order noise only.
+"""
+import numpy as np
+import pytest
+
+import bammmotif2_amd as bm
+from tests.cases import SMALL_CASES, Case
+from tests.test_parity_gpu import make_em
+
+pytestmark = pytest.mark.gpu
+
+CASES = [d for d in SMALL_CASES if d["W"] >= 2]
+
+
+@pytest.mark.parametrize("oq", [False, True], ids=["fixq", "optq"])
+@pytest.mark.parametrize("f", [0.05, 0.2])
+@pytest.mark.parametrize("spec", CASES, ids=[d["name"] for d in CASES])
+def test_mask_three_passes_match_oracle(spec, f, oq, gpu_ctx, orc):
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=oq, epsilon=0.0, max_iterations=3)
+    it = em.mask(f)
+    res = orc.mask(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=oq, f=f, epsilon=0.0, max_iter=3)
+    assert it == res["iterations"] == 3
+    assert np.float32(em.last_mask["cutoff"]) == np.float32(res["cutoff"])          # EM.cpp:343
+    assert em.last_mask["listed"] == res["listed"]                                   # EM.cpp:345-356
+    assert np.float32(em.getQ()) == np.float32(res["q"])                             # EM.cpp:321 chain
+    np.testing.assert_allclose(em.getCounts(), res["n"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
+    llh, vd, _ = em.trace()
+    np.testing.assert_allclose(llh, res["trace_llh"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(vd, res["trace_vdiff"], rtol=1e-3, atol=1e-6)
+    r = em.getR()
+    np.testing.assert_allclose(r, res["r"], rtol=2e-5, atol=1e-12)                    # incl. the r_[n][0] decay (:421)
+    assert np.array_equal(r == 0, res["r"] == 0)
+    em.close(); ss.close()
+
+
+def test_mask_stopping_rule_and_state_checks(gpu_ctx, orc):
+    c = Case(**SMALL_CASES[0])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    it = em.mask(0.05)
+    res = orc.mask(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+    m = min(it, res["iterations"])
+    assert m >= 5
+    llh, vd, _ = em.trace()
+    np.testing.assert_allclose(llh[:m], res["trace_llh"][:m], rtol=2e-5, atol=1e-5)
+    if it == res["iterations"]:
+        np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-4, atol=1e-8)
+    with pytest.raises(RuntimeError, match="already run"):
+        em.mask(0.05)
+    em.close()
+    em2 = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order)
+    with pytest.raises(RuntimeError, match="fraction"):
+        em2.mask(1.5)
+    em2.close(); ss.close()
+
+
+def test_mask_on_a_fold(gpu_ctx, orc):
+    """FDR.cpp:49-70: mask() on the training part of a fold == mask() on that subset alone."""
+    c = Case(**SMALL_CASES[0])
+    seq, kmer, off, vbg = c.encode(orc)
+    keep = (np.arange(c.N) % 4 != 1)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(gpu_ctx, pk)
+    em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, optimizeQ=True,
+               mask=keep.astype(np.uint8), epsilon=0.0, max_iterations=2)
+    em.mask(0.1)
+    lens = np.diff(off.astype(np.int64))
+    sub_kmer = np.concatenate([kmer[int(off[n]):int(off[n + 1])] for n in range(c.N) if keep[n]])
+    sub_off = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.uint64)
+    res = orc.mask(sub_kmer, sub_off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=True, f=0.1,
+                   epsilon=0.0, max_iter=2)
+    assert np.float32(em.last_mask["cutoff"]) == np.float32(res["cutoff"])
+    assert em.last_mask["listed"] == res["listed"]
+    assert np.float32(em.getQ()) == np.float32(res["q"])
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
+    em.close(); ss.close()
+
+
+def test_mask_k4_sliced_counts(gpu_ctx, orc):
+    """k=4, W=30: odds table read from HBM, counts in column slices."""
+    c = Case("k4", N=60, L0=120, W=30, K=4, seed=5, ss=True)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, epsilon=0.0, max_iterations=2)
+    em.mask(0.1)
+    res = orc.mask(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, f=0.1, epsilon=0.0, max_iter=2)
+    assert em.last_mask["listed"] == res["listed"]
+    np.testing.assert_allclose(em.getCounts(), res["n"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
+    em.close(); ss.close()
+
+
+def _mask_fixtures():
+    import glob, os
+    from tests.golden_util import GOLDEN_DIR
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, "mask_*.npz")))
+
+
+@pytest.mark.parametrize("name", _mask_fixtures())
+def test_mask_against_reference_golden(name, gpu_ctx, orc):
+    """The HIP path against values the reference's own mask() produced (tests/golden/mask_*.npz)."""
+    import os
+    from tests.golden_util import GOLDEN_DIR
+    c = Case(**next(d for d in SMALL_CASES if d["name"] == name))
+    g = np.load(os.path.join(GOLDEN_DIR, f"mask_{name}.npz"))
+    for oq in (0, 1):
+        for f in (0.05, 0.2):
+            t = f"oq{oq}_f{int(f * 100)}"
+            em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=bool(oq))
+            it = em.mask(f)
+            assert np.float32(em.last_mask["cutoff"]) == g[t + "_cutoff"]
+            assert em.last_mask["listed"] == int(g[t + "_listed"])
+            assert np.float32(em.getQ()) == g[t + "_q"]
+            m = min(it, int(g[t + "_iterations"]))
+            llh, vd, _ = em.trace()
+            # the trajectory is compared while it is still well-conditioned; EM amplifies rounding
+            # noise over dozens of passes (see tests/test_golden_gpu.py)
+            head = min(m, 8)
+            np.testing.assert_allclose(llh[:head], g[t + "_trace_llh"][:head], rtol=2e-5, atol=1e-5)
+            np.testing.assert_allclose(vd[:head], g[t + "_trace_vdiff"][:head], rtol=2e-3, atol=1e-5)
+            if it == int(g[t + "_iterations"]):
+                np.testing.assert_allclose(em.getV(), g[t + "_v"], rtol=1e-3, atol=1e-6)
+                nr = len(g[t + "_r"])
+                r = em.getR()[:nr]
+                np.testing.assert_allclose(r, g[t + "_r"], rtol=2e-3, atol=1e-9)
+            em.close(); ss.close()
