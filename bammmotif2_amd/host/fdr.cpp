@@ -1,6 +1,7 @@
 // Evaluation side of the BaMMmotif drop-in: negative-set sampler, FDR / PR statistics and window
 // p-values.  Restated from the reference lines cited in bamm_host.h; fp32 expression order kept.
 #include <algorithm>
+#include <charconv>
 #include <cassert>
 #include <cmath>
 #include <cstdlib>
@@ -101,27 +102,113 @@ struct NegSampler {
         }
     }
 
+    // libc's rand() behind a per-call lock costs more than the sampling itself (400 M draws for
+    // 2 M negatives).  glibc's default generator (TYPE_3 additive feedback, x[i] = x[i-3] + x[i-31],
+    // seeded by the Park-Miller LCG, 310 outputs discarded) is restated here and used only after
+    // its first draws have been checked against srand(42)/rand() of the running libc; otherwise
+    // the sampler stays on rand().  Every later rand() consumer reseeds (FDR.cpp:153).
+    struct Stream {
+        uint32_t r[34];
+        int i = 0;
+        bool fast = false;
+        void seed(uint32_t sd) {
+            int32_t x[344 + 34];
+            x[0] = (int32_t)sd;
+            for (int k = 1; k < 31; k++) {
+                int64_t w = (16807LL * x[k - 1]) % 2147483647LL;
+                if (w < 0) w += 2147483647LL;
+                x[k] = (int32_t)w;
+            }
+            for (int k = 31; k < 34; k++) x[k] = x[k - 31];
+            for (int k = 34; k < 344; k++) x[k] = (int32_t)((uint32_t)x[k - 31] + (uint32_t)x[k - 3]);
+            for (int k = 0; k < 34; k++) r[k] = (uint32_t)x[344 - 34 + k];   // the last 34 words are the state
+            i = 0;
+        }
+        inline int next_fast() {                   // o[k] = o[k-31] + o[k-3] over a ring of 34
+            int a = i + 3, b = i + 31;
+            a -= a >= 34 ? 34 : 0;
+            b -= b >= 34 ? 34 : 0;
+            const uint32_t v = r[a] + r[b];
+            r[i] = v;
+            i = i + 1 == 34 ? 0 : i + 1;
+            return (int)(v >> 1);
+        }
+        inline int next() { return fast ? next_fast() : rand(); }
+        void start() {                             // srand(42) happened just before
+            seed(42u);
+            fast = true;
+            int mine[8];
+            for (int k = 0; k < 8; k++) mine[k] = next_fast();
+            srand(42);
+            for (int k = 0; k < 8; k++) if (rand() != mine[k]) fast = false;
+            srand(42);
+            seed(42u);
+        }
+    } stream;
+
+    // F sequences of the same length from the same tables, drawn one after the other from the
+    // stream (sequence f consumes draws [f*L, (f+1)*L)) but advanced position by position together:
+    // the per-base dependency chain (context -> bars -> base -> context) of one sequence overlaps
+    // with those of the others.
+    void draw_many(size_t L, size_t F, uint8_t* seqs, std::vector<float>& rnd, std::vector<size_t>& ctx) {
+        if (s >= L || F == 1) { for (size_t f = 0; f < F; f++) draw(L, seqs + f * L); return; }
+        rnd.resize(F * L);
+        for (size_t k = 0; k < F * L; k++) rnd[k] = (float)stream.next() / (float)RAND_MAX;
+        ctx.assign(F, 0);
+        for (size_t f = 0; f < F; f++) {               // the first s bases: lower-order bars (as in draw())
+            uint8_t* seq = seqs + f * L;
+            const float* r = rnd.data() + f * L;
+            for (uint8_t y = 0; y < 4; y++)
+                if (r[0] <= range_bar[y]) { seq[0] = y + 1; break; }
+            for (size_t i = 1; i < s; i++) {
+                size_t yk = 0;
+                for (size_t k = i; k > 0; k--) yk += (size_t)(seq[i - k] - 1) * ipow4(k);
+                for (size_t y = yk, a = 1; y < yk + 4; y++, a++) {
+                    seq[i] = (uint8_t)a;
+                    if (r[i] <= range_bar[bgoff(i) + y]) break;
+                }
+            }
+            for (size_t k = s; k > 0; k--) ctx[f] = ctx[f] * 4 + (size_t)(seq[s - k] - 1);
+        }
+        const size_t ctx_mask = ipow4(s) - 1;
+        const float* bar = range_bar.data() + bgoff(s);
+        for (size_t i = s; i < L; i++)
+            for (size_t f = 0; f < F; f++) {
+                const float* b4 = bar + ctx[f] * 4;
+                const float random = rnd[f * L + i];
+                const uint8_t a = (uint8_t)(1 + (random > b4[0]) + (random > b4[1]) + (random > b4[2]));
+                seqs[f * L + i] = a;
+                ctx[f] = (ctx[f] * 4 + (size_t)(a - 1)) & ctx_mask;
+            }
+    }
+
     void draw(size_t L, uint8_t* seq) {             // :222-283 == :296-341 (same sampling loop)
-        float random = (float)rand() / (float)RAND_MAX;
+        float random = (float)stream.next() / (float)RAND_MAX;
         for (uint8_t y = 0; y < 4; y++)
             if (random <= range_bar[y]) { seq[0] = y + 1; break; }
         for (size_t i = 1; i < s && i < L; i++) {
             size_t yk = 0;
             for (size_t k = i; k > 0; k--) yk += (size_t)(seq[i - k] - 1) * ipow4(k);
-            random = (float)rand() / (float)RAND_MAX;
+            random = (float)stream.next() / (float)RAND_MAX;
             for (size_t y = yk, a = 1; y < yk + 4; y++, a++) {
                 seq[i] = (uint8_t)a;
                 if (random <= range_bar[bgoff(i) + y]) break;
             }
         }
+        if (s >= L) return;
+        // context of the previous s bases, rolled forward (yk = sum_k (seq[i-k]-1) * 4^k)
+        const size_t ctx_mod = ipow4(s);
+        size_t ctx = 0;
+        for (size_t k = s; k > 0; k--) ctx = ctx * 4 + (size_t)(seq[s - k] - 1);
+        const float* bar = range_bar.data() + bgoff(s);
         for (size_t i = s; i < L; i++) {
-            size_t yk = 0;
-            for (size_t k = s; k > 0; k--) yk += (size_t)(seq[i - k] - 1) * ipow4(k);
-            random = (float)rand() / (float)RAND_MAX;
-            for (size_t y = yk, a = 1; y < yk + 4; y++, a++) {
-                seq[i] = (uint8_t)a;
-                if (random <= range_bar[bgoff(s) + y]) break;
-            }
+            const float* b4 = bar + ctx * 4;
+            random = (float)stream.next() / (float)RAND_MAX;
+            // first base whose cumulative bar reaches `random`, the last one when none does; the
+            // bars are running sums (non-decreasing), so counting the bars below is the same thing
+            const uint8_t a = (uint8_t)(1 + (random > b4[0]) + (random > b4[1]) + (random > b4[2]));
+            seq[i] = a;
+            ctx = (ctx * 4 + (size_t)(a - 1)) & (ctx_mod - 1);
         }
     }
 };
@@ -136,18 +223,27 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
     }
     srand(42);                                         // SeqGenerator.cpp:35
     NegSampler g(s_order);
+    g.stream.start();
     g.kmer_frequency(y_s, off, n_seqs);
     codes_out.clear();
     off_out.assign(1, 0);
+    std::vector<float> rnd;
+    std::vector<size_t> ctx;
+    {
+        size_t total = 0;
+        for (size_t i = 0; i < n_seqs; i++) total += (off[i + 1] - off[i]) * m_fold;
+        codes_out.reserve(total);
+        off_out.reserve(n_seqs * m_fold + 1);
+    }
     for (size_t i = 0; i < n_seqs; i++) {
         const size_t L = off[i + 1] - off[i];
-        for (size_t f = 0; f < m_fold; f++) {
-            if (!generic) g.rescale(y_s + off[i], L);
-            const size_t o = codes_out.size();
-            codes_out.resize(o + L, 0);
-            g.draw(L, codes_out.data() + o);
-            off_out.push_back(codes_out.size());
-        }
+        // the reference recomputes the rescaled tables for every fold (SeqGenerator.cpp:296); they
+        // only depend on the positive sequence, so once per sequence gives the same tables
+        if (!generic) g.rescale(y_s + off[i], L);
+        const size_t o = codes_out.size();
+        codes_out.resize(o + L * m_fold, 0);
+        g.draw_many(L, m_fold, codes_out.data() + o, rnd, ctx);
+        for (size_t f = 0; f < m_fold; f++) off_out.push_back(o + L * (f + 1));
     }
     return 0;
 }
@@ -244,34 +340,69 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
     }
 }
 
+namespace {
+
+// rows of floats exactly as `ostream << float` prints them (printf %g at the stream's precision),
+// collected in memory and written once: the reference ends every row with std::endl, i.e. one
+// write() per line, which at 2.2 M rows costs more than computing the statistics
+struct RowWriter {
+    std::string buf;
+    int precision;
+    explicit RowWriter(int prec = 6) : precision(prec) { buf.reserve(1 << 20); }
+    void num(float x) {
+        char tmp[48];
+        auto res = std::to_chars(tmp, tmp + sizeof tmp, x, std::chars_format::general, precision);
+        buf.append(tmp, res.ptr);
+    }
+    void tab() { buf.push_back('\t'); }
+    void nl() { buf.push_back('\n'); }
+    void flush_to(std::ofstream& f) { f.write(buf.data(), (std::streamsize)buf.size()); buf.clear(); }
+    void maybe_flush(std::ofstream& f) { if (buf.size() > (1 << 20) - 256) flush_to(f); }
+};
+
+}  // namespace
+
 int fdr_write(const std::string& dir, const std::string& basename, const FdrResult& r, size_t posN, size_t negN,
               bool mops, bool zoops, bool save_prs, bool save_pvalues, std::string& err) {
     const std::string opath = dir + '/' + basename;
     if (save_prs) {
-        if (zoops) {
+        if (zoops) {                                   // FDR.cpp:385-407
             std::ofstream f(opath + ".zoops.stats");
             if (!f.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
             f << "TP" << '\t' << "FP" << '\t' << "FDR" << '\t' << "Recall" << '\t' << "p-value" << '\t'
               << (float)negN / (float)posN << '\t' << r.occ_frac << std::endl;
-            for (size_t i = 0; i < r.zoops_fdr.size(); i++)
-                f << r.zoops_tp[i] << '\t' << r.zoops_fp[i] << '\t' << r.zoops_fdr[i] << '\t' << r.zoops_rec[i] << '\t'
-                  << r.pn_pvalue[i] << '\t' << std::endl;
+            RowWriter w;
+            for (size_t i = 0; i < r.zoops_fdr.size(); i++) {
+                w.num(r.zoops_tp[i]); w.tab(); w.num(r.zoops_fp[i]); w.tab(); w.num(r.zoops_fdr[i]); w.tab();
+                w.num(r.zoops_rec[i]); w.tab(); w.num(r.pn_pvalue[i]); w.tab(); w.nl();
+                w.maybe_flush(f);
+            }
+            w.flush_to(f);
         }
-        if (mops) {
+        if (mops) {                                    // FDR.cpp:409-425
             std::ofstream f(opath + ".mops.stats");
             f << "TP" << '\t' << "FP" << '\t' << "FDR" << '\t' << "Recall" << '\t' << r.occ_mult << std::endl;
-            for (size_t i = 0; i < r.mops_fdr.size(); i++)
-                f << r.mops_tp[i] << '\t' << r.mops_fp[i] << '\t' << r.mops_fdr[i] << '\t' << r.mops_rec[i] << '\t' << std::endl;
+            RowWriter w;
+            for (size_t i = 0; i < r.mops_fdr.size(); i++) {
+                w.num(r.mops_tp[i]); w.tab(); w.num(r.mops_fp[i]); w.tab(); w.num(r.mops_fdr[i]); w.tab();
+                w.num(r.mops_rec[i]); w.tab(); w.nl();
+                w.maybe_flush(f);
+            }
+            w.flush_to(f);
         }
     }
-    if (save_pvalues) {
+    if (save_pvalues) {                                // FDR.cpp:428-449, setprecision(3)
         if (zoops) {
             std::ofstream f(opath + ".zoops.pvalues");
-            for (float p : r.zoops_pvalue) f << std::setprecision(3) << p << std::endl;
+            RowWriter w(3);
+            for (float p : r.zoops_pvalue) { w.num(p); w.nl(); w.maybe_flush(f); }
+            w.flush_to(f);
         }
         if (mops) {
             std::ofstream f(opath + ".mops.pvalues");
-            for (float p : r.mops_pvalue) f << std::setprecision(3) << p << std::endl;
+            RowWriter w(3);
+            for (float p : r.mops_pvalue) { w.num(p); w.nl(); w.maybe_flush(f); }
+            w.flush_to(f);
         }
     }
     return 0;

@@ -4,6 +4,7 @@
 // flags, defaults, messages and output files, including --scoreSeqset (.occurrence) and --FDR
 // (cross-validated .zoops.stats) and --advanceEM (EM::mask).  Not ported (exit with a clear
 // message): --CGS, --saveLogOdds, non-STANDARD alphabets.
+#include <omp.h>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -227,6 +228,7 @@ Options parse(int nargs, char** args) {
     o.optimizeQ = a.present(0, "optimizeQ");
     o.advanceEM = a.present(0, "advanceEM");
     a.get(0, "threads", o.threads);
+    omp_set_num_threads((int)std::max<size_t>(1, o.threads));   // Global.cpp:331-333 (default 4)
     // extensions of this build (the reference advertises but never parses the first two, Global.cpp:479-491)
     a.get(0, "maxEMIterations", o.max_iter);
     a.get('e', "epsilon", o.epsilon);
@@ -243,6 +245,15 @@ Options parse(int nargs, char** args) {
 
 int main(int nargs, char* args[]) {
     auto t0_wall = std::chrono::high_resolution_clock::now();
+    // BAMM_TIMING=1: wall time per stage on stderr (stdout stays the reference's)
+    const bool timing = getenv("BAMM_TIMING") != nullptr;
+    auto t_stage = t0_wall;
+    auto stage = [&](const char* what) {
+        if (!timing) return;
+        auto now = std::chrono::high_resolution_clock::now();
+        std::cerr << "[timing] " << what << ": " << std::chrono::duration<double>(now - t_stage).count() << " s" << std::endl;
+        t_stage = now;
+    };
     std::cout << std::endl
               << "======================================" << std::endl
               << "=      Welcome to use BaMM!motif     =" << std::endl
@@ -260,8 +271,10 @@ int main(int nargs, char* args[]) {
     FastaSet pos;
     if (read_fasta(o.fasta, pos, err)) die(err);
     if (pos.size() < o.cvFold) die("Error: Input sequences are too few for training! \n");
+    stage("read FASTA");
     bamm_packed* packed = nullptr;
     if (bamm_pack_codes(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, &packed)) die_abi("packing sequences");
+    stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
 
     if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
     BgModel bg;
@@ -271,6 +284,7 @@ int main(int nargs, char* args[]) {
         die(err);
     }
     if (bg_write(o.out_dir, o.basename, bg, err)) die(err);   // always saved (mainBaMM.cpp:51)
+    stage("background model");
 
     if (o.verbose) std::cout << std::endl << "***************************" << std::endl << "*   Initial Motif Model   *" << std::endl << "***************************" << std::endl;
     std::vector<uint32_t> yK(packed->total_len ? packed->total_len : 1);
@@ -281,6 +295,7 @@ int main(int nargs, char* args[]) {
     // MotifSet hands Global::bgModelOrder and the model's v to every Motif (mainBaMM.cpp:60-70)
     if (load_seeds(o.seed_file, o.seed_tag, (uint32_t)o.extend[0], (uint32_t)o.extend[1], o.K, o.alpha, o.maxPWM, o.q, bg,
                    yK.data(), off.data(), pos.size(), seeds, err)) die(err);
+    stage("seed models (initFromPWM / BaMM / sites)");
 
     // drop sequences shorter than the widest motif (mainBaMM.cpp:75-83)
     std::vector<uint8_t> keep(pos.size(), 1);
@@ -312,6 +327,7 @@ int main(int nargs, char* args[]) {
         }
         if (bamm_seqs_upload(ctx, use, 0, use->n_seqs, &dseqs)) die_abi("upload");
         kept_len.assign(use->len, use->len + use->n_seqs);
+        stage("device context + upload of the positives");
         if (o.score || o.FDR) {
             // negative set sampled from the s-mer statistics of the (kept) positives, mainBaMM.cpp:97-116
             size_t mFold = o.mFold;
@@ -326,6 +342,7 @@ int main(int nargs, char* args[]) {
             if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) die_abi("packing negatives");
             if (bamm_seqs_upload(ctx, npk, 0, npk->n_seqs, &dneg)) die_abi("upload negatives");
             bamm_packed_free(npk);
+            stage("negative set: sample + pack + upload");
         }
         if (filtered) bamm_packed_free(filtered);
     }
@@ -392,6 +409,7 @@ int main(int nargs, char* args[]) {
             motif_calculate_p(motif, bg);
             auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0);
             std::cout << "\n--- Runtime for EM: " << dt.count() << " seconds ---\n";        // EM.cpp:134
+            stage("EM (create + optimize + read-back)");
             if (o.saveBaMMs) {                                // EM::write (EM.cpp:553-601)
                 std::vector<float> cnts(bamm_v_size(motif.K, motif.W));
                 bamm_em_get_counts(em, cnts.data());
@@ -438,6 +456,7 @@ int main(int nargs, char* args[]) {
             std::cout << "Note: the model is not optimized!\n";
         }
         if (motif_write(o.out_dir, mbase, motif, err)) die(err);
+        stage("write model (+ .counts/.positions)");
         if (o.score) {                                       // mainBaMM.cpp:171-236
             if (o.verbose) std::cout << std::endl << "*************************" << std::endl << "*    Score Sequences    *" << std::endl << "*************************" << std::endl << std::endl;
             Motif sm = motif;
@@ -448,6 +467,7 @@ int main(int nargs, char* args[]) {
             mops_pvalues(pos_mops.data(), pos_mops.size(), neg_mops, kept_len.size(), pv, ev);
             if (occurrence_write(o.out_dir, mbase, kept_headers, kept_codes.data(), kept_off.data(), kept_len.size(), o.ss, sm.W,
                                  pv.data(), ev.data(), o.pvalCutoff, err)) die(err);
+            stage("--scoreSeqset: score + p-values + .occurrence");
         }
     }
 
@@ -503,10 +523,12 @@ int main(int nargs, char* args[]) {
                     o_m += nw;
                 }
             }
+            stage("--FDR: fold EMs + scoring");
             FdrResult res;
             fdr_statistics(posMax, negMax, posAll, negAll, P, negN, updatedQ, o.mops, o.zoops, o.savePvalues, res);
             if (fdr_write(o.out_dir, o.basename + "_motif_" + std::to_string(n + 1), res, P, negN, o.mops, o.zoops, o.savePRs,
                           o.savePvalues, err)) die(err);
+            stage("--FDR: PR / p-value statistics + writers");
         }
     }
 

@@ -55,13 +55,32 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may actually burn: the affinity mask capped by the cgroup CPU quota (a
+    container can see 256 logical CPUs and be throttled to 16; OpenMP on all 256 then crawls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, round(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(codes, in_off, W, K, v0, alpha, q, sample, iters, ss):
     """The reference's EM::EStep/MStep (compiled in place into oracle/_ref) on the host cores."""
     import oracle
     n = min(sample, len(in_off) - 1)
     sub_off = np.ascontiguousarray(in_off[: n + 1])
     sub_codes = np.ascontiguousarray(codes[: int(sub_off[-1])])
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()
     alpha_bg = np.array([1.0, 10.0, 10.0], np.float32)
     if oracle.have_reference():
         R = oracle.Reference()
@@ -240,7 +259,7 @@ def main():
                                                    args.cpu_iters, args.ss)
                 out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a reported number, never a reason to lose the line
-                out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": os.cpu_count(),
+                out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": usable_cpus(),
                                        "kind": "unavailable", "sample": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5 through the drop-in CLI: 200k x 200 bp, -k 2, --FDR -n 5 -m 10 (5-fold CV,
-10x sampled negatives).  Writes a FASTA + MEME seed, runs BaMMmotif, prints wall times."""
+10x sampled negatives).  Writes a FASTA + MEME seed, runs BaMMmotif, prints wall times (per stage
+with BAMM_TIMING=1).  `config5_run.py N OUT em` runs the plain --EM line instead (config 3 at N=1M)."""
 import os, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,11 +26,15 @@ with open(os.path.join(out, "seed.meme"), "w") as f:
 print("inputs written in %.1f s" % (time.time() - t))
 build.build_host()
 t = time.time()
+em_only = len(sys.argv) > 3 and sys.argv[3] == "em"
+extra = [] if em_only else ["--FDR", "-n", "5", "-m", "10"]
 r = subprocess.run([build.CLI, os.path.join(out, "res"), os.path.join(out, "pos.fasta"), "--PWMFile", os.path.join(out, "seed.meme"),
-                    "--EM", "-k", "2", "--FDR", "-n", "5", "-m", "10", "--maxEMIterations", "60"], capture_output=True, text=True)
+                    "--EM", "-k", "2", "--maxEMIterations", "60"] + extra, capture_output=True, text=True,
+                   env=dict(os.environ, BAMM_TIMING="1"))
 dt = time.time() - t
 print("BaMMmotif exit", r.returncode, "wall %.1f s" % dt)
 print("\n".join(l for l in r.stdout.splitlines() if "Runtime" in l))
-print(r.stderr[-500:])
+print(r.stderr[-2500:])
 print(sorted(os.listdir(os.path.join(out, "res"))))
-print(open(os.path.join(out, "res", "pos_motif_1.zoops.stats")).read()[:300])
+if not em_only:
+    print(open(os.path.join(out, "res", "pos_motif_1.zoops.stats")).read()[:300])
