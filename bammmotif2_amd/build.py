@@ -11,27 +11,49 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbamm_em.so")
-SOURCES = ["kernels.hip", "mask.hip", "abi.cpp", "pack.cpp"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "bamm_em.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+SOURCES = ["kernels.hip", "grouped.hip", "mask.hip", "abi.cpp", "pack.cpp"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"),
+           os.path.join(HERE, "..", "include", "bamm_em.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
+OBJDIR = os.path.join(HERE, "build")
 
 
-def is_stale() -> bool:
-    if not os.path.exists(LIB):
+def _obj(src: str) -> str:
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def is_stale() -> bool:
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
+    """One object per source (rebuilt only when it or a header changed, in parallel), then link."""
     if not force and not is_stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the gfx950 extension")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), _obj(s)
+        if force or _stale(obj, [src] + HEADERS):
+            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -34,6 +34,7 @@ struct Bucket {
     int mclass = 0;
     uint32_t count = 0;
     uint32_t* d_idx = nullptr;   // nullptr: all sequences in natural order
+    std::vector<uint32_t> h_idx; // host copy of d_idx (empty with d_idx == nullptr)
     double work = 0;             // sum of M over the bucket (LDS instruction proxy)
 };
 
@@ -41,6 +42,18 @@ struct ExcK {                    // exceptions relevant at one model order
     uint64_t* d_off = nullptr;
     uint2* d_exc = nullptr;
     uint64_t count = 0;
+    // grouped kernel (grouped.hip): per-sequence record + what decides whether it applies
+    uint4* d_xrec = nullptr;
+    std::vector<uint8_t> h_cnt, h_span;   // exceptions of the sequence (capped at 255), last - first position
+};
+
+struct EmBucket {                // one kernel launch of an EM pass
+    int mclass = 0;
+    uint32_t count = 0;
+    const uint32_t* d_idx = nullptr;
+    bool grouped = false;        // k_em_grp instead of k_em_seq
+    uint32_t blocks = 0, logc = 0, sparse_cap = 0, sparse_bytes = 0;
+    double work = 0;
 };
 
 }  // namespace
@@ -77,7 +90,7 @@ struct bamm_seqs {
         (void)hipFree(d_len);
         (void)hipFree(d_pos_off);
         for (auto& b : buckets) (void)hipFree(b.d_idx);
-        for (auto& kv : exc_by_order) { (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc); }
+        for (auto& kv : exc_by_order) { (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc); (void)hipFree(kv.second.d_xrec); }
     }
 };
 
@@ -100,8 +113,8 @@ struct bamm_em {
     double* d_partial_stat = nullptr;
     float* h_status = nullptr;                  // pinned, 8 floats
     uint32_t total_blocks = 0;
-    std::vector<uint32_t> bucket_blocks;
-    std::vector<uint32_t> bucket_logc, bucket_sparse_cap, bucket_sparse_bytes;
+    std::vector<EmBucket> ebuckets;             // launches of one pass (length class x kernel flavour)
+    std::vector<uint32_t*> owned_idx;           // index lists made for this handle (capable / other split)
     uint32_t threads = 0;
     // column-sliced path (tables beyond the fused kernel's LDS budget)
     bool sliced = false;
@@ -145,6 +158,13 @@ SeqView make_view(const bamm_seqs* s, const ExcK* exc, const Bucket& b, const ui
     return v;
 }
 
+SeqView make_view(const bamm_seqs* s, const ExcK* exc, const EmBucket& b, const uint8_t* d_mask) {
+    Bucket t;
+    t.d_idx = const_cast<uint32_t*>(b.d_idx);
+    t.count = b.count;
+    return make_view(s, exc, t, d_mask);
+}
+
 // build (once per order) the list of positions whose kmer_ mod 4^(K+1) differs from what the
 // 2-bit stream gives
 int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
@@ -153,25 +173,48 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
     std::vector<uint64_t> off(s->n + 1, 0);
     std::vector<uint2> ex;
+    ExcK k;
+    k.h_cnt.assign(s->n, 0);
+    k.h_span.assign(s->n, 0);
+    // x = first position | span << 12 | count << 16; y/z/w hold up to 9 exceptions, 10 bits each
+    // (position - first | y << 4); only meaningful for the sequences the grouped kernel takes
+    std::vector<uint4> xrec(K <= 2u ? s->n : 0, make_uint4(0, 0, 0, 0));
     for (uint64_t n = 0; n < s->n; n++) {
         off[n] = ex.size();
         for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
             if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
                 ex.push_back(make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY));
+        const size_t cnt = ex.size() - off[n];
+        if (cnt) {
+            const uint32_t lo = ex[off[n]].x, span = ex.back().x - lo;
+            k.h_cnt[n] = (uint8_t)std::min<size_t>(cnt, 255);
+            k.h_span[n] = (uint8_t)std::min<uint32_t>(span, 255);
+            if (K <= 2u && cnt <= 9 && span <= 15u && lo < 4096u) {
+                uint32_t w3[3] = {0, 0, 0};
+                for (size_t i = 0; i < cnt; i++) {
+                    const uint2 x = ex[off[n] + i];
+                    w3[i / 3] |= ((x.x - lo) | (x.y << 4)) << (10u * (uint32_t)(i % 3));
+                }
+                xrec[n] = make_uint4(lo | (span << 12) | ((uint32_t)cnt << 16), w3[0], w3[1], w3[2]);
+            }
+        }
     }
     off[s->n] = ex.size();
-    ExcK k;
     k.count = ex.size();
     int rc = dev_upload(&k.d_off, off.data(), off.size(), s->ctx->stream);
     if (rc) return rc;
     rc = dev_upload(&k.d_exc, ex.data(), ex.size(), s->ctx->stream);
     if (rc) { (void)hipFree(k.d_off); return rc; }
-    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {   // host vectors go out of scope
+    if (!xrec.empty() && (rc = dev_upload(&k.d_xrec, xrec.data(), xrec.size(), s->ctx->stream))) {
         (void)hipFree(k.d_off); (void)hipFree(k.d_exc);
+        return rc;
+    }
+    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {   // host vectors go out of scope
+        (void)hipFree(k.d_off); (void)hipFree(k.d_exc); (void)hipFree(k.d_xrec);
         set_error("stream sync failed while uploading the exception list");
         return BAMM_ERR_HIP;
     }
-    auto ins = s->exc_by_order.emplace(K, k);
+    auto ins = s->exc_by_order.emplace(K, std::move(k));
     *out = &ins.first->second;
     return BAMM_OK;
 }
@@ -209,6 +252,27 @@ int record_event(bamm_em* em, bool start) {
     return BAMM_OK;
 }
 
+// one bucket through the fused kernel of its flavour (grouped columns or one column at a time)
+int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKernelArgs& a, uint32_t threads,
+                 hipStream_t st) {
+    if (!eb.grouped) {
+        a.logC = eb.logc;
+        a.sparse_cap = accum ? eb.sparse_cap : 0u;
+        a.sparse_wave_bytes = accum ? eb.sparse_bytes : 0u;
+        return launch_em_seq(eb.mclass, accum, write_r, a, eb.blocks, threads, st);
+    }
+    GrpKernelArgs ga{};
+    a.logC = eb.logc;
+    a.sparse_cap = 0; a.sparse_wave_bytes = 0;
+    ga.e = a;
+    ga.xrec = em->exc->d_xrec;
+    if (!grp_geometry(em->prm.K, em->prm.W, kMClasses[eb.mclass], threads / 64u, accum, accum ? eb.logc : 0u, &ga.g)) {
+        set_error("grouped kernel geometry does not fit (K=%u W=%u)", em->prm.K, em->prm.W);
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    return launch_em_grp(eb.mclass, accum, write_r, ga, eb.blocks, threads, st);
+}
+
 // local E(+M) pass over every length bucket, then the deterministic partial reduction
 int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
     bamm_seqs* s = em->seqs;
@@ -217,14 +281,12 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
     if (rc) return rc;
     if ((rc = record_event(em, true))) return rc;
     uint32_t block_base = 0;
-    for (size_t b = 0; b < s->buckets.size(); b++) {
-        const Bucket& bk = s->buckets[b];
+    for (size_t b = 0; b < em->ebuckets.size(); b++) {
+        const EmBucket& bk = em->ebuckets[b];
         EmKernelArgs a{};
         a.sv = make_view(s, em->exc, bk, em->d_mask);
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
-        a.logC = em->bucket_logc[b];
-        a.sparse_cap = accum ? em->bucket_sparse_cap[b] : 0u;
-        a.sparse_wave_bytes = accum ? em->bucket_sparse_bytes[b] : 0u;
+        a.logC = bk.logc;
         a.s = replay_last ? em->s_last : em->d_s;
         a.q = replay_last ? em->q_last : em->d_q;
         a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
@@ -232,19 +294,19 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
         a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
         const uint32_t threads = default_threads(em->ctx, bk.mclass);
         if (!em->sliced) {
-            rc = launch_em_seq(bk.mclass, accum, false, a, em->bucket_blocks[b], threads, st);
+            rc = launch_fused(em, bk, accum, false, a, threads, st);
         } else {
             a.r_out = em->d_state;
             for (size_t i = 0; i < em->e_slices.size() && !rc; i++)
                 rc = launch_e_slice(bk.mclass, a, em->e_slices[i].first, em->e_slices[i].second,
-                                    i + 1 == em->e_slices.size(), em->bucket_blocks[b], threads, st);
+                                    i + 1 == em->e_slices.size(), bk.blocks, threads, st);
             a.logC = em->m_slice_logc;
             for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
                 rc = launch_m_slice(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second,
-                                    em->bucket_blocks[b], threads, st);
+                                    bk.blocks, threads, st);
         }
         if (rc) return rc;
-        block_base += em->bucket_blocks[b];
+        block_base += bk.blocks;
     }
     rc = record_event(em, false);
     if (rc) return rc;
@@ -420,8 +482,10 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
         b.count = (uint32_t)members[mc].size();
         b.work = (double)b.count * kMClasses[mc];
         s->buckets.push_back(b);
-        if (used > 1)
+        if (used > 1) {
             if ((rc = dev_upload(&s->buckets.back().d_idx, members[mc].data(), members[mc].size(), c->stream))) return rc;
+            s->buckets.back().h_idx = std::move(members[mc]);
+        }
     }
     BAMM_HIP(hipStreamSynchronize(c->stream));
     s->hbm_bytes = (w1 - w0) * 4 + (s->n + 1) * 8 * 2 + s->n * 4;
@@ -457,6 +521,7 @@ int bamm_em_destroy(bamm_em* em) {
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
                     (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})
         (void)hipFree(p);
+    for (uint32_t* p : em->owned_idx) (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
     for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     bamm_seqs_destroy(em->seqs);
@@ -543,35 +608,83 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         return fail(BAMM_ERR_HIP);
     }
     memset(em->h_status, 0, 8 * sizeof(float));
-    // launch geometry: blocks split over the length buckets in proportion to their work
-    double total_work = 0;
-    for (auto& b : seqs->buckets) total_work += b.work;
-    em->total_blocks = 0;
+    // launches of one pass: every length bucket, split into the sequences the grouped-column kernel
+    // takes (no exception, or all of them within its virtual rows) and the rest
+    const bool want_grouped = !sliced && prm->K <= 2u && !getenv("BAMM_NO_GROUPED");
     for (auto& b : seqs->buckets) {
+        const int Mcls = kMClasses[b.mclass];
+        const uint32_t threads = default_threads(c, b.mclass);
+        GrpGeom gg{};
+        uint32_t glogc = UINT32_MAX;
+        if (want_grouped && grp_supported_class(Mcls, prm->K)) glogc = grp_pick_log_copies(prm->K, prm->W, Mcls, threads / 64u);
+        std::vector<uint32_t> yes, no;
+        if (glogc != UINT32_MAX && grp_geometry(prm->K, prm->W, Mcls, threads / 64u, true, glogc, &gg)) {
+            const ExcK* x = em->exc;
+            auto capable = [&](uint32_t n) { return x->h_cnt[n] == 0 || (x->h_cnt[n] <= 9 && (uint32_t)x->h_span[n] + gg.G <= gg.Bv); };
+            bool all = true;
+            for (uint32_t i = 0; i < b.count && all; i++) all = capable(b.d_idx ? b.h_idx[i] : i);
+            if (!all)
+                for (uint32_t i = 0; i < b.count; i++) {
+                    const uint32_t n = b.d_idx ? b.h_idx[i] : i;
+                    (capable(n) ? yes : no).push_back(n);
+                }
+            EmBucket eb;
+            eb.mclass = b.mclass; eb.grouped = true; eb.logc = glogc;
+            if (all) { eb.count = b.count; eb.d_idx = b.d_idx; }
+            else {
+                uint32_t* d = nullptr;
+                if ((rc = dev_upload(&d, yes.data(), yes.size(), st))) return fail(rc);
+                em->owned_idx.push_back(d);
+                eb.count = (uint32_t)yes.size(); eb.d_idx = d;
+            }
+            eb.work = (double)eb.count * Mcls * 0.6;       // grouped passes cost about 60 % per sequence
+            if (eb.count) em->ebuckets.push_back(eb);
+            if (all) continue;
+        }
+        EmBucket eb;
+        eb.mclass = b.mclass;
+        if (!no.empty()) {
+            uint32_t* d = nullptr;
+            if ((rc = dev_upload(&d, no.data(), no.size(), st))) return fail(rc);
+            em->owned_idx.push_back(d);
+            eb.count = (uint32_t)no.size(); eb.d_idx = d;
+        } else { eb.count = b.count; eb.d_idx = b.d_idx; }
+        eb.work = (double)eb.count * Mcls;
+        em->ebuckets.push_back(eb);
+    }
+    if (!em->owned_idx.empty() && hipStreamSynchronize(st) != hipSuccess) { set_error("stream sync failed"); return fail(BAMM_ERR_HIP); }
+    // launch geometry: blocks split over the launches in proportion to their work
+    double total_work = 0;
+    for (auto& b : em->ebuckets) total_work += b.work;
+    em->total_blocks = 0;
+    for (auto& b : em->ebuckets) {
         const uint32_t threads = default_threads(c, b.mclass);
         // 16 waves per CU saturate the LDS pipe (tools/lds_bench2.hip); the LDS left over goes
         // into private copies of the count table
         const uint32_t blocks_per_cu = sliced ? 1u : std::max(1u, 1024u / threads);
-        // sparse M-step scratch (per wave) competes with the private copies for LDS; it is only
-        // enabled when at least 4 copies survive next to it
-        const int Mcls = kMClasses[b.mclass];
-        size_t scratch = sliced ? 0 : sparse_wave_bytes(Mcls) * (threads / 64u);
-        uint32_t cap = sliced ? 0u : sparse_cap_for(Mcls);
-        if (getenv("BAMM_NO_SPARSE")) { cap = 0; scratch = 0; }
-        if (cap && (em_lds_bytes(prm->W, Y, true, 0, scratch) > kLds / blocks_per_cu ||
-                    pick_log_copies(prm->W, Y, blocks_per_cu, scratch) + 1 < pick_log_copies(prm->W, Y, blocks_per_cu, 0))) {
-            cap = 0;
-            scratch = 0;
+        if (!b.grouped) {
+            // sparse M-step scratch (per wave) competes with the private copies for LDS; it is only
+            // enabled when at least 4 copies survive next to it
+            const int Mcls = kMClasses[b.mclass];
+            size_t scratch = sliced ? 0 : sparse_wave_bytes(Mcls) * (threads / 64u);
+            uint32_t cap = sliced ? 0u : sparse_cap_for(Mcls);
+            if (getenv("BAMM_NO_SPARSE")) { cap = 0; scratch = 0; }
+            if (cap && (em_lds_bytes(prm->W, Y, true, 0, scratch) > kLds / blocks_per_cu ||
+                        pick_log_copies(prm->W, Y, blocks_per_cu, scratch) + 1 < pick_log_copies(prm->W, Y, blocks_per_cu, 0))) {
+                cap = 0;
+                scratch = 0;
+            }
+            b.sparse_cap = cap;
+            b.sparse_bytes = (uint32_t)(cap ? sparse_wave_bytes(Mcls) : 0);
+            b.logc = sliced ? 0u : pick_log_copies(prm->W, Y, blocks_per_cu, scratch);
         }
-        em->bucket_sparse_cap.push_back(cap);
-        em->bucket_sparse_bytes.push_back((uint32_t)(cap ? sparse_wave_bytes(Mcls) : 0));
-        em->bucket_logc.push_back(sliced ? 0u : pick_log_copies(prm->W, Y, blocks_per_cu, scratch));
-        const uint32_t all = c->blocks ? c->blocks : (uint32_t)std::max(1, c->num_cus) * blocks_per_cu;
+        const uint32_t per_cu = b.grouped ? 1u : blocks_per_cu;
+        const uint32_t all = c->blocks ? c->blocks : (uint32_t)std::max(1, c->num_cus) * per_cu;
         uint32_t nb = (uint32_t)std::max(1.0, std::floor(all * (b.work / total_work) + 0.5));
         const uint32_t waves_per_block = threads / 64u;
         nb = std::min(nb, (b.count + waves_per_block - 1) / waves_per_block);
         nb = std::max(nb, 1u);
-        em->bucket_blocks.push_back(nb);
+        b.blocks = nb;
         em->total_blocks += nb;
     }
     if ((rc = dev_alloc(&em->d_partial_n, (size_t)em->total_blocks * em->cells))) return fail(rc);
@@ -914,17 +1027,17 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
     double* d_stat = nullptr;
     BAMM_HIP(hipMemsetAsync(d_r, 0, total * sizeof(float), st));
     uint32_t maxb = 0;
-    for (uint32_t nb : em->bucket_blocks) maxb = std::max(maxb, nb);
+    for (auto& eb : em->ebuckets) maxb = std::max(maxb, eb.blocks);
     if ((rc = dev_alloc(&d_stat, (size_t)maxb * 4))) { (void)hipFree(d_r); return rc; }
-    for (size_t b = 0; b < s->buckets.size() && !rc; b++) {
-        const Bucket& bk = s->buckets[b];
+    for (size_t b = 0; b < em->ebuckets.size() && !rc; b++) {
+        const EmBucket& bk = em->ebuckets[b];
         EmKernelArgs a{};
         a.sv = make_view(s, em->exc, bk, nullptr);        // masked-out sequences still have an r in the reference
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
         a.s = em->s_last; a.q = em->q_last;                 // the E pass the caller last ran (EM.cpp:521)
         a.partial_n = nullptr; a.partial_stat = d_stat;
         a.r_out = d_r; a.r_base = base; a.seq_begin = (uint32_t)begin; a.seq_end = (uint32_t)end;
-        rc = launch_em_seq(bk.mclass, false, true, a, em->bucket_blocks[b], default_threads(em->ctx, bk.mclass), st);
+        rc = launch_fused(em, bk, false, true, a, default_threads(em->ctx, bk.mclass), st);
     }
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d_r, total * sizeof(float), hipMemcpyDeviceToHost, st);

@@ -1,0 +1,197 @@
+// Device-side helpers shared by the sequence kernels (kernels.hip, grouped.hip): DPP wave shifts,
+// the 2^-40 fixed-point conversion, hand-issued LDS gathers / predicated LDS adds and the 2-bit
+// sequence decode.  Everything is `__device__ __forceinline__` in an anonymous namespace.
+#pragma once
+#include "common.h"
+
+namespace bamm {
+namespace {
+
+// ---- cross-lane helpers ------------------------------------------------------------------
+// DPP wave shifts exist on the GFX9 family (incl. gfx950).  `oldv` is what lane 0 keeps.
+__device__ __forceinline__ float wave_shr1(float oldv, float x) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
+                                           0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x) {   // lane 63 receives 0
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x & 0xffffffffull), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), 0x130, 0xf, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// r in [0,1] -> round(r * 2^40); exact integer accumulation up to 2^24 sequences per block
+__device__ __forceinline__ unsigned long long to_fixed40(float r) {
+    // exact power-of-two scalings and an exact split; the last unit (2^-40) is truncated
+    const float a = r * 256.0f;
+    const float hi_f = floorf(a);
+    const uint32_t hi = (uint32_t)hi_f;
+    const uint32_t lo = (uint32_t)((a - hi_f) * 4294967296.0f);
+    return ((unsigned long long)hi << 32) | lo;
+}
+constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
+// 128-bit LDS gather.  hipcc splits a float4 LDS load whose components are consumed under
+// different (even wave-uniform) conditions into b32/b64 pieces, which costs 2-4x the LDS cycles
+// (tools/lds_bench2.hip), so the read is issued by hand; lds_wait() retires all of them and
+// ties the results to the wait so that no consumer can be scheduled above it.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ f32x4 lds_read_b128(uint32_t byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+template <int M>
+__device__ __forceinline__ void lds_wait(f32x4 (&v)[M]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+#pragma unroll
+    for (int m = 1; m < M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
+}
+
+// One predicated 64-bit LDS add: exec <- pad & nz (both wave masks in SGPR pairs), ds_add_u64,
+// exec <- all lanes.  Replaces the compiler's v_cmp_u64 / s_nor / s_and_saveexec / s_or sequence
+// per atomic; valid because the call sites run with every lane of the wave active.  The adds are
+// fire-and-forget (no return): lds_drain() must run before anyone reads the table.
+__device__ __forceinline__ void lds_add_u64_masked(uint32_t byte_addr, unsigned long long v,
+                                                   unsigned long long pad_mask, unsigned long long nz_mask) {
+    asm volatile("s_and_b64 exec, %2, %3\n\tds_add_u64 %0, %1\n\ts_mov_b64 exec, -1"
+                 :: "v"(byte_addr), "v"(v), "s"(pad_mask), "s"(nz_mask) : "memory");
+}
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// One slot of one column.  The long-sequence classes (M > 16) keep 2*M wave masks, more than the
+// SGPR file holds; there the predication is left to the compiler (hipcc's spill code around the
+// hand-written exec sequence miscounted at M = 28).
+template <int M>
+__device__ __forceinline__ void lds_add_slot(uint32_t byte_addr, unsigned long long v, unsigned long long pad_mask,
+                                             unsigned long long nz_mask, bool pad_ok) {
+    if constexpr (M <= 16) {
+        lds_add_u64_masked(byte_addr, v, pad_mask, nz_mask);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+        if (pad_ok && v != 0ull) atomicAdd((unsigned long long*)(lds_u64*)(size_t)byte_addr, v);
+#endif
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+// sum over the 64 lanes without touching the LDS pipe: rotate-adds inside each row of 16 lanes
+// (row_ror:8/4/2/1), then the four row sums through SGPRs.  Same value in every lane.
+__device__ __forceinline__ float wave_sum(float x) {
+    x += dpp_f<0x128>(x);
+    x += dpp_f<0x124>(x);
+    x += dpp_f<0x122>(x);
+    x += dpp_f<0x121>(x);
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+// ---- sequence decode: M consecutive positions of one sequence into registers -------------
+// y[m] = kmer_[p] mod Y for p = lane*M+m (Sequence.cpp:35-41), PAD (= Y) where p >= limit.
+template <int M>
+__device__ __forceinline__ void decode_positions(const SeqView& sv, uint32_t seq, uint32_t L,
+                                                 uint32_t Y, uint32_t limit, int lane, uint32_t (&y)[M]) {
+    constexpr int NSEL = (M + 14) / 16 + 1;  // candidate words per position
+    const uint32_t* wp = sv.words + sv.word_off[seq];
+    const uint32_t nw = (L + 15u) >> 4;
+    const uint32_t p0 = (uint32_t)lane * M;
+    const uint32_t wi0 = p0 >> 4;
+    uint32_t w[NSEL + 1];  // w[0] = word wi0-1, w[1] = word wi0, ...
+    w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+    for (int i = 0; i < NSEL; i++) w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const uint32_t p = p0 + m;
+        const uint32_t sel = (p >> 4) - wi0;
+        uint32_t lo = w[1], hi = w[0];
+#pragma unroll
+        for (int c = 1; c < NSEL; c++) {
+            lo = (sel == (uint32_t)c) ? w[c + 1] : lo;
+            hi = (sel == (uint32_t)c) ? w[c] : hi;
+        }
+        const uint32_t sh = 30u - 2u * (p & 15u);
+        y[m] = __builtin_amdgcn_alignbit(hi, lo, sh) & (Y - 1u);
+    }
+    // positions whose k-mer the 2-bit stream cannot express (N randomisation, Sequence.cpp:38)
+    const uint64_t e0 = sv.exc_off[seq], e1 = sv.exc_off[seq + 1];
+    for (uint64_t e = e0; e < e1; e++) {
+        const uint2 x = sv.exc[e];
+        const int mm = (int)x.x - (int)p0;
+#pragma unroll
+        for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) y[m] = (p0 + m < limit) ? y[m] : Y;
+}
+
+__device__ __forceinline__ uint32_t pick_sequence(const SeqView& sv, uint32_t t) {
+    return sv.idx ? sv.idx[t] : t;
+}
+
+// The same decode split in two so that the HBM loads of sequence t+1 are in flight while
+// sequence t is being processed (a wave owns one sequence at a time; without this every
+// sequence starts with a chain of dependent global loads).
+template <int M>
+struct RawSeq {
+    static constexpr int NSEL = (M + 14) / 16 + 1;
+    uint32_t seq, L;
+    uint32_t w[NSEL + 1];
+    uint64_t e0, e1;
+    bool ok;
+};
+template <int M>
+__device__ __forceinline__ RawSeq<M> fetch_seq(const SeqView& sv, uint32_t t, int lane) {
+    RawSeq<M> r;
+    r.seq = pick_sequence(sv, t);
+    r.ok = !(sv.mask && !sv.mask[r.seq]);
+    r.L = sv.len[r.seq];
+    const uint32_t* wp = sv.words + sv.word_off[r.seq];
+    const uint32_t nw = (r.L + 15u) >> 4;
+    const uint32_t wi0 = ((uint32_t)lane * M) >> 4;
+    r.w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+    for (int i = 0; i < RawSeq<M>::NSEL; i++) r.w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+    r.e0 = sv.exc_off[r.seq];
+    r.e1 = sv.exc_off[r.seq + 1];
+    return r;
+}
+template <int M>
+__device__ __forceinline__ void decode_raw(const RawSeq<M>& r, const SeqView& sv, uint32_t Y, uint32_t limit, int lane,
+                                           uint32_t (&y)[M]) {
+    constexpr int NSEL = RawSeq<M>::NSEL;
+    const uint32_t p0 = (uint32_t)lane * M;
+    const uint32_t wi0 = p0 >> 4;
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+        const uint32_t p = p0 + m;
+        const uint32_t sel = (p >> 4) - wi0;
+        uint32_t lo = r.w[1], hi = r.w[0];
+#pragma unroll
+        for (int c = 1; c < NSEL; c++) {
+            lo = (sel == (uint32_t)c) ? r.w[c + 1] : lo;
+            hi = (sel == (uint32_t)c) ? r.w[c] : hi;
+        }
+        const uint32_t sh = 30u - 2u * (p & 15u);
+        y[m] = __builtin_amdgcn_alignbit(hi, lo, sh) & (Y - 1u);
+    }
+    for (uint64_t e = r.e0; e < r.e1; e++) {             // N exceptions (Sequence.cpp:38)
+        const uint2 x = sv.exc[e];
+        const int mm = (int)x.x - (int)p0;
+#pragma unroll
+        for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) y[m] = (p0 + m < limit) ? y[m] : Y;
+}
+
+}  // namespace
+}  // namespace bamm

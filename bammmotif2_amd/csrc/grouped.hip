@@ -1,0 +1,530 @@
+// gfx950 kernel of the fused EM pass with GROUPED motif columns (orders K <= 2).
+//
+// Same computation as k_em_seq (kernels.hip): EM::EStep refinement/EM.cpp:149-196, EM::MStep
+// EM.cpp:231-243 and the sum over r of EM.cpp:509-513 -- file:line relative to /root/reference/src.
+//
+// k_em_seq is bound by the LDS pipe: per (position, column) one odds-table gather and one count
+// add.  Here G = 4-K neighbouring columns share ONE table row: the row index of position p is the
+// (K+G)-mer ending at p (256 rows), the table entry of group t is the product of its G column
+// odds, so a window costs T = ceil(W/G) gathers / adds instead of W:
+//
+//   U_t(p) = U_{t-1}(p-G) * sG[t][row(p)],      row(p) = kmer_[p] mod 4^(K+G)
+//   nG[t][row(p)] += r(window)                  (marginalised to n[j][y] once per block)
+//
+// What keeps this exact:
+//   * EM.cpp:167 truncation (positions >= L-W+1 take no part): a group cut by that edge reads a
+//     "partial" row that only carries its leading columns; beyond it the neutral row.
+//   * N randomisation (Sequence.cpp:38): next to an exception the k-mers of neighbouring positions
+//     disagree, so no (K+G)-mer describes the group.  Those group ends (a handful per sequence:
+//     the strand junction) get per-wave VIRTUAL rows: a few "fix" lanes compute their G-column
+//     products from the single-column table before the chain starts, and after the M-step move
+//     what the virtual count rows collected into single-column bins.  The chain itself never
+//     sees an exception.  Sequences whose exceptions span more than the virtual rows go through
+//     k_em_seq instead (bamm_em_create splits the buckets).
+//   * counts are 64-bit fixed point (2^-40) as in k_em_seq: sums are exact and order-free, so the
+//     result is bit-identical to k_em_seq's for the same responsibilities.
+// Window products are rounded in a different order than the reference's left-to-right product
+// (pairs first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
+
+#include "device_utils.h"
+
+#include <algorithm>
+
+namespace bamm {
+namespace {
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // DS operations of one wave retire in order; this only pins the compiler's ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
+    asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %0, %1\n\ts_mov_b64 exec, -1"
+                 :: "v"(byte_addr), "v"(v), "s"(mask) : "memory");
+}
+
+template <int M>
+struct RawSeqG {
+    static constexpr int NSEL = (M + 14) / 16 + 1;
+    uint32_t seq, L;
+    uint32_t w[NSEL + 1];
+    uint4 xr;
+    bool ok;
+};
+
+template <int M>
+__device__ __forceinline__ RawSeqG<M> fetch_seq_g(const SeqView& sv, const uint4* xrec, uint32_t t, int lane) {
+    RawSeqG<M> r;
+    r.seq = pick_sequence(sv, t);
+    r.ok = !(sv.mask && !sv.mask[r.seq]);
+    r.L = sv.len[r.seq];
+    r.xr = xrec[r.seq];
+    const uint32_t* wp = sv.words + sv.word_off[r.seq];
+    const uint32_t nw = (r.L + 15u) >> 4;
+    const uint32_t wi0 = ((uint32_t)lane * M) >> 4;
+    r.w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+    for (int i = 0; i < RawSeqG<M>::NSEL; i++) r.w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+    return r;
+}
+
+template <int M, int G, bool ACCUM, bool WRITE_R, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
+    static_assert(M >= G, "a group must not span more than two lanes");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const EmKernelArgs& a = ga.e;
+    const GrpGeom& g = ga.g;
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
+    const uint32_t T = g.T, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
+    float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Tq][Rtot][4]
+    float* s1 = reinterpret_cast<float*>(lds_raw + g.off_s1);                             // [W][Y+1]
+    double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
+    unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);   // [T][Rtot][C]
+    unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]
+    const uint32_t logC = ACCUM ? a.logC : 0u;
+
+    // ---- block prologue: single-column table, grouped table, zeroed counts
+    for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < T * (Rn + 1u); i += blockDim.x) {
+        const uint32_t t = i / (Rn + 1u), row = i - t * (Rn + 1u);
+        uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
+        if (row < g.Rf) { nreal = G; code = row; }
+#pragma unroll
+        for (int d = 0; d < G - 1; d++)
+            if (row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = G - 1 - d; code = row - g.base[d]; }
+        float f = 1.0f;
+#pragma unroll
+        for (int c = 0; c < G; c++) {
+            const int col = (int)(G * t + c) - (int)delta;
+            if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + ((code >> (2u * (nreal - 1u - c))) & (Y - 1u))];
+        }
+        sg[((t >> 2) * Rtot + row) * 4u + (t & 3u)] = f;
+    }
+    if (ACCUM) {
+        for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const float q = *a.q;
+    const float one_minus_q = 1.0f - q;
+    const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
+    const uint32_t vbase = g.R0 + wave * g.Bv;
+    unsigned char* wscratch = lds_raw + g.off_wave + (size_t)wave * g.wave_bytes;
+    unsigned char* ybuf = wscratch;                                                      // [32] bytes
+    const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+    const uint32_t strideT = (Rtot << logC) * 8u;
+
+    double llh_acc = 0.0, sumr_acc = 0.0;
+    uint32_t seq_cnt = 0;
+
+    uint32_t t = blockIdx.x * waves_per_block + wave;
+    RawSeqG<M> nxt{};
+    if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
+    for (; t < a.sv.count; t += total_waves) {
+        const RawSeqG<M> cur = nxt;
+        if (t + total_waves < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t + total_waves, lane);   // prefetch
+        const uint32_t seq = cur.seq;
+        if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
+        if (!cur.ok) continue;
+        const uint32_t L = cur.L;
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+
+        // ---- row index of every position
+        uint32_t row[M];
+        {
+            constexpr int NSEL = RawSeqG<M>::NSEL;
+            const uint32_t wi0 = p0 >> 4;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                const uint32_t sel = (p >> 4) - wi0;
+                uint32_t lo = cur.w[1], hi = cur.w[0];
+#pragma unroll
+                for (int c = 1; c < NSEL; c++) {
+                    lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
+                    hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
+                }
+                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (p & 15u));   // kmer_[p] mod 4^16
+                uint32_t r = v & (g.Rf - 1u);
+                if (p >= LW1) {                              // EM.cpp:167: positions >= LW1 take no part
+                    r = Rn;
+                    const uint32_t d = p - LW1;
+#pragma unroll
+                    for (int dd = 0; dd < G - 1; dd++)
+                        if (d == (uint32_t)dd && p < L) r = g.base[dd] + ((v >> (2u * (dd + 1))) & (g.psize[dd] - 1u));
+                }
+                row[m] = r;
+            }
+        }
+
+        // ---- exceptions (Sequence.cpp:38): virtual rows for the group ends next to them
+        const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
+        const uint32_t E = xw >> 16;
+        const uint32_t xlo = xw & 0xfffu;
+        uint32_t B = 0;
+        uint32_t yfix[G];
+#pragma unroll
+        for (int c = 0; c < G; c++) yfix[c] = Y;
+        bool fix = false;
+        if (E != 0u) {
+            const uint32_t span = (xw >> 12) & 0xfu;
+            const uint32_t hiB = min(xlo + span + (uint32_t)(G - 1), L - 1u);
+            B = hiB - xlo + 1u;
+            // exact y of the positions [lo-G+1, hiB] -> ybuf[p + G-1 - lo]
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t k = p0 + m + (uint32_t)(G - 1) - xlo;
+                if (k < B + (uint32_t)(G - 1)) ybuf[k] = (unsigned char)((p0 + m < LW1) ? (row[m] & (Y - 1u)) : Y);
+            }
+            wave_lds_sync();
+            if ((uint32_t)lane < E) {
+                const uint32_t word = (lane < 3) ? cur.xr.y : ((lane < 6) ? cur.xr.z : cur.xr.w);
+                const uint32_t e = (word >> (10u * ((uint32_t)lane % 3u))) & 0x3ffu;
+                const uint32_t dpos = e & 15u;
+                if (xlo + dpos < LW1) ybuf[dpos + (uint32_t)(G - 1)] = (unsigned char)(e >> 4);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t k2 = p0 + m - xlo;
+                if (k2 < B) row[m] = vbase + k2;
+            }
+            fix = lane_b < B;
+            if (fix) {
+                float f = 1.0f;
+#pragma unroll
+                for (int c = 0; c < G; c++) {
+                    const int col = (int)(G * lane_t + c) - (int)delta;
+                    const int pos = (int)(xlo + lane_b) - (G - 1) + c;
+                    uint32_t yc = Y;
+                    if (col >= 0 && pos >= 0) yc = ybuf[lane_b + c];
+                    yfix[c] = yc;
+                    if (yc != Y) f *= s1[(uint32_t)col * Ys + yc];
+                }
+                sg[((lane_t >> 2) * Rtot + vbase + lane_b) * 4u + (lane_t & 3u)] = f;
+            }
+            wave_lds_sync();
+        }
+
+        // ---- E-step: slot p after group t holds the product of groups 0..t of the window whose
+        // group t ends at p (EM.cpp:167-176); after the last group that is window p-(W-1)
+        float U[M];
+        {
+            uint32_t ra[M];
+            const uint32_t sg_base = lds_offset(sg);
+#pragma unroll
+            for (int m = 0; m < M; m++) ra[m] = sg_base + row[m] * 16u;
+            for (uint32_t jq = 0; jq < Tq; jq++) {
+                f32x4 sv[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m]);
+#pragma unroll
+                for (int m = 0; m < M; m++) ra[m] += Rtot * 16u;
+                lds_wait<M>(sv);
+#define BAMM_GRP_STEP(COMP, TT)                                                        \
+                if ((TT) < T) {                                                        \
+                    float cy[G];                                                       \
+                    _Pragma("unroll") for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]); \
+                    _Pragma("unroll") for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * sv[m].COMP;      \
+                    _Pragma("unroll") for (int m = 0; m < G; m++) U[m] = cy[m] * sv[m].COMP;              \
+                }
+                if (jq == 0) {
+#pragma unroll
+                    for (int m = 0; m < M; m++) U[m] = sv[m].x;             // group 0 starts the chain
+                } else {
+                    BAMM_GRP_STEP(x, jq * 4u)
+                }
+                BAMM_GRP_STEP(y, jq * 4u + 1u)
+                BAMM_GRP_STEP(z, jq * 4u + 2u)
+                BAMM_GRP_STEP(w, jq * 4u + 3u)
+#undef BAMM_GRP_STEP
+            }
+        }
+        const float pos_i = q / (float)LW1;              // EM.cpp:160
+        float zpart = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t p = p0 + m;
+            const bool valid = (p + 1u >= W) && (p < L);
+            U[m] = valid ? U[m] * pos_i : 0.0f;          // EM.cpp:180
+            zpart += U[m];
+        }
+        const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
+        const float invZ = 1.0f / Z;
+#pragma unroll
+        for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187
+        llh_acc += (double)logf(Z);                      // EM.cpp:195
+        sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
+        seq_cnt++;
+
+        if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
+            float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                if (p < L) ro[L - 1u - p] = U[m];
+            }
+        }
+
+        if (ACCUM) {
+            // ---- M-step (EM.cpp:236-242), grouped: at group t slot p holds r of the window whose
+            // group t ends at p; it goes to nG[t][row(p)].  The neutral row is a sink nobody reads.
+            unsigned long long F[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
+            const uint32_t ng_base = lds_offset(ng);
+
+            bool dense = true;
+            if (g.cap != 0u) {
+                uint32_t nnz = 0, lpos[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const unsigned long long mask = __ballot(F[m] != 0ull);
+                    lpos[m] = nnz + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    nnz += (uint32_t)__popcll(mask);
+                }
+                if (nnz <= g.cap) {
+                    dense = false;
+                    const uint32_t cap = g.cap;
+                    unsigned long long* listF = reinterpret_cast<unsigned long long*>(wscratch + 32);
+                    unsigned short* listP = reinterpret_cast<unsigned short*>(listF + cap);
+                    unsigned short* rowbuf = listP + cap;
+#pragma unroll
+                    for (int m = 0; m < M; m++) {
+                        if (F[m] != 0ull) { listF[lpos[m]] = F[m]; listP[lpos[m]] = (unsigned short)(p0 + m); }
+                        rowbuf[p0 + m] = (unsigned short)row[m];
+                    }
+                    wave_lds_sync();
+                    const uint32_t ecnt = (nnz + 63u) >> 6;
+                    for (uint32_t e = 0; e < ecnt; e++) {
+                        const uint32_t idx = e * 64u + (uint32_t)lane;
+                        const bool ok = idx < nnz;
+                        const unsigned long long Fe = ok ? listF[idx] : 0ull;
+                        // first group ends at i - delta + G-1 with i = slot - (W-1)
+                        const uint32_t pe = ok ? (uint32_t)listP[idx] + (uint32_t)(G - 1) - delta - (W - 1u) : 0u;
+                        const unsigned short* rp = rowbuf + pe;
+                        unsigned long long* colp = ng + copy;
+                        for (uint32_t tb = 0; tb < T; tb += 5u) {
+                            uint32_t rr[5];
+#pragma unroll
+                            for (int u = 0; u < 5; u++) rr[u] = (tb + u < T) ? (uint32_t)rp[(tb + u) * G] : Rn;
+#pragma unroll
+                            for (int u = 0; u < 5; u++) {
+                                if (tb + u < T) {
+                                    if (ok) atomicAdd(&colp[rr[u] << logC], Fe);
+                                    colp += Rtot << logC;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (dense) {
+                unsigned long long nz[M];
+                uint32_t rad[M];                             // byte offset of (row, private copy) inside a group table
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
+                    rad[m] = ((row[m] << logC) + copy) * 8u;
+                }
+                uint32_t col = ng_base + (T - 1u) * strideT;
+                // F is a ring: after s steps logical slot m lives in F[(m + G*s) mod M]; the G slots
+                // that arrive from the next lane are shifted in place with one DPP pair each
+                for (uint32_t sb = 0; sb < T; sb += M) {
+#pragma unroll
+                    for (int u = 0; u < M; u++) {
+                        if (sb + u < T) {
+                            const int off = (G * u) % M;
+#pragma unroll
+                            for (int m = 0; m < M; m++)
+                                lds_add_u64_exec(col + rad[m], F[(m + off) % M], nz[(m + off) % M]);
+#pragma unroll
+                            for (int c = 0; c < G; c++) {
+                                const int idx = (M - G + c + G * (u + 1)) % M;
+                                F[idx] = wave_shl1_u64(F[idx]);
+                                nz[idx] = __ballot(F[idx] != 0ull);
+                            }
+                            col -= strideT;
+                        }
+                    }
+                }
+            }
+            // ---- virtual count rows -> single-column bins (exact: one window per cell)
+            if (E != 0u) {
+                wave_lds_sync();
+                if (fix) {
+                    unsigned long long acc = 0ull;
+                    unsigned long long* cell = ng + (((size_t)lane_t * Rtot + vbase + lane_b) << logC);
+                    for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[c]; cell[c] = 0ull; }
+                    if (acc != 0ull) {
+#pragma unroll
+                        for (int c = 0; c < G; c++) {
+                            const int col = (int)(G * lane_t + c) - (int)delta;
+                            if (yfix[c] != Y) atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+
+    // ---- block epilogue: marginalise the grouped counts to n[j][y], statistics
+    lds_drain();
+    if (lane == 0) {
+        stat_lds[wave * 3 + 0] = llh_acc;
+        stat_lds[wave * 3 + 1] = sumr_acc;
+        stat_lds[wave * 3 + 2] = (double)seq_cnt;
+    }
+    __syncthreads();
+    if (ACCUM) {
+        unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
+        const uint32_t C = 1u << logC;
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) {
+            const uint32_t j = i / Y, yy = i - j * Y;
+            const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
+            unsigned long long acc = n1[i];
+            const unsigned long long* tab = ng + (((size_t)t * Rtot) << logC);
+            // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free
+            {
+                const uint32_t lowd = 2u * ((uint32_t)G - 1u - c);
+                for (uint32_t h = 0; h < (1u << (2u * c)); h++)
+                    for (uint32_t l = 0; l < (1u << lowd); l++) {
+                        const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
+                        // h digits above y overlap y's own upper digits unless c digits are really free:
+                        // the (K+G)-mer has exactly c digits above y_c, so the mask above is a no-op
+                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[((size_t)row << logC) + cc];
+                    }
+            }
+#pragma unroll
+            for (int d = 0; d < G - 1; d++) {                // partial rows: positions c < G-1-d are real
+                const uint32_t nreal = (uint32_t)(G - 1 - d);
+                if (c < nreal) {
+                    const uint32_t lowd = 2u * (nreal - 1u - c);
+                    for (uint32_t h = 0; h < (1u << (2u * c)); h++)
+                        for (uint32_t l = 0; l < (1u << lowd); l++) {
+                            const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
+                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[((size_t)row << logC) + cc];
+                        }
+                }
+            }
+            out[i] = acc;
+        }
+    }
+    if (threadIdx.x < 3) {
+        double acc = 0.0;
+        for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
+        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+    }
+}
+
+template <int M, int G, int THREADS>
+void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
+    const size_t lds = a.g.lds_bytes;
+    if (write_r) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, false, true, THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_em_grp<M, G, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    } else if (accum) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, true, false, THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_em_grp<M, G, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, false, false, THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_em_grp<M, G, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    }
+}
+
+}  // namespace
+
+// length classes the grouped kernel is instantiated for: 4..16 positions per lane (M >= G)
+bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 4 && M <= 16; }
+
+uint32_t grp_sparse_cap(int M) { return (uint32_t)std::min(192, 64 * M); }
+
+bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out) {
+    if (K > 2u || W == 0u) return false;
+    GrpGeom g{};
+    g.G = 4u - K;
+    g.T = (W + g.G - 1u) / g.G;
+    if (g.T > 64u) return false;
+    g.Tq = (g.T + 3u) / 4u;
+    g.delta = g.G * g.T - W;
+    g.Rf = 1u << (2u * (K + g.G));
+    uint32_t r = g.Rf;
+    for (uint32_t d = 0; d + 1u < g.G; d++) {
+        g.base[d] = r;
+        g.psize[d] = 1u << (2u * (K + g.G - 1u - d));
+        r += g.psize[d];
+    }
+    g.Rn = r;
+    g.R0 = r + 1u;
+    g.Bv = std::min(8u, 64u / g.T);
+    if (g.Bv < g.G) return false;
+    g.Rtot = g.R0 + waves * g.Bv;
+    const uint32_t Y = 1u << (2u * (K + 1u));
+    auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
+    uint32_t off = 0;
+    g.off_sg = off; off = up16(off + g.Tq * g.Rtot * 16u);
+    g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
+    g.off_stat = off; off = up16(off + 16u * 3u * 8u);
+    g.off_ng = off;
+    if (accum) off = up16(off + ((g.T * g.Rtot) << logC) * 8u);
+    g.off_n1 = off;
+    if (accum) off = up16(off + W * Y * 8u);
+    g.off_wave = off;
+    g.cap = accum ? grp_sparse_cap(M) : 0u;
+    g.wave_bytes = up16(32u + (accum ? g.cap * 8u + g.cap * 2u + 64u * (uint32_t)M * 2u : 0u));
+    off += waves * g.wave_bytes;
+    g.lds_bytes = off;
+    *out = g;
+    return off <= 160u * 1024u;
+}
+
+uint32_t grp_pick_log_copies(uint32_t K, uint32_t W, int M, uint32_t waves) {
+    GrpGeom g;
+    uint32_t best = UINT32_MAX;
+    for (uint32_t lc = 0; lc <= 3u; lc++)
+        if (grp_geometry(K, W, M, waves, true, lc, &g)) best = lc;
+    return best;
+}
+
+#define BAMM_FOR_EACH_GCLASS(X) \
+    X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) X(7, 8, 1024) X(8, 10, 512) X(9, 12, 512) X(10, 14, 512) X(11, 16, 512)
+
+int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
+                  hipStream_t st) {
+    if (a.g.lds_bytes > 160u * 1024u || blocks == 0 || (threads & 63u) || threads == 0 ||
+        threads > max_threads_for_mclass(mclass)) {
+        set_error("bad launch of the grouped kernel (%u x %u, %u bytes of LDS)", blocks, threads, a.g.lds_bytes);
+        return BAMM_ERR_ARG;
+    }
+    switch (mclass * 8 + (int)a.g.G) {
+#define X(idx, M, T)                                                                              \
+    case idx * 8 + 2: launch_variant<M, 2, T>(accum, write_r, a, blocks, threads, st); break;     \
+    case idx * 8 + 3: launch_variant<M, 3, T>(accum, write_r, a, blocks, threads, st); break;     \
+    case idx * 8 + 4: launch_variant<M, 4, T>(accum, write_r, a, blocks, threads, st); break;
+        BAMM_FOR_EACH_GCLASS(X)
+#undef X
+        default:
+            set_error("no grouped kernel for M class %d, G=%u", mclass, a.g.G);
+            return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+}  // namespace bamm
