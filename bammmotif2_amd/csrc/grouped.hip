@@ -29,6 +29,7 @@
 #include "device_utils.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace bamm {
 namespace {
@@ -43,6 +44,21 @@ __device__ __forceinline__ void wave_lds_sync() {
 __device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
     asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %0, %1\n\ts_mov_b64 exec, -1"
                  :: "v"(byte_addr), "v"(v), "s"(mask) : "memory");
+}
+
+__device__ __forceinline__ void lds_add_u64_plain(uint32_t byte_addr, unsigned long long v) {
+    asm volatile("ds_add_u64 %0, %1" :: "v"(byte_addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_read_u16(uint32_t byte_addr) {
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(byte_addr));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_u32(uint32_t (&v)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+#pragma unroll
+    for (int i = 1; i < N; i++) asm volatile("" : "+v"(v[i]) : "v"(v[0]));
 }
 
 template <int M>
@@ -134,7 +150,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const uint32_t seq = cur.seq;
         if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
         if (!cur.ok) continue;
-        const uint32_t L = cur.L;
+        const uint32_t L = __builtin_amdgcn_readfirstlane(cur.L);   // one sequence per wave: uniform
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
 
@@ -143,26 +159,57 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         {
             constexpr int NSEL = RawSeqG<M>::NSEL;
             const uint32_t wi0 = p0 >> 4;
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const uint32_t p = p0 + m;
-                const uint32_t sel = (p >> 4) - wi0;
+            // bits a position needs: its (K+G)-mer, shifted by up to G-1 digits for a partial row
+            constexpr bool kOneWindow = 2 * (M - 1) + 8 + 2 * (G - 1) <= 32;
+            if constexpr (kOneWindow) {
+                // one 32-bit window of the stream ending at the lane's LAST position; position p0+m
+                // is that window shifted by a compile-time 2*(M-1-m) bits
+                const uint32_t pe = p0 + (uint32_t)(M - 1);
+                const uint32_t sel = (pe >> 4) - wi0;
                 uint32_t lo = cur.w[1], hi = cur.w[0];
 #pragma unroll
                 for (int c = 1; c < NSEL; c++) {
                     lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
                     hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
                 }
-                const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (p & 15u));   // kmer_[p] mod 4^16
-                uint32_t r = v & (g.Rf - 1u);
-                if (p >= LW1) {                              // EM.cpp:167: positions >= LW1 take no part
-                    r = Rn;
-                    const uint32_t d = p - LW1;
+                const uint32_t X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
 #pragma unroll
-                    for (int dd = 0; dd < G - 1; dd++)
-                        if (d == (uint32_t)dd && p < L) r = g.base[dd] + ((v >> (2u * (dd + 1))) & (g.psize[dd] - 1u));
+                for (int m = 0; m < M; m++)
+                    row[m] = (p0 + m < LW1) ? ((X >> (2 * (M - 1 - m))) & (g.Rf - 1u)) : Rn;   // EM.cpp:167
+                // groups cut by the LW1 edge: G-1 positions of the whole sequence, patched by their lane
+#pragma unroll
+                for (int dd = 0; dd < G - 1; dd++) {
+                    const uint32_t pp = LW1 + (uint32_t)dd;
+                    if (pp < L) {
+                        const uint32_t lp = pp / (uint32_t)M, ms = pp - lp * (uint32_t)M;
+                        const uint32_t patch = g.base[dd] + ((X >> (2u * ((uint32_t)(M - 1) - ms) + 2u * (dd + 1))) & (g.psize[dd] - 1u));
+                        const bool mine = (uint32_t)lane == lp;
+#pragma unroll
+                        for (int m = 0; m < M; m++) row[m] = (mine && ms == (uint32_t)m) ? patch : row[m];
+                    }
                 }
-                row[m] = r;
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const uint32_t p = p0 + m;
+                    const uint32_t sel = (p >> 4) - wi0;
+                    uint32_t lo = cur.w[1], hi = cur.w[0];
+#pragma unroll
+                    for (int c = 1; c < NSEL; c++) {
+                        lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
+                        hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
+                    }
+                    const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (p & 15u));   // kmer_[p] mod 4^16
+                    uint32_t r = v & (g.Rf - 1u);
+                    if (p >= LW1) {                              // EM.cpp:167: positions >= LW1 take no part
+                        r = Rn;
+                        const uint32_t d = p - LW1;
+#pragma unroll
+                        for (int dd = 0; dd < G - 1; dd++)
+                            if (d == (uint32_t)dd && p < L) r = g.base[dd] + ((v >> (2u * (dd + 1))) & (g.psize[dd] - 1u));
+                    }
+                    row[m] = r;
+                }
             }
         }
 
@@ -262,8 +309,9 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const float invZ = 1.0f / Z;
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187
-        llh_acc += (double)logf(Z);                      // EM.cpp:195
-        sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
+        // EM.cpp:195; v_log_f32 is good to 1 ulp of the result, the sum runs in fp64
+        llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);
+        sumr_acc += (double)invZ;                        // sum_i r[i] = 1 - (1-q)/Z  (EM.cpp:509-513), finished below
         seq_cnt++;
 
         if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
@@ -295,33 +343,39 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 if (nnz <= g.cap) {
                     dense = false;
                     const uint32_t cap = g.cap;
-                    unsigned long long* listF = reinterpret_cast<unsigned long long*>(wscratch + 32);
-                    unsigned short* listP = reinterpret_cast<unsigned short*>(listF + cap);
-                    unsigned short* rowbuf = listP + cap;
+                    // list entry = addend (41 bits) | slot << 48
+                    unsigned long long* list = reinterpret_cast<unsigned long long*>(wscratch + 32);
+                    unsigned short* rowbuf = reinterpret_cast<unsigned short*>(list + cap);
 #pragma unroll
                     for (int m = 0; m < M; m++) {
-                        if (F[m] != 0ull) { listF[lpos[m]] = F[m]; listP[lpos[m]] = (unsigned short)(p0 + m); }
+                        if (F[m] != 0ull) list[lpos[m]] = F[m] | ((unsigned long long)(p0 + m) << 48);
                         rowbuf[p0 + m] = (unsigned short)row[m];
                     }
                     wave_lds_sync();
                     const uint32_t ecnt = (nnz + 63u) >> 6;
+                    const uint32_t rowbuf_base = lds_offset(rowbuf);
+                    const uint32_t sh = logC + 3u;
                     for (uint32_t e = 0; e < ecnt; e++) {
                         const uint32_t idx = e * 64u + (uint32_t)lane;
-                        const bool ok = idx < nnz;
-                        const unsigned long long Fe = ok ? listF[idx] : 0ull;
-                        // first group ends at i - delta + G-1 with i = slot - (W-1)
-                        const uint32_t pe = ok ? (uint32_t)listP[idx] + (uint32_t)(G - 1) - delta - (W - 1u) : 0u;
-                        const unsigned short* rp = rowbuf + pe;
-                        unsigned long long* colp = ng + copy;
-                        for (uint32_t tb = 0; tb < T; tb += 5u) {
-                            uint32_t rr[5];
+                        if (idx < nnz) {
+                            const unsigned long long ent = list[idx];
+                            const unsigned long long Fe = ent & 0xffffffffffffull;
+                            // first group ends at i - delta + G-1 with i = slot - (W-1)
+                            const uint32_t pe = (uint32_t)(ent >> 48) + (uint32_t)(G - 1) - delta - (W - 1u);
+                            uint32_t ra2 = rowbuf_base + pe * 2u;
+                            uint32_t colv = ng_base + copy * 8u;
+                            for (uint32_t tb = 0; tb < T; tb += 5u) {
+                                uint32_t rr[5];
 #pragma unroll
-                            for (int u = 0; u < 5; u++) rr[u] = (tb + u < T) ? (uint32_t)rp[(tb + u) * G] : Rn;
+                                for (int u = 0; u < 5; u++) rr[u] = (tb + u < T) ? lds_read_u16(ra2 + (uint32_t)u * 2u * G) : Rn;
+                                ra2 += 10u * G;
+                                lds_wait_u32<5>(rr);
 #pragma unroll
-                            for (int u = 0; u < 5; u++) {
-                                if (tb + u < T) {
-                                    if (ok) atomicAdd(&colp[rr[u] << logC], Fe);
-                                    colp += Rtot << logC;
+                                for (int u = 0; u < 5; u++) {
+                                    if (tb + u < T) {
+                                        lds_add_u64_plain(colv + (rr[u] << sh), Fe);
+                                        colv += strideT;
+                                    }
                                 }
                             }
                         }
@@ -382,7 +436,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     lds_drain();
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
-        stat_lds[wave * 3 + 1] = sumr_acc;
+        stat_lds[wave * 3 + 1] = (double)seq_cnt - (double)one_minus_q * sumr_acc;
         stat_lds[wave * 3 + 2] = (double)seq_cnt;
     }
     __syncthreads();
@@ -453,7 +507,7 @@ void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t b
 // length classes the grouped kernel is instantiated for: 4..16 positions per lane (M >= G)
 bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 4 && M <= 16; }
 
-uint32_t grp_sparse_cap(int M) { return (uint32_t)std::min(192, 64 * M); }
+uint32_t grp_sparse_cap(int M) { return getenv("BAMM_NO_SPARSE") ? 0u : (uint32_t)std::min(192, 64 * M); }
 
 bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out) {
     if (K > 2u || W == 0u) return false;
@@ -487,7 +541,7 @@ bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uin
     if (accum) off = up16(off + W * Y * 8u);
     g.off_wave = off;
     g.cap = accum ? grp_sparse_cap(M) : 0u;
-    g.wave_bytes = up16(32u + (accum ? g.cap * 8u + g.cap * 2u + 64u * (uint32_t)M * 2u : 0u));
+    g.wave_bytes = up16(32u + (accum ? g.cap * 8u + 64u * (uint32_t)M * 2u : 0u));
     off += waves * g.wave_bytes;
     g.lds_bytes = off;
     *out = g;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Steady-state PMC passes over the bench workload (separate rocprofv3 --pmc runs per counter group,
 # no tracing flags).  Usage (on the GPU box): bash tools/pmc_run.sh [extra bench.py flags]
+# PMC_SCRIPT="tools/time_e_only.py" profiles another driver script instead of bench.py.
 # Results: gpurun_out/pmc/<group>/..., summary gpurun_out/hbm_traffic.json (tools/summarize_pmc.py).
 set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
@@ -13,7 +14,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_WAVES SQ_WAIT_INST_ANY"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $grp -d gpurun_out/pmc/g$i -o pmc --output-format csv -- \
-      python3 bench.py --no-cpu-baseline --warmup 25 --steps 6 "$@" > gpurun_out/pmc/g$i.log 2>&1
+      python3 ${PMC_SCRIPT:-bench.py --no-cpu-baseline --warmup 25 --steps 6} "$@" > gpurun_out/pmc/g$i.log 2>&1
   echo "pmc group $i done"
 done
 python3 tools/summarize_pmc.py gpurun_out/pmc 401000000
