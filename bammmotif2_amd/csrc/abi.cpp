@@ -1066,6 +1066,16 @@ int bamm_em_get_trace(bamm_em* em, float* llh, float* v_diff, float* q, uint32_t
     return BAMM_OK;
 }
 
+int bamm_em_plan(bamm_em* em, uint64_t* grouped_seqs, uint64_t* percolumn_seqs, uint32_t* launches) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    uint64_t g = 0, o = 0;
+    for (auto& b : em->ebuckets) (b.grouped ? g : o) += b.count;
+    if (grouped_seqs) *grouped_seqs = g;
+    if (percolumn_seqs) *percolumn_seqs = o;
+    if (launches) *launches = (uint32_t)em->ebuckets.size();
+    return BAMM_OK;
+}
+
 int bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches) {
     if (!em || !total_ms || !launches) { set_error("bad argument"); return BAMM_ERR_ARG; }
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));

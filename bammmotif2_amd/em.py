@@ -317,6 +317,12 @@ class EM:
         check(self.lib.bamm_em_kernel_time(self.h, C.byref(ms), C.byref(n)))
         return float(ms.value), int(n.value)
 
+    def plan(self):
+        """(sequences through the grouped-column kernel, through the per-column kernel, launches per pass)."""
+        g, o, n = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        check(self.lib.bamm_em_plan(self.h, C.byref(g), C.byref(o), C.byref(n)))
+        return int(g.value), int(o.value), int(n.value)
+
     def close(self):
         if self.h:
             self.lib.bamm_em_destroy(self.h)

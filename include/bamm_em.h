@@ -185,6 +185,9 @@ int  bamm_em_get_trace(bamm_em* em, float* llh, float* v_diff, float* q, uint32_
 /* device time of the sequence kernel over the last iterate()/optimize() call (HIP events on
  * the context's stream): total milliseconds and number of launches.                          */
 int  bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches);
+/* how one pass is laid out: sequences that go through the grouped-column kernel (grouped.hip)
+ * and through the one-column-at-a-time kernel (kernels.hip), and the kernel launches per pass. */
+int  bamm_em_plan(bamm_em* em, uint64_t* grouped_seqs, uint64_t* percolumn_seqs, uint32_t* launches);
 
 /* ------------------------------------------------------------------ scorer -------------- */
 /* ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67) with Motif::calculateLogS

@@ -1,0 +1,149 @@
+"""The grouped-column kernel (bammmotif2_amd/csrc/grouped.hip) against the pinned oracle, and against
+the one-column-at-a-time kernel it replaces for orders K <= 2.
+
+What is specific to it and therefore tested here: G = 4-K columns per table row (K = 0, 1, 2), the
+partial rows at the EM.cpp:167 truncation edge (W not a multiple of G, W < G), the virtual rows next
+to N exceptions (Sequence.cpp:38; the strand junction of every double-stranded sequence, and N inside
+a sequence), the split of a bucket into sequences the kernel takes and the rest, and every length
+class it is built for (4..16 positions per lane).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bammmotif2_amd as bm
+from tests.cases import Case
+
+pytestmark = pytest.mark.gpu
+
+GROUPED_CASES = [
+    dict(name="g_k2_ds_m5", N=80, L0=150, W=9, K=2, n_frac=0.0, ragged=20),
+    dict(name="g_k2_ds_m7_N", N=120, L0=200, W=20, K=2, n_frac=0.004, ragged=0),
+    dict(name="g_k1_ds_N", N=64, L0=200, W=7, K=1, n_frac=0.01, ragged=30),
+    dict(name="g_k0_ss", N=64, L0=300, W=13, K=0, ss=True, n_frac=0.005, ragged=40),
+    dict(name="g_k0_ds_w2", N=48, L0=170, W=2, K=0, ragged=10),
+    dict(name="g_k2_w1", N=40, L0=160, W=1, K=2, ragged=12),
+    dict(name="g_k2_w3", N=40, L0=160, W=3, K=2, n_frac=0.003, ragged=12),
+    dict(name="g_k2_m10", N=40, L0=300, W=20, K=2, ragged=0),
+    dict(name="g_k2_m16", N=24, L0=480, W=21, K=2, n_frac=0.001, ragged=60),
+    dict(name="g_k1_ss_m4", N=64, L0=250, W=12, K=1, ss=True, ragged=30),
+    dict(name="g_k2_wide", N=32, L0=200, W=31, K=2, ragged=0),
+]
+
+
+def make_em(ctx, c, orc, **kw):
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(ctx, pk)
+    em = bm.EM(ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, **kw)
+    return em, ss, kmer, off, vbg
+
+
+@pytest.mark.parametrize("spec", GROUPED_CASES, ids=[d["name"] for d in GROUPED_CASES])
+def test_grouped_kernel_matches_oracle(spec, gpu_ctx, orc):
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    grouped, other, _ = em.plan()
+    assert grouped > 0, "this case is meant to exercise the grouped kernel"
+    if c.n_frac >= 0.004 and not c.ss:
+        assert other > 0, "sequences with scattered N must fall to the per-column kernel"
+    Kb = min(c.bg_order, c.K)
+    for it in range(3):
+        v = em.getV()
+        em.EStep()
+        s_o = orc.linear_s(v, vbg, c.K, c.W, Kb)
+        r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, c.q)
+        r_g = em.getR()
+        # products are rounded group-wise, not left to right: a few 2^-24 per window
+        np.testing.assert_allclose(r_g, r_o, rtol=1e-5, atol=1e-12)
+        assert np.array_equal(r_g == 0, r_o == 0)
+        # Z_n is a wave tree sum here and a sequential fp32 loop over L-W+1 near-equal terms in the
+        # reference (EM.cpp:179-182), whose rounding is one-sided when the terms are alike (W <= 2
+        # seeds): up to ~1e-6 absolute per sequence on log Z_n
+        np.testing.assert_allclose(em.getLLH(), llh_o, rtol=2e-6, atol=2e-6 * c.N)
+        em.MStep()
+        n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
+        # the oracle accumulates N*(L-W+1) fp32 addends per cell like the reference; with
+        # W <= 2 every window carries weight, which is its worst case (~sqrt(n) * 2^-24)
+        np.testing.assert_allclose(em.getCounts(), n_o, rtol=3e-5 if c.W <= 2 else 1e-5, atol=1e-6)
+        np.testing.assert_allclose(em.getV(), orc.update_v(n_o, c.A, vbg, c.K, c.W),
+                                   rtol=3e-5 if c.W <= 2 else 1e-5, atol=1e-9)
+    em.close(); ss.close()
+
+
+@pytest.mark.parametrize("spec", GROUPED_CASES, ids=[d["name"] for d in GROUPED_CASES])
+def test_grouped_kernel_matches_exact_arithmetic(spec, gpu_ctx, orc):
+    """One E+M step against the oracle's fp64 restatement of the same formulas: the fixed-point
+    counts carry no accumulation noise, so this bar is ten times tighter than the parity bar."""
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    v64, *_ = orc.em_step_f64(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+    em.iterate(1)
+    np.testing.assert_allclose(em.getV(), v64, rtol=1e-6, atol=1e-9)
+    em.close(); ss.close()
+
+
+@pytest.mark.parametrize("spec", GROUPED_CASES[:5], ids=[d["name"] for d in GROUPED_CASES[:5]])
+def test_grouped_equals_per_column_kernel(spec, gpu_ctx, orc, monkeypatch):
+    """Same handle twice, once with the grouped kernel switched off: counts are sums of the same
+    fixed-point addends up to the rounding of r, llh and q chain identically."""
+    c = Case(**spec)
+    res = []
+    for off_switch in (False, True):
+        if off_switch:
+            monkeypatch.setenv("BAMM_NO_GROUPED", "1")
+        else:
+            monkeypatch.delenv("BAMM_NO_GROUPED", raising=False)
+        em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+        g, o, _ = em.plan()
+        assert (g == 0) == off_switch
+        em.iterate(4)
+        res.append((em.getV(), em.getCounts(), em.getQ(), em.trace()[0], em.getR()))
+        em.close(); ss.close()
+    a, b = res
+    np.testing.assert_allclose(a[0], b[0], rtol=2e-6, atol=1e-10)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-6)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-5, atol=5e-7 * c.N)     # log Z_n of a Z_n that differs by 1 ulp
+    np.testing.assert_allclose(a[4], b[4], rtol=5e-6, atol=1e-12)
+
+
+def test_grouped_sparse_and_dense_m_step_agree(gpu_ctx, orc, monkeypatch):
+    """The compacted (sparse) M-step and the dense one add the same integers."""
+    c = Case(name="g_sd", N=300, L0=200, W=20, K=2)
+    out = []
+    for no_sparse in (False, True):
+        if no_sparse:
+            monkeypatch.setenv("BAMM_NO_SPARSE", "1")
+        else:
+            monkeypatch.delenv("BAMM_NO_SPARSE", raising=False)
+        em, ss, *_ = make_em(gpu_ctx, c, orc)
+        assert em.plan()[0] == c.N
+        em.iterate(12)                       # late iterations are sparse enough for the list path
+        out.append((em.getCounts(), em.getV()))
+        em.close(); ss.close()
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_grouped_with_fold_mask_and_optimize(gpu_ctx, orc):
+    """CV-fold mask + the full optimize() loop through the grouped kernel vs the oracle."""
+    c = Case(name="g_opt", N=400, L0=200, W=12, K=2, n_frac=0.0)
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(gpu_ctx, pk)
+    mask = (np.arange(c.N) % 5 != 2).astype(np.uint8)
+    em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, mask=mask, max_iterations=8)
+    assert em.plan()[0] == c.N
+    em.optimize()
+    keep = np.flatnonzero(mask)
+    sub_off = np.zeros(len(keep) + 1, np.uint64)
+    parts = []
+    for i, n in enumerate(keep):
+        parts.append(kmer[int(off[n]):int(off[n + 1])])
+        sub_off[i + 1] = sub_off[i] + np.uint64(len(parts[-1]))
+    res = orc.optimize(np.concatenate(parts), sub_off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, max_iter=8)
+    assert em.iteration() == res["iterations"]
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=5e-5, atol=1e-8)
+    em.close(); ss.close()
