@@ -44,7 +44,7 @@ struct ExcK {                    // exceptions relevant at one model order
     uint64_t count = 0;
     // grouped kernel (grouped.hip): per-sequence record + what decides whether it applies
     uint4* d_xrec = nullptr;
-    std::vector<uint8_t> h_cnt, h_span;   // exceptions of the sequence (capped at 255), last - first position
+    std::vector<uint8_t> h_B;             // group ends that need a virtual row (0 = no exception, 255 = too many)
 };
 
 struct EmBucket {                // one kernel launch of an EM pass
@@ -78,6 +78,8 @@ struct bamm_seqs {
     uint32_t* d_len = nullptr;
     uint64_t* d_pos_off = nullptr;
     std::vector<uint32_t> h_len;
+    std::vector<uint32_t> h_words;              // host copy of the 2-bit stream (grouped kernel's exception records)
+    std::vector<uint64_t> h_word_off;
     std::vector<uint64_t> h_pos_off;
     std::vector<uint64_t> h_exc_off;            // full (11-mer level) exception list
     std::vector<uint32_t> h_exc_pos, h_exc_kmer, h_exc_clean;
@@ -174,29 +176,47 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
     std::vector<uint64_t> off(s->n + 1, 0);
     std::vector<uint2> ex;
     ExcK k;
-    k.h_cnt.assign(s->n, 0);
-    k.h_span.assign(s->n, 0);
-    // x = first position | span << 12 | count << 16; y/z/w hold up to 9 exceptions, 10 bits each
-    // (position - first | y << 4); only meaningful for the sequences the grouped kernel takes
+    k.h_B.assign(s->n, 0);
+    // grouped kernel (K <= 2, G = 4-K columns per row): x = first exception position | B << 12,
+    // y/z/w = exact y of the positions lo-G+1 .. lo+B-1, 7 bits each, 4 per word
+    const uint32_t G = 4u - std::min(K, 3u);
     std::vector<uint4> xrec(K <= 2u ? s->n : 0, make_uint4(0, 0, 0, 0));
+    auto stream_y = [&](uint64_t n, int64_t pos) -> uint32_t {      // kmer_ mod 4^(K+1) as the stream alone gives it
+        uint32_t y = 0;
+        for (uint32_t d = 0; d <= K; d++) {
+            const int64_t q = pos - (int64_t)d;
+            if (q < 0) break;                                        // implicit A-padding (Sequence.cpp:35-41)
+            const uint32_t w = s->h_words[s->h_word_off[n] + (uint64_t)(q >> 4)];
+            y |= ((w >> (30u - 2u * (uint32_t)(q & 15))) & 3u) << (2u * d);
+        }
+        return y;
+    };
     for (uint64_t n = 0; n < s->n; n++) {
         off[n] = ex.size();
         for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
             if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
                 ex.push_back(make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY));
         const size_t cnt = ex.size() - off[n];
-        if (cnt) {
-            const uint32_t lo = ex[off[n]].x, span = ex.back().x - lo;
-            k.h_cnt[n] = (uint8_t)std::min<size_t>(cnt, 255);
-            k.h_span[n] = (uint8_t)std::min<uint32_t>(span, 255);
-            if (K <= 2u && cnt <= 9 && span <= 15u && lo < 4096u) {
-                uint32_t w3[3] = {0, 0, 0};
-                for (size_t i = 0; i < cnt; i++) {
-                    const uint2 x = ex[off[n] + i];
-                    w3[i / 3] |= ((x.x - lo) | (x.y << 4)) << (10u * (uint32_t)(i % 3));
+        if (cnt && K <= 2u) {
+            const uint32_t lo = ex[off[n]].x, hi = ex.back().x, L = s->h_len[n];
+            const uint32_t hiB = std::min(hi + G - 1u, L - 1u);
+            const uint32_t B = hiB - lo + 1u;
+            if (B > 8u || B + G - 1u > 12u || lo >= 4096u) { k.h_B[n] = 255; continue; }
+            k.h_B[n] = (uint8_t)B;
+            uint32_t w3[3] = {0, 0, 0};
+            size_t e = off[n];
+            for (uint32_t i = 0; i < B + G - 1u; i++) {
+                const int64_t pos = (int64_t)lo - (int64_t)(G - 1u) + i;
+                uint32_t y = maskY + 1u;                             // no such position
+                if (pos >= 0) {
+                    while (e < ex.size() && (int64_t)ex[e].x < pos) e++;
+                    y = (e < ex.size() && (int64_t)ex[e].x == pos) ? ex[e].y : stream_y(n, pos);
                 }
-                xrec[n] = make_uint4(lo | (span << 12) | ((uint32_t)cnt << 16), w3[0], w3[1], w3[2]);
+                w3[i >> 2] |= y << (7u * (i & 3u));
             }
+            xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
+        } else if (cnt) {
+            k.h_B[n] = 255;
         }
     }
     off[s->n] = ex.size();
@@ -450,6 +470,8 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
         s->min_len = std::min(s->min_len, s->h_len[n]);
     }
     woff[s->n] = w1 - w0;
+    s->h_words.assign(p->words + w0, p->words + w1);
+    s->h_word_off = woff;
     s->h_pos_off[s->n] = pos;
     s->h_exc_off[s->n] = e1 - e0;
     s->total_len = pos;
@@ -469,7 +491,10 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
         members[mc].push_back((uint32_t)n);
     }
     int rc;
-    if ((rc = dev_upload(&s->d_words, p->words + w0, w1 - w0, c->stream))) return rc;
+    // 80 zero words of slack: the grouped kernel reads a lane's words without checking the sequence's end
+    if ((rc = dev_alloc(&s->d_words, (w1 - w0) + 80))) return rc;
+    BAMM_HIP(hipMemsetAsync(s->d_words + (w1 - w0), 0, 80 * sizeof(uint32_t), c->stream));
+    if (w1 > w0) BAMM_HIP(hipMemcpyAsync(s->d_words, p->words + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if ((rc = dev_upload(&s->d_word_off, woff.data(), woff.size(), c->stream))) return rc;
     if ((rc = dev_upload(&s->d_len, s->h_len.data(), s->h_len.size(), c->stream))) return rc;
     if ((rc = dev_upload(&s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size(), c->stream))) return rc;
@@ -620,7 +645,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         std::vector<uint32_t> yes, no;
         if (glogc != UINT32_MAX && grp_geometry(prm->K, prm->W, Mcls, threads / 64u, true, glogc, &gg)) {
             const ExcK* x = em->exc;
-            auto capable = [&](uint32_t n) { return x->h_cnt[n] == 0 || (x->h_cnt[n] <= 9 && (uint32_t)x->h_span[n] + gg.G <= gg.Bv); };
+            auto capable = [&](uint32_t n) { return (uint32_t)x->h_B[n] <= gg.Bv; };
             bool all = true;
             for (uint32_t i = 0; i < b.count && all; i++) all = capable(b.d_idx ? b.h_idx[i] : i);
             if (!all)

@@ -73,6 +73,7 @@ struct GrpGeom {
     uint32_t Rf;                 // full rows = 4^(K+G)
     uint32_t base[3], psize[3];  // partial class d (d+1 trailing positions neutral): first row, rows = 4^(K+G-1-d)
     uint32_t Rn, R0, Bv, Rtot;   // neutral row, first virtual row, virtual rows per wave, rows in all
+    uint32_t rowstride;          // floats per row of the odds table [Rtot][Tq][4]
     uint32_t off_sg, off_s1, off_stat, off_ng, off_n1, off_wave, wave_bytes;   // LDS byte offsets
     uint32_t cap;                // sparse M-step list capacity per wave (0 = dense only)
     uint32_t lds_bytes;
@@ -81,7 +82,8 @@ struct GrpGeom {
 struct GrpKernelArgs {
     EmKernelArgs e;
     GrpGeom g;
-    const uint4* xrec;           // per sequence: x = lo | span<<12 | E<<16, y/z/w = 3 exceptions each, 10 bits (dpos | y<<4)
+    const uint4* xrec;           // per sequence: x = lo | B<<12 (group ends lo..lo+B-1 need a virtual row), y/z/w = exact y of
+                                 // the positions lo-G+1.., 7 bits each, 4 per word (the value Y = position before the sequence)
 };
 
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply

@@ -61,6 +61,13 @@ __device__ __forceinline__ void lds_wait_u32(uint32_t (&v)[N]) {
     for (int i = 1; i < N; i++) asm volatile("" : "+v"(v[i]) : "v"(v[0]));
 }
 
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128_off(uint32_t byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
+}
+
 template <int M>
 struct RawSeqG {
     static constexpr int NSEL = (M + 14) / 16 + 1;
@@ -77,12 +84,13 @@ __device__ __forceinline__ RawSeqG<M> fetch_seq_g(const SeqView& sv, const uint4
     r.ok = !(sv.mask && !sv.mask[r.seq]);
     r.L = sv.len[r.seq];
     r.xr = xrec[r.seq];
+    // words past the sequence's end only feed positions >= L, whose rows are overridden; the
+    // stream buffer carries 80 words of slack behind the last sequence (bamm_seqs_upload)
     const uint32_t* wp = sv.words + sv.word_off[r.seq];
-    const uint32_t nw = (r.L + 15u) >> 4;
     const uint32_t wi0 = ((uint32_t)lane * M) >> 4;
-    r.w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+    r.w[0] = (wi0 >= 1u) ? wp[wi0 - 1u] : 0u;
 #pragma unroll
-    for (int i = 0; i < RawSeqG<M>::NSEL; i++) r.w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+    for (int i = 0; i < RawSeqG<M>::NSEL; i++) r.w[i + 1] = wp[wi0 + i];
     return r;
 }
 
@@ -94,7 +102,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     const GrpGeom& g = ga.g;
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     const uint32_t T = g.T, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
-    float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Tq][Rtot][4]
+    float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Rtot][Tq][4]
     float* s1 = reinterpret_cast<float*>(lds_raw + g.off_s1);                             // [W][Y+1]
     double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
     unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);   // [T][Rtot][C]
@@ -117,7 +125,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             const int col = (int)(G * t + c) - (int)delta;
             if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + ((code >> (2u * (nreal - 1u - c))) & (Y - 1u))];
         }
-        sg[((t >> 2) * Rtot + row) * 4u + (t & 3u)] = f;
+        sg[row * g.rowstride + t] = f;
     }
     if (ACCUM) {
         for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
@@ -134,7 +142,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
     const uint32_t vbase = g.R0 + wave * g.Bv;
     unsigned char* wscratch = lds_raw + g.off_wave + (size_t)wave * g.wave_bytes;
-    unsigned char* ybuf = wscratch;                                                      // [32] bytes
     const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
     const uint32_t strideT = (Rtot << logC) * 8u;
 
@@ -213,51 +220,35 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             }
         }
 
-        // ---- exceptions (Sequence.cpp:38): virtual rows for the group ends next to them
+        // ---- exceptions (Sequence.cpp:38): virtual rows for the group ends next to them.  The
+        // record carries the exact y of the positions [lo-G+1, lo+B), 7 bits each (Y = none)
         const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
-        const uint32_t E = xw >> 16;
+        const uint32_t B = (xw >> 12) & 0xfu;                // group ends that need a virtual row (0: none)
         const uint32_t xlo = xw & 0xfffu;
-        uint32_t B = 0;
         uint32_t yfix[G];
 #pragma unroll
         for (int c = 0; c < G; c++) yfix[c] = Y;
-        bool fix = false;
-        if (E != 0u) {
-            const uint32_t span = (xw >> 12) & 0xfu;
-            const uint32_t hiB = min(xlo + span + (uint32_t)(G - 1), L - 1u);
-            B = hiB - xlo + 1u;
-            // exact y of the positions [lo-G+1, hiB] -> ybuf[p + G-1 - lo]
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const uint32_t k = p0 + m + (uint32_t)(G - 1) - xlo;
-                if (k < B + (uint32_t)(G - 1)) ybuf[k] = (unsigned char)((p0 + m < LW1) ? (row[m] & (Y - 1u)) : Y);
-            }
-            wave_lds_sync();
-            if ((uint32_t)lane < E) {
-                const uint32_t word = (lane < 3) ? cur.xr.y : ((lane < 6) ? cur.xr.z : cur.xr.w);
-                const uint32_t e = (word >> (10u * ((uint32_t)lane % 3u))) & 0x3ffu;
-                const uint32_t dpos = e & 15u;
-                if (xlo + dpos < LW1) ybuf[dpos + (uint32_t)(G - 1)] = (unsigned char)(e >> 4);
-            }
-            wave_lds_sync();
+        const bool fix = lane_b < B;
+        if (B != 0u) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const uint32_t k2 = p0 + m - xlo;
                 if (k2 < B) row[m] = vbase + k2;
             }
-            fix = lane_b < B;
             if (fix) {
                 float f = 1.0f;
 #pragma unroll
                 for (int c = 0; c < G; c++) {
                     const int col = (int)(G * lane_t + c) - (int)delta;
-                    const int pos = (int)(xlo + lane_b) - (G - 1) + c;
-                    uint32_t yc = Y;
-                    if (col >= 0 && pos >= 0) yc = ybuf[lane_b + c];
+                    const uint32_t k = lane_b + (uint32_t)c;               // entry of position lo-G+1+k
+                    const uint32_t pos = xlo + k - (uint32_t)(G - 1);      // wraps for positions before the sequence
+                    const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                    uint32_t yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                    if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167
                     yfix[c] = yc;
                     if (yc != Y) f *= s1[(uint32_t)col * Ys + yc];
                 }
-                sg[((lane_t >> 2) * Rtot + vbase + lane_b) * 4u + (lane_t & 3u)] = f;
+                sg[(vbase + lane_b) * g.rowstride + lane_t] = f;
             }
             wave_lds_sync();
         }
@@ -269,32 +260,44 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             uint32_t ra[M];
             const uint32_t sg_base = lds_offset(sg);
 #pragma unroll
-            for (int m = 0; m < M; m++) ra[m] = sg_base + row[m] * 16u;
-            for (uint32_t jq = 0; jq < Tq; jq++) {
+            for (int m = 0; m < M; m++) ra[m] = sg_base + row[m] * (g.rowstride * 4u);
+#define BAMM_GRP_STEP(COMP, TT)                                                        \
+            if ((TT) < T) {                                                            \
+                float cy[G];                                                           \
+                _Pragma("unroll") for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]); \
+                _Pragma("unroll") for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * sv[m].COMP;      \
+                _Pragma("unroll") for (int m = 0; m < G; m++) U[m] = cy[m] * sv[m].COMP;              \
+            }
+#define BAMM_GRP_QUAD(JQ)                                                              \
+            if ((JQ) < Tq) {                                                           \
+                f32x4 sv[M];                                                           \
+                _Pragma("unroll") for (int m = 0; m < M; m++) sv[m] = lds_read_b128_off<(JQ) * 16>(ra[m]); \
+                lds_wait<M>(sv);                                                       \
+                if ((JQ) == 0) {                                                       \
+                    _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = sv[m].x;      \
+                } else {                                                               \
+                    BAMM_GRP_STEP(x, (JQ) * 4u)                                        \
+                }                                                                      \
+                BAMM_GRP_STEP(y, (JQ) * 4u + 1u)                                       \
+                BAMM_GRP_STEP(z, (JQ) * 4u + 2u)                                       \
+                BAMM_GRP_STEP(w, (JQ) * 4u + 3u)                                       \
+            }
+            BAMM_GRP_QUAD(0)
+            BAMM_GRP_QUAD(1)
+            BAMM_GRP_QUAD(2)
+            BAMM_GRP_QUAD(3)
+            for (uint32_t jq = 4; jq < Tq; jq++) {           // W > 16*G: rare, plain loop
                 f32x4 sv[M];
 #pragma unroll
-                for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m]);
-#pragma unroll
-                for (int m = 0; m < M; m++) ra[m] += Rtot * 16u;
+                for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m] + jq * 16u);
                 lds_wait<M>(sv);
-#define BAMM_GRP_STEP(COMP, TT)                                                        \
-                if ((TT) < T) {                                                        \
-                    float cy[G];                                                       \
-                    _Pragma("unroll") for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]); \
-                    _Pragma("unroll") for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * sv[m].COMP;      \
-                    _Pragma("unroll") for (int m = 0; m < G; m++) U[m] = cy[m] * sv[m].COMP;              \
-                }
-                if (jq == 0) {
-#pragma unroll
-                    for (int m = 0; m < M; m++) U[m] = sv[m].x;             // group 0 starts the chain
-                } else {
-                    BAMM_GRP_STEP(x, jq * 4u)
-                }
+                BAMM_GRP_STEP(x, jq * 4u)
                 BAMM_GRP_STEP(y, jq * 4u + 1u)
                 BAMM_GRP_STEP(z, jq * 4u + 2u)
                 BAMM_GRP_STEP(w, jq * 4u + 3u)
-#undef BAMM_GRP_STEP
             }
+#undef BAMM_GRP_QUAD
+#undef BAMM_GRP_STEP
         }
         const float pos_i = q / (float)LW1;              // EM.cpp:160
         float zpart = 0.0f;
@@ -412,7 +415,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 }
             }
             // ---- virtual count rows -> single-column bins (exact: one window per cell)
-            if (E != 0u) {
+            if (B != 0u) {
                 wave_lds_sync();
                 if (fix) {
                     unsigned long long acc = 0ull;
@@ -531,6 +534,7 @@ bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uin
     const uint32_t Y = 1u << (2u * (K + 1u));
     auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
     uint32_t off = 0;
+    g.rowstride = g.Tq * 4u;
     g.off_sg = off; off = up16(off + g.Tq * g.Rtot * 16u);
     g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
     g.off_stat = off; off = up16(off + 16u * 3u * 8u);
