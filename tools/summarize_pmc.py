@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 --pmc CSVs (one pass per counter group) into profiles/hbm_traffic.json.
 
-HBM bytes per launch of k_em_seq = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both
+HBM bytes per launch of the fused sequence kernel (k_em_grp, else k_em_seq) = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both
 in KiB and on gfx950 FETCH_SIZE reads half of the bytes a coalesced stream fetches
 (/opt/skills/guides/MI355X_MICROARCH.md, section HBM)."""
 import csv
@@ -20,7 +20,8 @@ summary = {}
 for k, cs in acc.items():
     summary[k] = {c: sum(v) / len(v) for c, v in cs.items()}
     summary[k]["dispatches"] = max(len(v) for v in cs.values())
-main = next((k for k in summary if "k_em_seq" in k), None)
+main = next((k for k in summary if "k_em_grp" in k and "true, false" in k), None) or \
+    next((k for k in summary if "k_em_seq" in k), None)
 res = {"positions_per_launch": positions, "per_kernel_mean_counters": summary}
 if main and "FETCH_SIZE" in summary[main] and "WRITE_SIZE" in summary[main]:
     f, w = summary[main]["FETCH_SIZE"], summary[main]["WRITE_SIZE"]
