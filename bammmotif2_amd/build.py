@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libbamm_em.so")
 SOURCES = ["kernels.hip", "grouped.hip", "mask.hip", "abi.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"),
            os.path.join(HERE, "..", "include", "bamm_em.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
 OBJDIR = os.path.join(HERE, "build")
 

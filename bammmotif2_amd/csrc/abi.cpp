@@ -42,9 +42,13 @@ struct ExcK {                    // exceptions relevant at one model order
     uint64_t* d_off = nullptr;
     uint2* d_exc = nullptr;
     uint64_t count = 0;
-    // grouped kernel (grouped.hip): per-sequence record + what decides whether it applies
-    uint4* d_xrec = nullptr;
-    std::vector<uint8_t> h_B;             // group ends that need a virtual row (0 = no exception, 255 = too many)
+    std::vector<uint64_t> h_off;          // host copies (the grouped kernel's records are built from them)
+    std::vector<uint2> h_ex;
+    struct XRec {                         // grouped kernel (grouped.hip), one set per group size G
+        uint4* d_xrec = nullptr;          // per-sequence record
+        std::vector<uint8_t> h_B;         // group ends that need a virtual row (0 = no exception, 255 = too many)
+    };
+    std::map<uint32_t, XRec> xrec;
 };
 
 struct EmBucket {                // one kernel launch of an EM pass
@@ -52,6 +56,8 @@ struct EmBucket {                // one kernel launch of an EM pass
     uint32_t count = 0;
     const uint32_t* d_idx = nullptr;
     bool grouped = false;        // k_em_grp instead of k_em_seq
+    uint32_t G = 0;              // its group size
+    const uint4* d_xrec = nullptr;
     uint32_t blocks = 0, logc = 0, sparse_cap = 0, sparse_bytes = 0;
     double work = 0;
 };
@@ -84,7 +90,7 @@ struct bamm_seqs {
     std::vector<uint64_t> h_exc_off;            // full (11-mer level) exception list
     std::vector<uint32_t> h_exc_pos, h_exc_kmer, h_exc_clean;
     std::vector<Bucket> buckets;
-    std::map<uint32_t, ExcK> exc_by_order;
+    std::map<uint32_t, ExcK> exc_by_order;      // node-based: pointers into it stay valid
 
     ~bamm_seqs() {                               // also runs on every error path of bamm_seqs_upload
         (void)hipFree(d_words);
@@ -92,7 +98,10 @@ struct bamm_seqs {
         (void)hipFree(d_len);
         (void)hipFree(d_pos_off);
         for (auto& b : buckets) (void)hipFree(b.d_idx);
-        for (auto& kv : exc_by_order) { (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc); (void)hipFree(kv.second.d_xrec); }
+        for (auto& kv : exc_by_order) {
+            (void)hipFree(kv.second.d_off); (void)hipFree(kv.second.d_exc);
+            for (auto& x : kv.second.xrec) (void)hipFree(x.second.d_xrec);
+        }
     }
 };
 
@@ -123,7 +132,7 @@ struct bamm_em {
     std::vector<std::pair<uint32_t, uint32_t>> e_slices, m_slices;
     uint32_t m_slice_logc = 0;
     float* d_state = nullptr;                   // one float per position slot: E-chain state, then r
-    const ExcK* exc = nullptr;
+    ExcK* exc = nullptr;
     bool estep_done = false;
     float llh_prev = 0.0f;                      // EM.h:61
     uint32_t host_iteration = 0;
@@ -169,18 +178,43 @@ SeqView make_view(const bamm_seqs* s, const ExcK* exc, const EmBucket& b, const 
 
 // build (once per order) the list of positions whose kmer_ mod 4^(K+1) differs from what the
 // 2-bit stream gives
-int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
+int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
     auto it = s->exc_by_order.find(K);
     if (it != s->exc_by_order.end()) { *out = &it->second; return BAMM_OK; }
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
-    std::vector<uint64_t> off(s->n + 1, 0);
-    std::vector<uint2> ex;
     ExcK k;
-    k.h_B.assign(s->n, 0);
-    // grouped kernel (K <= 2, G = 4-K columns per row): x = first exception position | B << 12,
-    // y/z/w = exact y of the positions lo-G+1 .. lo+B-1, 7 bits each, 4 per word
-    const uint32_t G = 4u - std::min(K, 3u);
-    std::vector<uint4> xrec(K <= 2u ? s->n : 0, make_uint4(0, 0, 0, 0));
+    k.h_off.assign(s->n + 1, 0);
+    for (uint64_t n = 0; n < s->n; n++) {
+        k.h_off[n] = k.h_ex.size();
+        for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
+            if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
+                k.h_ex.push_back(make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY));
+    }
+    k.h_off[s->n] = k.h_ex.size();
+    k.count = k.h_ex.size();
+    int rc = dev_upload(&k.d_off, k.h_off.data(), k.h_off.size(), s->ctx->stream);
+    if (rc) return rc;
+    rc = dev_upload(&k.d_exc, k.h_ex.data(), k.h_ex.size(), s->ctx->stream);
+    if (rc) { (void)hipFree(k.d_off); return rc; }
+    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {
+        (void)hipFree(k.d_off); (void)hipFree(k.d_exc);
+        set_error("stream sync failed while uploading the exception list");
+        return BAMM_ERR_HIP;
+    }
+    auto ins = s->exc_by_order.emplace(K, std::move(k));
+    *out = &ins.first->second;
+    return BAMM_OK;
+}
+
+// records of the grouped kernel for group size G (built once per (order, G)): x = first exception
+// position | B << 12, y/z/w = exact y of the positions lo-G+1 .. lo+B-1, 7 bits each, 4 per word
+int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XRec** out) {
+    auto it = k->xrec.find(G);
+    if (it != k->xrec.end()) { *out = &it->second; return BAMM_OK; }
+    const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
+    ExcK::XRec x;
+    x.h_B.assign(s->n, 0);
+    std::vector<uint4> xrec(s->n, make_uint4(0, 0, 0, 0));
     auto stream_y = [&](uint64_t n, int64_t pos) -> uint32_t {      // kmer_ mod 4^(K+1) as the stream alone gives it
         uint32_t y = 0;
         for (uint32_t d = 0; d <= K; d++) {
@@ -192,49 +226,34 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, const ExcK** out) {
         return y;
     };
     for (uint64_t n = 0; n < s->n; n++) {
-        off[n] = ex.size();
-        for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
-            if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
-                ex.push_back(make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY));
-        const size_t cnt = ex.size() - off[n];
-        if (cnt && K <= 2u) {
-            const uint32_t lo = ex[off[n]].x, hi = ex.back().x, L = s->h_len[n];
-            const uint32_t hiB = std::min(hi + G - 1u, L - 1u);
-            const uint32_t B = hiB - lo + 1u;
-            if (B > 8u || B + G - 1u > 12u || lo >= 4096u) { k.h_B[n] = 255; continue; }
-            k.h_B[n] = (uint8_t)B;
-            uint32_t w3[3] = {0, 0, 0};
-            size_t e = off[n];
-            for (uint32_t i = 0; i < B + G - 1u; i++) {
-                const int64_t pos = (int64_t)lo - (int64_t)(G - 1u) + i;
-                uint32_t y = maskY + 1u;                             // no such position
-                if (pos >= 0) {
-                    while (e < ex.size() && (int64_t)ex[e].x < pos) e++;
-                    y = (e < ex.size() && (int64_t)ex[e].x == pos) ? ex[e].y : stream_y(n, pos);
-                }
-                w3[i >> 2] |= y << (7u * (i & 3u));
+        const uint64_t e0 = k->h_off[n], e1 = k->h_off[n + 1];
+        if (e0 == e1) continue;
+        const uint32_t lo = k->h_ex[e0].x, hi = k->h_ex[e1 - 1].x, L = s->h_len[n];
+        const uint32_t hiB = std::min(hi + G - 1u, L - 1u);
+        const uint32_t B = hiB - lo + 1u;
+        if (B > 8u || B + G - 1u > 12u || lo >= 4096u) { x.h_B[n] = 255; continue; }
+        x.h_B[n] = (uint8_t)B;
+        uint32_t w3[3] = {0, 0, 0};
+        uint64_t e = e0;
+        for (uint32_t i = 0; i < B + G - 1u; i++) {
+            const int64_t pos = (int64_t)lo - (int64_t)(G - 1u) + i;
+            uint32_t y = maskY + 1u;                                 // no such position
+            if (pos >= 0) {
+                while (e < e1 && (int64_t)k->h_ex[e].x < pos) e++;
+                y = (e < e1 && (int64_t)k->h_ex[e].x == pos) ? k->h_ex[e].y : stream_y(n, pos);
             }
-            xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
-        } else if (cnt) {
-            k.h_B[n] = 255;
+            w3[i >> 2] |= y << (7u * (i & 3u));
         }
+        xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
     }
-    off[s->n] = ex.size();
-    k.count = ex.size();
-    int rc = dev_upload(&k.d_off, off.data(), off.size(), s->ctx->stream);
+    int rc = dev_upload(&x.d_xrec, xrec.data(), xrec.size(), s->ctx->stream);
     if (rc) return rc;
-    rc = dev_upload(&k.d_exc, ex.data(), ex.size(), s->ctx->stream);
-    if (rc) { (void)hipFree(k.d_off); return rc; }
-    if (!xrec.empty() && (rc = dev_upload(&k.d_xrec, xrec.data(), xrec.size(), s->ctx->stream))) {
-        (void)hipFree(k.d_off); (void)hipFree(k.d_exc);
-        return rc;
-    }
-    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {   // host vectors go out of scope
-        (void)hipFree(k.d_off); (void)hipFree(k.d_exc); (void)hipFree(k.d_xrec);
-        set_error("stream sync failed while uploading the exception list");
+    if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {
+        (void)hipFree(x.d_xrec);
+        set_error("stream sync failed while uploading the sequence records");
         return BAMM_ERR_HIP;
     }
-    auto ins = s->exc_by_order.emplace(K, std::move(k));
+    auto ins = k->xrec.emplace(G, std::move(x));
     *out = &ins.first->second;
     return BAMM_OK;
 }
@@ -285,8 +304,8 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
     a.logC = eb.logc;
     a.sparse_cap = 0; a.sparse_wave_bytes = 0;
     ga.e = a;
-    ga.xrec = em->exc->d_xrec;
-    if (!grp_geometry(em->prm.K, em->prm.W, kMClasses[eb.mclass], threads / 64u, accum, accum ? eb.logc : 0u, &ga.g)) {
+    ga.xrec = eb.d_xrec;
+    if (!grp_geometry(em->prm.K, em->prm.W, eb.G, kMClasses[eb.mclass], threads / 64u, accum, accum ? eb.logc : 0u, &ga.g)) {
         set_error("grouped kernel geometry does not fit (K=%u W=%u)", em->prm.K, em->prm.W);
         return BAMM_ERR_UNSUPPORTED;
     }
@@ -640,12 +659,13 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         const int Mcls = kMClasses[b.mclass];
         const uint32_t threads = default_threads(c, b.mclass);
         GrpGeom gg{};
-        uint32_t glogc = UINT32_MAX;
-        if (want_grouped && grp_supported_class(Mcls, prm->K)) glogc = grp_pick_log_copies(prm->K, prm->W, Mcls, threads / 64u);
+        uint32_t glogc = 0, gG = 0;
+        const ExcK::XRec* xr = nullptr;
         std::vector<uint32_t> yes, no;
-        if (glogc != UINT32_MAX && grp_geometry(prm->K, prm->W, Mcls, threads / 64u, true, glogc, &gg)) {
-            const ExcK* x = em->exc;
-            auto capable = [&](uint32_t n) { return (uint32_t)x->h_B[n] <= gg.Bv; };
+        if (want_grouped && grp_supported_class(Mcls, prm->K) && grp_plan(prm->K, prm->W, Mcls, threads / 64u, &gG, &glogc) &&
+            grp_geometry(prm->K, prm->W, gG, Mcls, threads / 64u, true, glogc, &gg)) {
+            if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
+            auto capable = [&](uint32_t n) { return (uint32_t)xr->h_B[n] <= gg.Bv; };
             bool all = true;
             for (uint32_t i = 0; i < b.count && all; i++) all = capable(b.d_idx ? b.h_idx[i] : i);
             if (!all)
@@ -654,7 +674,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
                     (capable(n) ? yes : no).push_back(n);
                 }
             EmBucket eb;
-            eb.mclass = b.mclass; eb.grouped = true; eb.logc = glogc;
+            eb.mclass = b.mclass; eb.grouped = true; eb.logc = glogc; eb.G = gG; eb.d_xrec = xr->d_xrec;
             if (all) { eb.count = b.count; eb.d_idx = b.d_idx; }
             else {
                 uint32_t* d = nullptr;
@@ -1141,7 +1161,7 @@ int bamm_logodds_subset(bamm_ctx* c, bamm_seqs* s, const uint8_t* seq_mask, uint
     for (uint64_t n = 0; n < s->n; n++) moff[n + 1] = moff[n] + (s->h_len[n] - W + 1);
     if (mops && mops_cap < moff[s->n]) { set_error("mops buffer too small"); return BAMM_ERR_ARG; }
     hipStream_t st = c->stream;
-    const ExcK* exc = nullptr;
+    ExcK* exc = nullptr;
     int rc = exceptions_for_order(s, K, &exc);
     if (rc) return rc;
     float *d_tab = nullptr, *d_mops = nullptr, *d_zoops = nullptr;

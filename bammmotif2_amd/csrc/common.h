@@ -64,7 +64,7 @@ struct EmKernelArgs {
     uint32_t seq_begin, seq_end; // WRITE_R range filter (sequence ids)
 };
 
-// ---- grouped-column kernel (grouped.hip): G = 4-K motif columns share one table row ----------
+// ---- grouped-column kernel (grouped.hip): G motif columns (K+G = 4 or 5) share one table row ------
 // Row index of a position p = the (K+G)-mer ending at p; rows beyond the full ones cover groups cut
 // by the EM.cpp:167 truncation (p >= L-W+1), one neutral row, and per-wave "virtual" rows that
 // stand in for group ends next to an N exception (Sequence.cpp:38).
@@ -75,7 +75,7 @@ struct GrpGeom {
     uint32_t Rn, R0, Bv, Rtot;   // neutral row, first virtual row, virtual rows per wave, rows in all
     uint32_t rowstride;          // floats per row of the odds table [Rtot][Tq][4]
     uint32_t off_sg, off_s1, off_stat, off_ng, off_n1, off_wave, wave_bytes;   // LDS byte offsets
-    uint32_t cap;                // sparse M-step list capacity per wave (0 = dense only)
+    uint32_t cap;                // unused (the grouped kernel has no sparse M-step)
     uint32_t lds_bytes;
 };
 
@@ -87,8 +87,8 @@ struct GrpKernelArgs {
 };
 
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply
-bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out);
-uint32_t grp_pick_log_copies(uint32_t K, uint32_t W, int M, uint32_t waves);   // largest logC that fits, or UINT32_MAX
+bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out);
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, uint32_t* G, uint32_t* logC);   // false: use k_em_seq
 bool grp_supported_class(int M, uint32_t K);
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st);

@@ -46,21 +46,6 @@ __device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned lo
                  :: "v"(byte_addr), "v"(v), "s"(mask) : "memory");
 }
 
-__device__ __forceinline__ void lds_add_u64_plain(uint32_t byte_addr, unsigned long long v) {
-    asm volatile("ds_add_u64 %0, %1" :: "v"(byte_addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_read_u16(uint32_t byte_addr) {
-    uint32_t v;
-    asm volatile("ds_read_u16 %0, %1" : "=v"(v) : "v"(byte_addr));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait_u32(uint32_t (&v)[N]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
-#pragma unroll
-    for (int i = 1; i < N; i++) asm volatile("" : "+v"(v[i]) : "v"(v[0]));
-}
-
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read_b128_off(uint32_t byte_addr) {
     f32x4 v;
@@ -94,7 +79,52 @@ __device__ __forceinline__ RawSeqG<M> fetch_seq_g(const SeqView& sv, const uint4
     return r;
 }
 
-template <int M, int G, bool ACCUM, bool WRITE_R, int THREADS>
+// One step of the E-step chain: slots move up by G, the G lowest come from the previous lane.
+template <int M, int G>
+__device__ __forceinline__ void grp_step(float (&U)[M], const float (&f)[M]) {
+    float cy[G];
+#pragma unroll
+    for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]);
+#pragma unroll
+    for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * f[m];
+#pragma unroll
+    for (int m = 0; m < G; m++) U[m] = cy[m] * f[m];
+}
+
+// E-step chain over NQ quads of group slots, straight-line: EVERY slot of a quad is multiplied in
+// (the slots in front of the first real group hold 1.0f), so no branch sits between two steps and
+// the shift by G slots per step is pure register renaming.  A guard per step (T is a run-time
+// value) makes the compiler move all M registers at every merge point.
+template <int M, int G, int NQ>
+__device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]) {
+    static_assert(NQ >= 1 && NQ <= 4, "quads");
+#define BAMM_GRP_QUAD(JQ)                                                                       \
+    if constexpr (NQ > (JQ)) {                                                                  \
+        f32x4 sv[M];                                                                            \
+        _Pragma("unroll") for (int m = 0; m < M; m++) sv[m] = lds_read_b128_off<(JQ) * 16>(ra[m]); \
+        lds_wait<M>(sv);                                                                        \
+        float f[M];                                                                             \
+        if constexpr ((JQ) == 0) {                                                              \
+            _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = sv[m].x;                       \
+        } else {                                                                                \
+            _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].x;                       \
+            grp_step<M, G>(U, f);                                                               \
+        }                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].y;                           \
+        grp_step<M, G>(U, f);                                                                   \
+        _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].z;                           \
+        grp_step<M, G>(U, f);                                                                   \
+        _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].w;                           \
+        grp_step<M, G>(U, f);                                                                   \
+    }
+    BAMM_GRP_QUAD(0)
+    BAMM_GRP_QUAD(1)
+    BAMM_GRP_QUAD(2)
+    BAMM_GRP_QUAD(3)
+#undef BAMM_GRP_QUAD
+}
+
+template <int M, int G, int KG, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     static_assert(M >= G, "a group must not span more than two lanes");
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -102,11 +132,12 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     const GrpGeom& g = ga.g;
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     const uint32_t T = g.T, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
+    const uint32_t pad = 4u * Tq - T;                     // neutral table slots in front of the first real group
     float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Rtot][Tq][4]
     float* s1 = reinterpret_cast<float*>(lds_raw + g.off_s1);                             // [W][Y+1]
     double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
     unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);   // [T][Rtot][C]
-    unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]
+    unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]: counts of the virtual rows
     const uint32_t logC = ACCUM ? a.logC : 0u;
 
     // ---- block prologue: single-column table, grouped table, zeroed counts
@@ -125,7 +156,12 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             const int col = (int)(G * t + c) - (int)delta;
             if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + ((code >> (2u * (nreal - 1u - c))) & (Y - 1u))];
         }
-        sg[row * g.rowstride + t] = f;
+        sg[row * g.rowstride + pad + t] = f;
+    }
+    // neutral slots of every row, and the virtual rows as a whole (their real slots are rewritten per sequence)
+    for (uint32_t i = threadIdx.x; i < Rtot * g.rowstride; i += blockDim.x) {
+        const uint32_t row = i / g.rowstride, slot = i - row * g.rowstride;
+        if (slot < pad || row > Rn) sg[i] = 1.0f;
     }
     if (ACCUM) {
         for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
@@ -141,7 +177,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
     const uint32_t vbase = g.R0 + wave * g.Bv;
-    unsigned char* wscratch = lds_raw + g.off_wave + (size_t)wave * g.wave_bytes;
     const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
     const uint32_t strideT = (Rtot << logC) * 8u;
 
@@ -167,7 +202,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             constexpr int NSEL = RawSeqG<M>::NSEL;
             const uint32_t wi0 = p0 >> 4;
             // bits a position needs: its (K+G)-mer, shifted by up to G-1 digits for a partial row
-            constexpr bool kOneWindow = 2 * (M - 1) + 8 + 2 * (G - 1) <= 32;
+            constexpr bool kOneWindow = 2 * (M - 1) + 10 + 2 * (G - 1) <= 32;    // rows are at most 10 bits (K+G <= 5)
             if constexpr (kOneWindow) {
                 // one 32-bit window of the stream ending at the lane's LAST position; position p0+m
                 // is that window shifted by a compile-time 2*(M-1-m) bits
@@ -248,7 +283,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     yfix[c] = yc;
                     if (yc != Y) f *= s1[(uint32_t)col * Ys + yc];
                 }
-                sg[(vbase + lane_b) * g.rowstride + lane_t] = f;
+                sg[(vbase + lane_b) * g.rowstride + pad + lane_t] = f;
             }
             wave_lds_sync();
         }
@@ -261,43 +296,34 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             const uint32_t sg_base = lds_offset(sg);
 #pragma unroll
             for (int m = 0; m < M; m++) ra[m] = sg_base + row[m] * (g.rowstride * 4u);
-#define BAMM_GRP_STEP(COMP, TT)                                                        \
-            if ((TT) < T) {                                                            \
-                float cy[G];                                                           \
-                _Pragma("unroll") for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]); \
-                _Pragma("unroll") for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * sv[m].COMP;      \
-                _Pragma("unroll") for (int m = 0; m < G; m++) U[m] = cy[m] * sv[m].COMP;              \
-            }
-#define BAMM_GRP_QUAD(JQ)                                                              \
-            if ((JQ) < Tq) {                                                           \
-                f32x4 sv[M];                                                           \
-                _Pragma("unroll") for (int m = 0; m < M; m++) sv[m] = lds_read_b128_off<(JQ) * 16>(ra[m]); \
-                lds_wait<M>(sv);                                                       \
-                if ((JQ) == 0) {                                                       \
-                    _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = sv[m].x;      \
-                } else {                                                               \
-                    BAMM_GRP_STEP(x, (JQ) * 4u)                                        \
-                }                                                                      \
-                BAMM_GRP_STEP(y, (JQ) * 4u + 1u)                                       \
-                BAMM_GRP_STEP(z, (JQ) * 4u + 2u)                                       \
-                BAMM_GRP_STEP(w, (JQ) * 4u + 3u)                                       \
-            }
-            BAMM_GRP_QUAD(0)
-            BAMM_GRP_QUAD(1)
-            BAMM_GRP_QUAD(2)
-            BAMM_GRP_QUAD(3)
-            for (uint32_t jq = 4; jq < Tq; jq++) {           // W > 16*G: rare, plain loop
-                f32x4 sv[M];
+            switch (Tq) {
+                case 1: grp_chain<M, G, 1>(ra, U); break;
+                case 2: grp_chain<M, G, 2>(ra, U); break;
+                case 3: grp_chain<M, G, 3>(ra, U); break;
+                case 4: grp_chain<M, G, 4>(ra, U); break;
+                default: {                                   // more than 16 groups: plain loop
+                    grp_chain<M, G, 4>(ra, U);
+                    for (uint32_t jq = 4; jq < Tq; jq++) {
+                        f32x4 sv[M];
 #pragma unroll
-                for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m] + jq * 16u);
-                lds_wait<M>(sv);
-                BAMM_GRP_STEP(x, jq * 4u)
-                BAMM_GRP_STEP(y, jq * 4u + 1u)
-                BAMM_GRP_STEP(z, jq * 4u + 2u)
-                BAMM_GRP_STEP(w, jq * 4u + 3u)
+                        for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m] + jq * 16u);
+                        lds_wait<M>(sv);
+                        float f[M];
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].x;
+                        grp_step<M, G>(U, f);
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].y;
+                        grp_step<M, G>(U, f);
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].z;
+                        grp_step<M, G>(U, f);
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].w;
+                        grp_step<M, G>(U, f);
+                    }
+                }
             }
-#undef BAMM_GRP_QUAD
-#undef BAMM_GRP_STEP
         }
         const float pos_i = q / (float)LW1;              // EM.cpp:160
         float zpart = 0.0f;
@@ -333,58 +359,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
             const uint32_t ng_base = lds_offset(ng);
 
-            bool dense = true;
-            if (g.cap != 0u) {
-                uint32_t nnz = 0, lpos[M];
-#pragma unroll
-                for (int m = 0; m < M; m++) {
-                    const unsigned long long mask = __ballot(F[m] != 0ull);
-                    lpos[m] = nnz + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                    nnz += (uint32_t)__popcll(mask);
-                }
-                if (nnz <= g.cap) {
-                    dense = false;
-                    const uint32_t cap = g.cap;
-                    // list entry = addend (41 bits) | slot << 48
-                    unsigned long long* list = reinterpret_cast<unsigned long long*>(wscratch + 32);
-                    unsigned short* rowbuf = reinterpret_cast<unsigned short*>(list + cap);
-#pragma unroll
-                    for (int m = 0; m < M; m++) {
-                        if (F[m] != 0ull) list[lpos[m]] = F[m] | ((unsigned long long)(p0 + m) << 48);
-                        rowbuf[p0 + m] = (unsigned short)row[m];
-                    }
-                    wave_lds_sync();
-                    const uint32_t ecnt = (nnz + 63u) >> 6;
-                    const uint32_t rowbuf_base = lds_offset(rowbuf);
-                    const uint32_t sh = logC + 3u;
-                    for (uint32_t e = 0; e < ecnt; e++) {
-                        const uint32_t idx = e * 64u + (uint32_t)lane;
-                        if (idx < nnz) {
-                            const unsigned long long ent = list[idx];
-                            const unsigned long long Fe = ent & 0xffffffffffffull;
-                            // first group ends at i - delta + G-1 with i = slot - (W-1)
-                            const uint32_t pe = (uint32_t)(ent >> 48) + (uint32_t)(G - 1) - delta - (W - 1u);
-                            uint32_t ra2 = rowbuf_base + pe * 2u;
-                            uint32_t colv = ng_base + copy * 8u;
-                            for (uint32_t tb = 0; tb < T; tb += 5u) {
-                                uint32_t rr[5];
-#pragma unroll
-                                for (int u = 0; u < 5; u++) rr[u] = (tb + u < T) ? lds_read_u16(ra2 + (uint32_t)u * 2u * G) : Rn;
-                                ra2 += 10u * G;
-                                lds_wait_u32<5>(rr);
-#pragma unroll
-                                for (int u = 0; u < 5; u++) {
-                                    if (tb + u < T) {
-                                        lds_add_u64_plain(colv + (rr[u] << sh), Fe);
-                                        colv += strideT;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            if (dense) {
+            {
                 unsigned long long nz[M];
                 uint32_t rad[M];                             // byte offset of (row, private copy) inside a group table
 #pragma unroll
@@ -483,24 +458,24 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     }
 }
 
-template <int M, int G, int THREADS>
+template <int M, int G, int KG, int THREADS>
 void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
     const size_t lds = a.g.lds_bytes;
     if (write_r) {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, false, true, THREADS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_em_grp<M, G, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL((k_em_grp<M, G, KG, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
     } else if (accum) {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, true, false, THREADS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_em_grp<M, G, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
     } else {
         if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, false, false, THREADS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, false, THREADS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_em_grp<M, G, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        hipLaunchKernelGGL((k_em_grp<M, G, KG, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
     }
 }
 
@@ -509,12 +484,10 @@ void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t b
 // length classes the grouped kernel is instantiated for: 4..16 positions per lane (M >= G)
 bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 4 && M <= 16; }
 
-uint32_t grp_sparse_cap(int M) { return getenv("BAMM_NO_SPARSE") ? 0u : (uint32_t)std::min(192, 64 * M); }
-
-bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out) {
-    if (K > 2u || W == 0u) return false;
+bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out) {
+    if (K > 2u || W == 0u || G < 2u || G > 4u || K + G > 5u || (int)G > M) return false;
     GrpGeom g{};
-    g.G = 4u - K;
+    g.G = G;
     g.T = (W + g.G - 1u) / g.G;
     if (g.T > 64u) return false;
     g.Tq = (g.T + 3u) / 4u;
@@ -528,7 +501,8 @@ bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uin
     }
     g.Rn = r;
     g.R0 = r + 1u;
-    g.Bv = std::min(8u, 64u / g.T);
+    // one N makes K exceptions in a row (B = K-1+G group ends); two more rows cover "NN" and "N.N"
+    g.Bv = std::min(std::min(8u, K + g.G + 1u), 64u / g.T);
     if (g.Bv < g.G) return false;
     g.Rtot = g.R0 + waves * g.Bv;
     const uint32_t Y = 1u << (2u * (K + 1u));
@@ -543,20 +517,30 @@ bool grp_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, uin
     g.off_n1 = off;
     if (accum) off = up16(off + W * Y * 8u);
     g.off_wave = off;
-    g.cap = accum ? grp_sparse_cap(M) : 0u;
-    g.wave_bytes = up16(32u + (accum ? g.cap * 8u + 64u * (uint32_t)M * 2u : 0u));
+    const uint32_t kLds = 160u * 1024u;
+    g.cap = 0;
+    g.wave_bytes = 0u;
     off += waves * g.wave_bytes;
     g.lds_bytes = off;
     *out = g;
-    return off <= 160u * 1024u;
+    return off <= kLds;
 }
 
-uint32_t grp_pick_log_copies(uint32_t K, uint32_t W, int M, uint32_t waves) {
-    GrpGeom g;
-    uint32_t best = UINT32_MAX;
-    for (uint32_t lc = 0; lc <= 3u; lc++)
-        if (grp_geometry(K, W, M, waves, true, lc, &g)) best = lc;
-    return best;
+// group size and private copies for (K, W): wider groups first (fewer gathers / adds per window),
+// then as many private copies of the count table as the 160 KiB hold
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, uint32_t* G_out, uint32_t* logC_out) {
+    const uint32_t forced = getenv("BAMM_GRP_G") ? (uint32_t)atoi(getenv("BAMM_GRP_G")) : 0u;
+    for (uint32_t G = 5u - K; G >= 2u && G + 1u >= 5u - K; G--) {          // G = 5-K, then 4-K
+        if (G > 4u || (forced && G != forced)) continue;
+        for (int lc = 2; lc >= 0; lc--) {
+            GrpGeom g;
+            if (grp_geometry(K, W, G, M, waves, true, (uint32_t)lc, &g)) {
+                *G_out = G; *logC_out = (uint32_t)lc;
+                return true;
+            }
+        }
+    }
+    return false;
 }
 
 #define BAMM_FOR_EACH_GCLASS(X) \
@@ -569,11 +553,14 @@ int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, 
         set_error("bad launch of the grouped kernel (%u x %u, %u bytes of LDS)", blocks, threads, a.g.lds_bytes);
         return BAMM_ERR_ARG;
     }
-    switch (mclass * 8 + (int)a.g.G) {
-#define X(idx, M, T)                                                                              \
-    case idx * 8 + 2: launch_variant<M, 2, T>(accum, write_r, a, blocks, threads, st); break;     \
-    case idx * 8 + 3: launch_variant<M, 3, T>(accum, write_r, a, blocks, threads, st); break;     \
-    case idx * 8 + 4: launch_variant<M, 4, T>(accum, write_r, a, blocks, threads, st); break;
+    const uint32_t KG = a.e.K + a.g.G;                       // row = (K+G)-mer: 4 or 5 bases
+    switch (mclass * 64 + (int)a.g.G * 8 + (int)KG) {
+#define X(idx, M, T)                                                                                        \
+    case idx * 64 + 2 * 8 + 4: launch_variant<M, 2, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 3 * 8 + 4: launch_variant<M, 3, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 4 * 8 + 4: launch_variant<M, 4, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 3 * 8 + 5: launch_variant<M, 3, 5, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 4 * 8 + 5: launch_variant<M, 4, 5, T>(accum, write_r, a, blocks, threads, st); break;
         BAMM_FOR_EACH_GCLASS(X)
 #undef X
         default:
