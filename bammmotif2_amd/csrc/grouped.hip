@@ -4,11 +4,12 @@
 // EM.cpp:231-243 and the sum over r of EM.cpp:509-513 -- file:line relative to /root/reference/src.
 //
 // k_em_seq is bound by the LDS pipe: per (position, column) one odds-table gather and one count
-// add.  Here G = 4-K neighbouring columns share ONE table row: the row index of position p is the
-// (K+G)-mer ending at p (256 rows), the table entry of group t is the product of its G column
-// odds, so a window costs T = ceil(W/G) gathers / adds instead of W:
+// add.  Here G neighbouring columns share ONE table row.  The row index of position p is the
+// (K+G)-mer ending at p -- 5 bases (1024 rows, G = 5-K) when the tables fit the 160 KiB of a CU,
+// else 4 bases (256 rows, G = 4-K) -- and the table entry of group t is the product of its G column
+// odds, so a window costs T = ceil(W/G) gathers / adds instead of W (7 instead of 20 at K=2, W=20):
 //
-//   U_t(p) = U_{t-1}(p-G) * sG[t][row(p)],      row(p) = kmer_[p] mod 4^(K+G)
+//   U_t(p) = U_{t-1}(p-G) * sG[row(p)][t],      row(p) = kmer_[p] mod 4^(K+G)
 //   nG[t][row(p)] += r(window)                  (marginalised to n[j][y] once per block)
 //
 // What keeps this exact:
@@ -17,14 +18,22 @@
 //   * N randomisation (Sequence.cpp:38): next to an exception the k-mers of neighbouring positions
 //     disagree, so no (K+G)-mer describes the group.  Those group ends (a handful per sequence:
 //     the strand junction) get per-wave VIRTUAL rows: a few "fix" lanes compute their G-column
-//     products from the single-column table before the chain starts, and after the M-step move
-//     what the virtual count rows collected into single-column bins.  The chain itself never
-//     sees an exception.  Sequences whose exceptions span more than the virtual rows go through
-//     k_em_seq instead (bamm_em_create splits the buckets).
+//     products from the single-column table before the chain starts (the exact y of the positions
+//     involved travels inline with the sequence record), and after the M-step move what the
+//     virtual count rows collected into single-column bins.  The chain itself never sees an
+//     exception.  Sequences whose exceptions span more than the virtual rows go through k_em_seq
+//     instead (bamm_em_create splits the buckets).
 //   * counts are 64-bit fixed point (2^-40) as in k_em_seq: sums are exact and order-free, so the
 //     result is bit-identical to k_em_seq's for the same responsibilities.
 // Window products are rounded in a different order than the reference's left-to-right product
-// (pairs first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
+// (groups first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
+//
+// Things measured and left out: a compacted list of the non-zero windows for
+// the M-step (its scratch does not fit next to the 1024-row tables, and at 256 rows it is no faster
+// than the dense walk here); the virtual-row counts as no-return atomics on an HBM table instead of
+// the LDS one (+0.19 ms per pass: ~20 L2 atomics per sequence); per-step guards on the run-time
+// group count in the E-chain (each merge point costs M register moves: the chain is straight-line
+// over padded neutral slots instead).
 
 #include "device_utils.h"
 

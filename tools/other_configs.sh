@@ -1,0 +1,17 @@
+#!/bin/bash
+# The other BASELINE.json configurations on one GPU (bench.py flags), one summary line each.
+# Usage (GPU box): bash tools/other_configs.sh > gpurun_out/r01_other_configs.txt
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
+run() {
+  echo "cfg: $*"
+  python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c '
+import json,sys
+d=json.loads(sys.stdin.read())
+print("%s | %.3f ms/iter | %.1f it/s | %.2e pos/s | %s" % (d["config"]["workload"], d["ms_per_step"], d["iterations_per_s"], d["value"], d["roofline"]["kernel"]))'
+}
+run --nseq 50000
+run --nseq 1000000 --ss
+run --nseq 200000
+run --nseq 1000000 --len 500 --width 30 --order 4 --steps 5 --warmup 1
+run --nseq 1000000 --order 1
+run --nseq 1000000 --order 0
