@@ -1136,6 +1136,45 @@ int bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches) {
 }
 
 // ------------------------------------------------------------------------------ scorer -----
+int bamm_seed_from_pwm(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, const float* score, float q, const double* u,
+                       int32_t* counts, uint32_t* z) {
+    if (!c || !s || !score || !u || !counts) { set_error("bamm_seed_from_pwm: null argument"); return BAMM_ERR_ARG; }
+    if (K > BAMM_MAX_ORDER || W == 0) { set_error("bamm_seed_from_pwm: bad K/W"); return BAMM_ERR_ARG; }
+    if (s->ctx != c) { set_error("sequence set belongs to another context"); return BAMM_ERR_ARG; }
+    const size_t vsz = v_size(K, W);
+    std::fill(counts, counts + vsz, 0);
+    if (s->n == 0) return BAMM_OK;
+    BAMM_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    ExcK* exc = nullptr;
+    int rc = exceptions_for_order(s, K, &exc);
+    if (rc) return rc;
+    float* d_score = nullptr;
+    double* d_u = nullptr;
+    int* d_counts = nullptr;
+    uint32_t* d_z = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_score); (void)hipFree(d_u); (void)hipFree(d_counts); (void)hipFree(d_z); };
+    if ((rc = dev_upload(&d_score, score, (size_t)4 * W, st)) || (rc = dev_upload(&d_u, u, s->n, st)) ||
+        (rc = dev_alloc(&d_counts, vsz)) || (z && (rc = dev_alloc(&d_z, s->n)))) { cleanup(); return rc; }
+    if (hipMemsetAsync(d_counts, 0, vsz * sizeof(int), st) != hipSuccess) { set_error("hipMemsetAsync failed"); cleanup(); return BAMM_ERR_HIP; }
+    SeedKernelArgs a{};
+    Bucket all;                                              // every sequence, natural order
+    all.count = (uint32_t)s->n;
+    a.sv = make_view(s, exc, all, nullptr);
+    a.K = K; a.W = W; a.Y = (uint32_t)ipow4(K + 1);
+    a.max_len = s->max_len; a.vsize = (uint32_t)vsz;
+    a.score = d_score; a.q = q; a.u = d_u; a.counts = d_counts; a.z_out = d_z;
+    rc = launch_seed_pwm(a, (uint32_t)std::max(1, c->num_cus), st);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(counts, d_counts, vsz * sizeof(int), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && z) e = hipMemcpyAsync(z, d_z, s->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { set_error("bamm_seed_from_pwm: copy failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
+    }
+    cleanup();
+    return rc;
+}
+
 int bamm_logodds(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, uint32_t bg_order, const float* v, const float* vbg,
                  float* mops, uint64_t mops_cap, float* zoops, uint64_t* z) {
     return bamm_logodds_subset(c, s, nullptr, K, W, bg_order, v, vbg, mops, mops_cap, zoops, z);

@@ -93,6 +93,19 @@ bool grp_supported_class(int M, uint32_t K);
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st);
 
+struct SeedKernelArgs {          // Motif::initFromPWM's pass over the sequences (seed.hip)
+    SeqView  sv;                 // every resident sequence, exceptions of order K
+    uint32_t K, W, Y;            // Y = 4^(K+1)
+    uint32_t max_len, vsize;     // longest sequence, cells of the count table (all orders)
+    uint32_t table_bytes, count_bytes, wave_bytes;   // LDS layout, filled in by the launcher
+    const float* score;          // [4][W] floored PWM / 0th-order background (Motif.cpp:205-226)
+    float    q;
+    const double* u;             // [N] the uniform variate of each sequence's draw
+    int*     counts;             // [vsize] flat [k][y][j], zeroed by the caller
+    uint32_t* z_out;             // nullable: sampled index per sequence (0 = no motif)
+};
+int launch_seed_pwm(SeedKernelArgs a, uint32_t num_cus, hipStream_t st);
+
 struct ScoreKernelArgs {
     SeqView  sv;
     uint32_t K, W, Y;

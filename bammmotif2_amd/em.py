@@ -329,6 +329,20 @@ class EM:
             self.h = None
 
 
+def seed_from_pwm(ctx: Context, seqs: SeqSet, K: int, W: int, score, q: float, u):
+    """The pass over the sequences of Motif::initFromPWM (Motif.cpp:228-311) on the device: returns
+    (counts[v_size(K,W)] int32, z[n_seqs] uint32).  score: [4][W] floored PWM / 0th-order background;
+    u[n]: the uniform variate of sequence n's draw (see include/bamm_em.h)."""
+    score = _f32(score)
+    u = np.ascontiguousarray(u, np.float64)
+    assert len(score) == 4 * W and len(u) == seqs.n_seqs
+    counts = np.zeros(v_size(K, W), np.int32)
+    z = np.zeros(seqs.n_seqs, np.uint32)
+    check(ctx.lib.bamm_seed_from_pwm(ctx.h, seqs.h, K, W, score, q, u.ctypes.data_as(C.c_void_p),
+                                     counts.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p)))
+    return counts, z
+
+
 def logodds(ctx: Context, seqs: SeqSet, K: int, W: int, bg_order: int, v, vbg, want_mops: bool = True, mask=None):
     """ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67): returns (mops or None, zoops, z).
 

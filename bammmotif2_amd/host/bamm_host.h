@@ -42,9 +42,16 @@ struct Motif {
     std::vector<float> v, p;            // flat [k][y][j]
 };
 void motif_alloc(Motif& m, uint32_t W, uint32_t K, const std::vector<float>& alpha, float q);
-// Motif::initFromPWM (Motif.cpp:192-333): pwm[y][j] (4 x W); yK = kmer_ mod 4^(K+1) per position
-void motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
-                         const uint64_t* off, size_t n_seqs, float q);
+// a resident copy of the training set: lets initFromPWM's pass over the sequences run on the device
+struct SeedDevice {
+    bamm_ctx* ctx = nullptr;
+    bamm_seqs* seqs = nullptr;
+};
+// Motif::initFromPWM (Motif.cpp:192-333): pwm[y][j] (4 x W); yK = kmer_ mod 4^(K+1) per position (host
+// path; may be null with `dev`).  With `dev` the posteriors, the sampling and the counts run through
+// bamm_seed_from_pwm; the std::mt19937 draws stay here, in sequence order.  Returns 0, or 1 + err.
+int motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
+                        const uint64_t* off, size_t n_seqs, float q, const SeedDevice* dev, std::string& err);
 int motif_init_from_bamm(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,
                          std::string& err);                                                     // Motif.cpp:336-397
 int motif_init_from_sites(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,
@@ -59,7 +66,7 @@ struct SeedSet {
 // MotifSet::MotifSet (MotifSet.cpp:3-222); tag = "PWM" | "BaMM" | "bindingsites"
 int load_seeds(const std::string& path, const std::string& tag, uint32_t l_flank, uint32_t r_flank, uint32_t K,
                const std::vector<float>& alpha, size_t max_pwm, float glob_q, const BgModel& bg, const uint32_t* yK,
-               const uint64_t* off, size_t n_seqs, SeedSet& out, std::string& err);
+               const uint64_t* off, size_t n_seqs, SeedSet& out, std::string& err, const SeedDevice* dev = nullptr);
 
 std::string base_name(const std::string& path);   // refinement/utils.h:66-85
 

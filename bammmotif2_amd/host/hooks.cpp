@@ -57,9 +57,10 @@ int bh_write_motif(const char* dir, const char* base, uint32_t W, uint32_t K, co
 }
 
 // seeds: returns the number of motifs; v_out holds motif `index` (flat), w_out its width, q_out its q
-int bh_load_seed(const char* path, const char* tag, uint32_t l_flank, uint32_t r_flank, uint32_t K, const float* alpha,
+static int load_seed_impl(const char* path, const char* tag, uint32_t l_flank, uint32_t r_flank, uint32_t K, const float* alpha,
                  uint64_t max_pwm, float glob_q, uint32_t bg_order, const float* vbg, const bamm_packed* packed,
-                 uint32_t index, uint32_t* n_motifs, uint32_t* w_out, float* q_out, float* v_out, uint64_t v_cap) {
+                 uint32_t index, uint32_t* n_motifs, uint32_t* w_out, float* q_out, float* v_out, uint64_t v_cap,
+                 const SeedDevice* dev) {
     BgModel bg;
     bg.K = bg_order;
     bg.v.assign(vbg, vbg + bamm_bg_size(bg_order));
@@ -69,7 +70,7 @@ int bh_load_seed(const char* path, const char* tag, uint32_t l_flank, uint32_t r
     for (uint64_t n = 0; n < packed->n_seqs; n++) off[n + 1] = off[n] + packed->len[n];
     SeedSet seeds;
     std::vector<float> al(alpha, alpha + K + 1);
-    if (load_seeds(path, tag, l_flank, r_flank, K, al, max_pwm, glob_q, bg, yK.data(), off.data(), packed->n_seqs, seeds, g_err)) return 1;
+    if (load_seeds(path, tag, l_flank, r_flank, K, al, max_pwm, glob_q, bg, yK.data(), off.data(), packed->n_seqs, seeds, g_err, dev)) return 1;
     *n_motifs = (uint32_t)seeds.motifs.size();
     if (index >= seeds.motifs.size()) { g_err = "motif index out of range"; return 1; }
     const Motif& m = seeds.motifs[index];
@@ -78,6 +79,24 @@ int bh_load_seed(const char* path, const char* tag, uint32_t l_flank, uint32_t r
     if (m.v.size() > v_cap) { g_err = "v buffer too small"; return 1; }
     memcpy(v_out, m.v.data(), m.v.size() * sizeof(float));
     return 0;
+}
+
+int bh_load_seed(const char* path, const char* tag, uint32_t l_flank, uint32_t r_flank, uint32_t K, const float* alpha,
+                 uint64_t max_pwm, float glob_q, uint32_t bg_order, const float* vbg, const bamm_packed* packed,
+                 uint32_t index, uint32_t* n_motifs, uint32_t* w_out, float* q_out, float* v_out, uint64_t v_cap) {
+    return load_seed_impl(path, tag, l_flank, r_flank, K, alpha, max_pwm, glob_q, bg_order, vbg, packed, index, n_motifs,
+                          w_out, q_out, v_out, v_cap, nullptr);
+}
+
+// the same with initFromPWM's pass over the sequences on the device (ctx / seqs: the uploaded `packed`)
+int bh_load_seed_dev(const char* path, const char* tag, uint32_t l_flank, uint32_t r_flank, uint32_t K, const float* alpha,
+                     uint64_t max_pwm, float glob_q, uint32_t bg_order, const float* vbg, const bamm_packed* packed,
+                     uint32_t index, uint32_t* n_motifs, uint32_t* w_out, float* q_out, float* v_out, uint64_t v_cap,
+                     bamm_ctx* ctx, bamm_seqs* seqs) {
+    SeedDevice dev;
+    dev.ctx = ctx; dev.seqs = seqs;
+    return load_seed_impl(path, tag, l_flank, r_flank, K, alpha, max_pwm, glob_q, bg_order, vbg, packed, index, n_motifs,
+                          w_out, q_out, v_out, v_cap, &dev);
 }
 
 const char* bh_base_name(const char* path) {

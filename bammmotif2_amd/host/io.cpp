@@ -203,8 +203,8 @@ static void orders_from_counts(Motif& m, const std::vector<int>& n, bool order0_
         }
 }
 
-void motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
-                         const uint64_t* off, size_t n_seqs, float q) {
+int motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
+                        const uint64_t* off, size_t n_seqs, float q, const SeedDevice* dev, std::string& err) {
     const uint32_t W = m.W, K = m.K;
     m.q = q;
     std::vector<int> n(bamm_v_size(K, W), 0);
@@ -221,6 +221,21 @@ void motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel&
     for (size_t y = 0; y < 4; y++)
         for (uint32_t j = 0; j < W; j++) score[y * W + j] = m.v[y * W + j] / bg.v[y];
     std::mt19937 rngx;                                        // default-seeded on purpose (Motif.cpp:237)
+    if (dev) {
+        // device path: only the uniform variates are serial.  std::discrete_distribution::operator()
+        // draws exactly one std::generate_canonical<double,53> per call (libstdc++ bits/random.tcc),
+        // and the reference calls it once per sequence with L >= W, in sequence order.
+        std::vector<double> u(n_seqs ? n_seqs : 1, 0.0);
+        for (size_t s = 0; s < n_seqs; s++)
+            if (off[s + 1] - off[s] >= W) u[s] = std::generate_canonical<double, 53>(rngx);
+        if (bamm_seed_from_pwm(dev->ctx, dev->seqs, K, W, score.data(), q, u.data(), n.data(), nullptr)) {
+            err = std::string("PWM seeding on the device failed: ") + bamm_last_error();
+            return 1;
+        }
+        orders_from_counts(m, n, false, 0, bg);
+        motif_calculate_p(m, bg);
+        return 0;
+    }
     // The posteriors of different sequences are independent, the draws are not (one RNG stream, in
     // sequence order): posteriors are computed for a block of sequences in parallel, then sampled
     // serially -- same results as the reference's loop run with one thread.
@@ -261,6 +276,8 @@ void motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel&
     }
     orders_from_counts(m, n, false, 0, bg);
     motif_calculate_p(m, bg);
+    (void)err;
+    return 0;
 }
 
 int motif_init_from_bamm(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,
@@ -340,7 +357,7 @@ int motif_write(const std::string& dir, const std::string& basename, const Motif
 // -------------------------------------------------------------------------------- seeds ----
 int load_seeds(const std::string& path, const std::string& tag, uint32_t l_flank, uint32_t r_flank, uint32_t K,
                const std::vector<float>& alpha, size_t max_pwm, float glob_q, const BgModel& bg, const uint32_t* yK,
-               const uint64_t* off, size_t n_seqs, SeedSet& out, std::string& err) {
+               const uint64_t* off, size_t n_seqs, SeedSet& out, std::string& err, const SeedDevice* dev) {
     out = SeedSet();
     std::ifstream file(path.c_str());
     if (tag == "bindingsites") {
@@ -380,7 +397,7 @@ int load_seeds(const std::string& path, const std::string& tag, uint32_t l_flank
                 std::stringstream number(row);
                 for (size_t y = 0; y < 4; y++) number >> pwm[y * length + j];
             }
-            motif_init_from_pwm(m, pwm, bg, yK, off, n_seqs, q);
+            if (motif_init_from_pwm(m, pwm, bg, yK, off, n_seqs, q, dev, err)) return 1;
             out.max_w = std::max(out.max_w, m.W);
             out.motifs.push_back(std::move(m));
             if (out.motifs.size() >= max_pwm) break;

@@ -287,14 +287,27 @@ int main(int nargs, char* args[]) {
     stage("background model");
 
     if (o.verbose) std::cout << std::endl << "***************************" << std::endl << "*   Initial Motif Model   *" << std::endl << "***************************" << std::endl;
-    std::vector<uint32_t> yK(packed->total_len ? packed->total_len : 1);
-    if (bamm_unpack_y(packed, o.K, yK.data())) die_abi("unpack");
     std::vector<uint64_t> off(pos.size() + 1, 0);
     for (size_t n = 0; n < pos.size(); n++) off[n + 1] = off[n] + packed->len[n];
+    const bool need_gpu = o.EM || o.score || o.FDR;
+    bamm_ctx* ctx = nullptr;
+    bamm_seqs* dseqs_all = nullptr;                          // every positive record, resident (seeding, then EM)
+    SeedDevice seed_dev;
+    std::vector<uint32_t> yK;
+    if (need_gpu && o.seed_tag == "PWM" && !getenv("BAMM_HOST_SEEDING")) {
+        // Motif::initFromPWM's pass over the sequences runs on the device: upload first
+        if (bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
+        if (bamm_seqs_upload(ctx, packed, 0, packed->n_seqs, &dseqs_all)) die_abi("upload");
+        seed_dev.ctx = ctx; seed_dev.seqs = dseqs_all;
+        stage("device context + upload of the positives");
+    } else if (o.seed_tag == "PWM") {
+        yK.resize(packed->total_len ? packed->total_len : 1);
+        if (bamm_unpack_y(packed, o.K, yK.data())) die_abi("unpack");
+    }
     SeedSet seeds;
     // MotifSet hands Global::bgModelOrder and the model's v to every Motif (mainBaMM.cpp:60-70)
     if (load_seeds(o.seed_file, o.seed_tag, (uint32_t)o.extend[0], (uint32_t)o.extend[1], o.K, o.alpha, o.maxPWM, o.q, bg,
-                   yK.data(), off.data(), pos.size(), seeds, err)) die(err);
+                   yK.empty() ? nullptr : yK.data(), off.data(), pos.size(), seeds, err, seed_dev.ctx ? &seed_dev : nullptr)) die(err);
     stage("seed models (initFromPWM / BaMM / sites)");
 
     // drop sequences shorter than the widest motif (mainBaMM.cpp:75-83)
@@ -304,15 +317,13 @@ int main(int nargs, char* args[]) {
     if (posN < o.cvFold) { std::cerr << "There are " << posN << " sequences longer than input motif. Exit!\n"; exit(1); }
 
     if (o.verbose) std::cout << std::endl << "*********************" << std::endl << "*   BaMM Training   *" << std::endl << "*********************" << std::endl;
-    bamm_ctx* ctx = nullptr;
     bamm_seqs* dseqs = nullptr;
-    const bool need_gpu = o.EM || o.score || o.FDR;
     bamm_seqs* dneg = nullptr;
     std::vector<uint8_t> neg_codes;
     std::vector<uint64_t> neg_off{0};
     std::vector<uint32_t> kept_len;
     if (need_gpu) {
-        if (bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
+        if (!ctx && bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
         bamm_packed* use = packed;
         bamm_packed* filtered = nullptr;
         if (posN != pos.size()) {                            // re-pack only the kept records; kmers are position-local
@@ -325,7 +336,13 @@ int main(int nargs, char* args[]) {
             if (bamm_pack_kmers(km.data(), kept_off.data(), kept_off.size() - 1, &filtered)) die_abi("re-pack");
             use = filtered;
         }
-        if (bamm_seqs_upload(ctx, use, 0, use->n_seqs, &dseqs)) die_abi("upload");
+        if (dseqs_all && use == packed) {
+            dseqs = dseqs_all;                               // nothing was dropped: the seeding copy is the training set
+        } else {
+            if (dseqs_all) bamm_seqs_destroy(dseqs_all);
+            if (bamm_seqs_upload(ctx, use, 0, use->n_seqs, &dseqs)) die_abi("upload");
+        }
+        dseqs_all = nullptr;
         kept_len.assign(use->len, use->len + use->n_seqs);
         stage("device context + upload of the positives");
         if (o.score || o.FDR) {

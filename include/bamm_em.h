@@ -189,6 +189,17 @@ int  bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches);
  * and through the one-column-at-a-time kernel (kernels.hip), and the kernel launches per pass. */
 int  bamm_em_plan(bamm_em* em, uint64_t* grouped_seqs, uint64_t* percolumn_seqs, uint32_t* launches);
 
+/* ------------------------------------------------------------------ seeding ------------- */
+/* The pass over the sequences of Motif::initFromPWM (Motif.cpp:228-311): 0th-order posterior of
+ * every window, one motif start sampled per sequence, integer k-mer counts of the sampled sites
+ * for the orders 0..K.  score = floored PWM / 0th-order background, [4][W] (Motif.cpp:205-226).
+ * u[n]: the uniform variate the reference's std::discrete_distribution would draw for sequence n
+ * (std::generate_canonical<double,53> on the default-seeded std::mt19937 of Motif.cpp:237, drawn
+ * in sequence order for the sequences with L >= W only).  counts: v_size(K,W) ints, flat
+ * [k][y][j].  z (may be NULL): the sampled index per sequence, 0 = no motif, i = window i-1.   */
+int  bamm_seed_from_pwm(bamm_ctx* ctx, bamm_seqs* seqs, uint32_t K, uint32_t W, const float* score,
+                        float q, const double* u, int32_t* counts, uint32_t* z);
+
 /* ------------------------------------------------------------------ scorer -------------- */
 /* ScoreSeqSet::calcLogOdds (ScoreSeqSet.cpp:25-67) with Motif::calculateLogS
  * (Motif.cpp:471-483).  mops (may be NULL): concatenated L-W+1 scores per sequence;
