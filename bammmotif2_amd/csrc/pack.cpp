@@ -6,7 +6,10 @@
 // base by rand()%4 independently for every (position, digit) term
 // (/root/reference/src/init/Sequence.cpp:35-41).
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +33,32 @@ void set_error(const char* fmt, ...) {
 }  // namespace bamm
 
 using namespace bamm;
+
+namespace {
+
+std::atomic<uint32_t> g_host_threads{0};
+
+uint32_t host_threads() {
+    uint32_t n = g_host_threads.load();
+    if (n) return n;
+    n = std::thread::hardware_concurrency();
+    return std::max(1u, std::min(n ? n : 1u, 8u));      // unset: a modest default, the CLI passes --threads
+}
+
+// fn(thread, begin, end) over contiguous, ordered ranges of [0, n)
+template <class F>
+void parallel_ranges(uint64_t n, uint32_t T, F&& fn) {
+    if (T <= 1 || n < 2) { fn(0u, uint64_t(0), n); return; }
+    std::vector<std::thread> th;
+    th.reserve(T);
+    for (uint32_t t = 0; t < T; t++) {
+        const uint64_t a = n * t / T, b2 = n * (t + 1) / T;
+        th.emplace_back([&fn, t, a, b2]() { fn(t, a, b2); });
+    }
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -93,11 +122,17 @@ struct PackBuilder {
 
     // km[i] = kmer_[i] as the reference holds it (any multiple of 4^11 may be added)
     void add(uint64_t n, const uint64_t* km) {
+        p->exc_off[n] = epos.size();
+        add_to(n, km, epos, ekmer, eclean);
+    }
+    // the same with the exceptions appended to the caller's vectors (one set per worker thread);
+    // the words of different sequences never overlap
+    void add_to(uint64_t n, const uint64_t* km, std::vector<uint32_t>& epos, std::vector<uint32_t>& ekmer,
+                std::vector<uint32_t>& eclean) const {
         const uint32_t MASK22 = (1u << 22) - 1u;
         const uint32_t L = p->len[n];
         uint32_t* w = p->words + p->word_off[n];
         uint32_t clean = 0;
-        p->exc_off[n] = epos.size();
         for (uint32_t i = 0; i < L; i++) {
             const uint32_t k22 = (uint32_t)(km[i] & MASK22);
             const uint32_t base = k22 & 3u;                       // digit 0 = base at i
@@ -145,6 +180,8 @@ static int pack_impl(const uint64_t* const* ptrs, const uint64_t* flat, const ui
     return BAMM_OK;
 }
 
+void bamm_set_host_threads(uint32_t n) { g_host_threads.store(n); }
+
 int bamm_pack_kmers(const uint64_t* kmer, const uint64_t* off, uint64_t n_seqs, bamm_packed** out) {
     return pack_impl(nullptr, kmer, off, n_seqs, out);
 }
@@ -178,41 +215,78 @@ int bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, 
     PackBuilder b;
     int rc = b.begin(n_seqs, lens);
     if (rc) return rc;
-    std::vector<uint8_t> seq(maxL + 1);
-    std::vector<uint64_t> km(maxL + 1);
-    for (uint64_t n = 0; n < n_seqs; n++) {
-        const uint8_t* c = codes + off[n];
-        const uint64_t L0 = off[n + 1] - off[n], L = lens[n];
-        if (single_strand) {
-            memcpy(seq.data(), c, L0);
-        } else {
-            for (uint64_t i = 0; i < L0; i++) {
-                seq[i] = c[i];
-                const uint8_t x = c[i];
-                seq[2 * L0 - i] = (x >= 1 && x <= 4) ? (uint8_t)(5 - x) : (uint8_t)'N';
-            }
-            seq[L0] = 0;
+    // The only serial part is the libc rand() stream: an unknown base at position z is drawn once per
+    // (position, digit) term that sees it, i.e. min(11, L - z) times, in position order.  The draws of
+    // the whole set are taken up front, in the reference's order; the encoding itself then runs on
+    // several host threads, each sequence reading its own slice of the draws.
+    const uint32_t T = std::max<uint32_t>(1, std::min<uint64_t>(host_threads(), n_seqs ? n_seqs : 1));
+    std::vector<uint64_t> doff(n_seqs + 1, 0);
+    parallel_ranges(n_seqs, T, [&](uint32_t, uint64_t n0, uint64_t n1) {
+        for (uint64_t n = n0; n < n1; n++) {
+            const uint8_t* c = codes + off[n];
+            const uint64_t L0 = off[n + 1] - off[n], L = lens[n];
+            uint64_t d = 0;
+            for (const uint8_t* z = (const uint8_t*)memchr(c, 0, L0); z; z = (const uint8_t*)memchr(z + 1, 0, (size_t)(c + L0 - z - 1)))
+                d += std::min<uint64_t>(11, L - (uint64_t)(z - c));
+            if (!single_strand) d += std::min<uint64_t>(11, L - L0);   // the separator behind the forward strand
+            doff[n + 1] = d;
         }
-        uint64_t roll = 0;
-        int64_t special_until = -1;                      // last position still seeing a special byte
-        for (uint64_t i = 0; i < L; i++) {
-            const uint8_t x = seq[i];
-            if (x == 0 || x > 4) special_until = (int64_t)i + 10;
-            if ((int64_t)i <= special_until) {
-                uint64_t acc = 0;
-                for (uint64_t k = (i < 10 ? i + 1 : 11); k > 0; k--) {
-                    const uint8_t cc = seq[i - k + 1];
-                    const uint64_t digit = (cc == 0) ? (uint64_t)rand() % 4 : (uint64_t)(cc - 1);
-                    acc += digit << (2 * (k - 1));
-                }
-                km[i] = acc;
-                roll = acc;
+    });
+    for (uint64_t n = 0; n < n_seqs; n++) doff[n + 1] += doff[n];
+    std::vector<uint8_t> draws(doff[n_seqs] ? doff[n_seqs] : 1);
+    for (uint64_t d = 0; d < doff[n_seqs]; d++) draws[d] = (uint8_t)(rand() % 4);
+
+    struct Local { std::vector<uint32_t> epos, ekmer, eclean; uint64_t n0 = 0, n1 = 0; };
+    std::vector<Local> loc(T);
+    std::vector<uint32_t> ecount(n_seqs ? n_seqs : 1, 0);
+    parallel_ranges(n_seqs, T, [&](uint32_t t, uint64_t n0, uint64_t n1) {
+        Local& me = loc[t];
+        me.n0 = n0; me.n1 = n1;
+        std::vector<uint8_t> seq(maxL + 1);
+        std::vector<uint64_t> km(maxL + 1);
+        for (uint64_t n = n0; n < n1; n++) {
+            const uint8_t* c = codes + off[n];
+            const uint64_t L0 = off[n + 1] - off[n], L = lens[n];
+            const uint8_t* dr = draws.data() + doff[n];
+            if (single_strand) {
+                memcpy(seq.data(), c, L0);
             } else {
-                roll = ((roll << 2) | (uint64_t)(x - 1)) & ((1ull << 22) - 1);
-                km[i] = roll;
+                for (uint64_t i = 0; i < L0; i++) {
+                    seq[i] = c[i];
+                    const uint8_t x = c[i];
+                    seq[2 * L0 - i] = (x >= 1 && x <= 4) ? (uint8_t)(5 - x) : (uint8_t)'N';
+                }
+                seq[L0] = 0;
             }
+            uint64_t roll = 0;
+            int64_t special_until = -1;                      // last position still seeing a special byte
+            for (uint64_t i = 0; i < L; i++) {
+                const uint8_t x = seq[i];
+                if (x == 0 || x > 4) special_until = (int64_t)i + 10;
+                if ((int64_t)i <= special_until) {
+                    uint64_t acc = 0;
+                    for (uint64_t k = (i < 10 ? i + 1 : 11); k > 0; k--) {
+                        const uint8_t cc = seq[i - k + 1];
+                        const uint64_t digit = (cc == 0) ? (uint64_t)*dr++ : (uint64_t)(cc - 1);
+                        acc += digit << (2 * (k - 1));
+                    }
+                    km[i] = acc;
+                    roll = acc;
+                } else {
+                    roll = ((roll << 2) | (uint64_t)(x - 1)) & ((1ull << 22) - 1);
+                    km[i] = roll;
+                }
+            }
+            const size_t before = me.epos.size();
+            b.add_to(n, km.data(), me.epos, me.ekmer, me.eclean);
+            ecount[n] = (uint32_t)(me.epos.size() - before);
         }
-        b.add(n, km.data());
+    });
+    for (uint64_t n = 0; n < n_seqs; n++) b.p->exc_off[n + 1] = b.p->exc_off[n] + ecount[n];
+    for (uint32_t t = 0; t < T; t++) {                       // ranges are contiguous and in thread order
+        b.epos.insert(b.epos.end(), loc[t].epos.begin(), loc[t].epos.end());
+        b.ekmer.insert(b.ekmer.end(), loc[t].ekmer.begin(), loc[t].ekmer.end());
+        b.eclean.insert(b.eclean.end(), loc[t].eclean.begin(), loc[t].eclean.end());
     }
     *out = b.finish();
     return BAMM_OK;

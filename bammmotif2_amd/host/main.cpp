@@ -229,6 +229,7 @@ Options parse(int nargs, char** args) {
     o.advanceEM = a.present(0, "advanceEM");
     a.get(0, "threads", o.threads);
     omp_set_num_threads((int)std::max<size_t>(1, o.threads));   // Global.cpp:331-333 (default 4)
+    bamm_set_host_threads((uint32_t)std::max<size_t>(1, o.threads));
     // extensions of this build (the reference advertises but never parses the first two, Global.cpp:479-491)
     a.get(0, "maxEMIterations", o.max_iter);
     a.get('e', "epsilon", o.epsilon);

@@ -86,6 +86,9 @@ int  bamm_pack_kmer_ptrs(const uint64_t* const* kmer_ptrs, const uint64_t* L, ui
  * the caller's srand(42) (mainBaMM.cpp:22) the result equals packing the reference's kmer_.   */
 int  bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
                      bamm_packed** out);
+/* host threads the packing helpers may use (0 = a default of at most 8); the result never depends
+ * on it: the rand() draws are taken serially, in the reference's order                        */
+void bamm_set_host_threads(uint32_t n);
 /* inverse (host): rebuild kmer_[i] mod 4^(K+1) for every position -- used by tests          */
 int  bamm_unpack_y(const bamm_packed* p, uint32_t K, uint32_t* y_out /* [total_len] */);
 void bamm_packed_free(bamm_packed* p);
