@@ -40,6 +40,22 @@ def test_pack_roundtrip_matches_reference_kmers(spec, orc, lib):
         assert pk.n_exceptions >= c.N
 
 
+@pytest.mark.parametrize("threads", [1, 3, 8])
+def test_packing_does_not_depend_on_host_threads(threads, orc, lib):
+    """bamm_pack_codes takes the rand() draws serially in the reference's order (Sequence.cpp:35-41) and
+    encodes on several threads: same words, same exceptions, equal to the reference's kmer_."""
+    c = Case(name="pk_thr", N=257, L0=70, W=8, K=2, n_frac=0.03, ragged=60)
+    _, kmer, off, _ = c.encode(orc)
+    lib.bamm_set_host_threads(threads)
+    try:
+        pk = bm.PackedSeqs.from_codes(c.codes, c.in_off, False, seed=42)
+    finally:
+        lib.bamm_set_host_threads(0)
+    assert np.array_equal(pk.unpack_y(10).astype(np.uint64), kmer % np.uint64(4 ** 11))
+    ref = bm.PackedSeqs.from_kmers(kmer, off)
+    assert np.array_equal(pk.words, ref.words) and pk.n_exceptions == ref.n_exceptions
+
+
 @pytest.mark.parametrize("spec", SMALL_CASES[:4], ids=[d["name"] for d in SMALL_CASES[:4]])
 def test_bg_model_matches_oracle(spec, orc, lib):
     c = Case(**spec)
