@@ -131,6 +131,8 @@ struct bamm_em {
     bool sliced = false;
     std::vector<std::pair<uint32_t, uint32_t>> e_slices, m_slices;
     uint32_t m_slice_logc = 0;
+    bool e_fused = false;                       // the E pass of the sliced path is k_em_seq (whole odds table in LDS)
+    uint32_t m_slice_cap = 0;                   // sparse list capacity per wave in the M-slices (0 = dense)
     float* d_state = nullptr;                   // one float per position slot: E-chain state, then r
     ExcK* exc = nullptr;
     bool estep_done = false;
@@ -336,12 +338,29 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
             rc = launch_fused(em, bk, accum, false, a, threads, st);
         } else {
             a.r_out = em->d_state;
-            for (size_t i = 0; i < em->e_slices.size() && !rc; i++)
-                rc = launch_e_slice(bk.mclass, a, em->e_slices[i].first, em->e_slices[i].second,
-                                    i + 1 == em->e_slices.size(), bk.blocks, threads, st);
+            if (em->e_fused) {
+                // the whole odds table fits LDS (only the count table does not): the fused kernel's E
+                // pass, leaving r in the reference's layout (k_em_seq WRITE_R)
+                a.seq_end = (uint32_t)s->n;
+                a.logC = 0; a.sparse_cap = 0; a.sparse_wave_bytes = 0;
+                rc = launch_em_seq(bk.mclass, false, true, a, bk.blocks, threads, st);
+            } else {
+                for (size_t i = 0; i < em->e_slices.size() && !rc; i++)
+                    rc = launch_e_slice(bk.mclass, a, em->e_slices[i].first, em->e_slices[i].second,
+                                        i + 1 == em->e_slices.size(), bk.blocks, threads, st);
+            }
             a.logC = em->m_slice_logc;
+            {   // this bucket's list capacity: what fits next to the widest slice's count table
+                uint32_t widest = 0;
+                for (auto& sl : em->m_slices) widest = std::max(widest, sl.second - sl.first);
+                const size_t table = m_slice_lds_bytes(widest, em->Y, em->m_slice_logc);
+                uint32_t cap = em->m_slice_cap;
+                while (cap && table + (threads / 64u) * m_slice_wave_bytes(kMClasses[bk.mclass], cap) > 160u * 1024u) cap -= 64u;
+                a.sparse_cap = cap;
+                a.sparse_wave_bytes = (uint32_t)m_slice_wave_bytes(kMClasses[bk.mclass], cap);
+            }
             for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
-                rc = launch_m_slice(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second,
+                rc = launch_m_slice(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second, em->e_fused,
                                     bk.blocks, threads, st);
         }
         if (rc) return rc;
@@ -617,8 +636,21 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             return per;
         };
         cut(e_cols, em->e_slices);
+        em->e_fused = em_lds_bytes(prm->W, Y, false, 0, 0) <= kLds && !getenv("BAMM_NO_EFUSED");
+        // sparse M-slices: room for a list of 256 windows + the y of every position per wave (8 waves per
+        // block at the longest length class) is taken off the column budget when that costs no extra slice
+        const int Mmax = kMClasses[m_class_for_len(seqs->max_len ? seqs->max_len : 1)];
+        const uint32_t waves = max_threads_for_mclass(m_class_for_len(seqs->max_len ? seqs->max_len : 1)) / 64u;
+        const size_t scratch = getenv("BAMM_NO_SPARSE") ? 0 : m_slice_wave_bytes(Mmax, 256) * waves;
+        uint32_t m_cols_sparse = 0;
+        while (scratch && m_cols_sparse < prm->W && m_slice_lds_bytes(m_cols_sparse + 1, Y, 0) + scratch <= kLds) m_cols_sparse++;
+        if (m_cols_sparse && (prm->W + m_cols_sparse - 1) / m_cols_sparse == (prm->W + m_cols - 1) / m_cols) {
+            m_cols = m_cols_sparse;
+            em->m_slice_cap = 256;
+        }
         const uint32_t per_m = cut(m_cols, em->m_slices);
-        while (em->m_slice_logc < 4 && m_slice_lds_bytes(per_m, Y, em->m_slice_logc + 1) <= kLds) em->m_slice_logc++;
+        const size_t used = em->m_slice_cap ? scratch : 0;
+        while (em->m_slice_logc < 4 && m_slice_lds_bytes(per_m, Y, em->m_slice_logc + 1) + used <= kLds) em->m_slice_logc++;
     }
     hipStream_t st = c->stream;
     int rc = BAMM_OK;
@@ -1060,10 +1092,11 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         if (rc2) return rc2;
         BAMM_HIP(hipMemcpyAsync(out, em->d_state + base, total * sizeof(float), hipMemcpyDeviceToHost, st));
         BAMM_HIP(hipStreamSynchronize(st));
-        for (uint64_t n = begin; n < end; n++) {
-            float* r = out + (s->h_pos_off[n] - base);
-            std::reverse(r, r + s->h_len[n]);
-        }
+        if (!em->e_fused)
+            for (uint64_t n = begin; n < end; n++) {
+                float* r = out + (s->h_pos_off[n] - base);
+                std::reverse(r, r + s->h_len[n]);
+            }
         return BAMM_OK;
     }
     float* d_r = nullptr;

@@ -183,8 +183,9 @@ size_t e_slice_lds_bytes(uint32_t cols, uint32_t Y);
 size_t m_slice_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC);
 int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool last, uint32_t blocks,
                    uint32_t threads, hipStream_t st);
-int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads,
-                   hipStream_t st);
+size_t m_slice_wave_bytes(int M, uint32_t cap);
+int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool r_reversed, uint32_t blocks,
+                   uint32_t threads, hipStream_t st);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
                  hipStream_t st);
 int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks,

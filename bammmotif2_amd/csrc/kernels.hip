@@ -369,8 +369,11 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
     }
 }
 
+// r_reversed: the E pass left r in the reference's layout r[L-1-slot] (k_em_seq WRITE_R) instead of
+// per slot.  sparse_cap: non-zero windows of a sequence compacted into a per-wave list, as in
+// k_em_seq (a ds_add_u64 costs the same LDS cycles whether 3 or 64 lanes take part).
 template <int M, int THREADS>
-__global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0, uint32_t j1) {
+__global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0, uint32_t j1, int r_reversed) {
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;
     unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y+1][C], row Y = dump
@@ -381,6 +384,7 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t total_waves = gridDim.x * waves_per_block;
     const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+    unsigned char* wscratch = reinterpret_cast<unsigned char*>(n_lds + ((size_t)(nc * Ys) << logC)) + (size_t)wave * a.sparse_wave_bytes;
     for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
         const uint32_t seq = pick_sequence(a.sv, t);
         if (a.sv.mask && !a.sv.mask[seq]) continue;
@@ -391,28 +395,73 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
         uint32_t y[M];
         decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
         const uint32_t shift = W - j1;                               // slot offset at column j1-1
-        unsigned long long F[M], nz[M], padm[M];
-        uint32_t ya[M];
+        unsigned long long F[M];
 #pragma unroll
         for (int m = 0; m < M; m++) {
             const uint32_t slot = p0 + m + shift;
-            F[m] = to_fixed40(slot < L ? rs[slot] : 0.0f);
-            nz[m] = __ballot(F[m] != 0ull);
-            padm[m] = __ballot(y[m] != Y);
-            ya[m] = ((y[m] << logC) + copy) * 8u;
+            F[m] = to_fixed40(slot < L ? rs[r_reversed ? L - 1u - slot : slot] : 0.0f);
         }
-        const uint32_t stride = (Ys << logC) * 8u;
-        uint32_t col = lds_offset(n_lds) + (nc - 1u) * stride;
-        for (uint32_t jb = 0; jb < nc; jb += M) {
+        bool dense = true;
+        if (a.sparse_cap != 0u) {
+            const uint32_t cap = a.sparse_cap;
+            unsigned long long* list = reinterpret_cast<unsigned long long*>(wscratch);   // addend | position << 48
+            unsigned short* ybuf = reinterpret_cast<unsigned short*>(list + cap);         // [64*M]
+            uint32_t nnz = 0;
 #pragma unroll
-            for (int t = 0; t < M; t++) {
-                if (jb + t < nc) {
+            for (int m = 0; m < M; m++) {
+                const bool nzm = F[m] != 0ull;
+                const unsigned long long mask = __ballot(nzm);
+                const uint32_t at = nnz + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (nzm && at < cap) list[at] = F[m] | ((unsigned long long)(p0 + m) << 48);
+                nnz += (uint32_t)__popcll(mask);
+            }
+            if (nnz <= cap) {
+                dense = false;
 #pragma unroll
-                    for (int m = 0; m < M; m++)
-                        lds_add_slot<M>(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M], y[m] != Y);
-                    F[t] = wave_shl1_u64(F[t]);
-                    nz[t] = __ballot(F[t] != 0ull);
-                    col -= stride;
+                for (int m = 0; m < M; m++) ybuf[p0 + m] = (unsigned short)y[m];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t ecnt = (nnz + 63u) >> 6;
+                for (uint32_t e = 0; e < ecnt; e++) {
+                    const uint32_t idx = e * 64u + (uint32_t)lane;
+                    if (idx < nnz) {
+                        const unsigned long long ent = list[idx];
+                        const unsigned long long Fe = ent & 0xffffffffffffull;
+                        // the entry sits at position q in column j1-1: it is r of the window that
+                        // started at q - (j1-1); that window's column j is at q - (j1-1) + j
+                        uint32_t q = (uint32_t)(ent >> 48) + j0 + 1u - j1;
+                        unsigned long long* ncol = n_lds + copy;
+                        for (uint32_t j = j0; j < j1; j++, q++, ncol += (Ys << logC)) {
+                            const uint32_t yq = ybuf[q];
+                            if (yq != Y) atomicAdd(&ncol[yq << logC], Fe);
+                        }
+                    }
+                }
+            }
+        }
+        if (dense) {
+            unsigned long long nz[M], padm[M];
+            uint32_t ya[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                nz[m] = __ballot(F[m] != 0ull);
+                padm[m] = __ballot(y[m] != Y);
+                ya[m] = ((y[m] << logC) + copy) * 8u;
+            }
+            const uint32_t stride = (Ys << logC) * 8u;
+            uint32_t col = lds_offset(n_lds) + (nc - 1u) * stride;
+            for (uint32_t jb = 0; jb < nc; jb += M) {
+#pragma unroll
+                for (int t2 = 0; t2 < M; t2++) {
+                    if (jb + t2 < nc) {
+#pragma unroll
+                        for (int m = 0; m < M; m++)
+                            lds_add_slot<M>(col + ya[m], F[(m + t2) % M], padm[m], nz[(m + t2) % M], y[m] != Y);
+                        F[t2] = wave_shl1_u64(F[t2]);
+                        nz[t2] = __ballot(F[t2] != 0ull);
+                        col -= stride;
+                    }
                 }
             }
         }
@@ -724,6 +773,8 @@ size_t e_slice_lds_bytes(uint32_t cols, uint32_t Y) {
     return ((((size_t)cols * (Y + 1)) + 1) & ~size_t(1)) * sizeof(float) + 16 * 3 * sizeof(double);
 }
 size_t m_slice_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC) { return (((size_t)cols * (Y + 1)) << logC) * 8; }
+// per-wave scratch of the sparse M-slice: [cap x u64 list][64*M x u16 y]
+size_t m_slice_wave_bytes(int M, uint32_t cap) { return cap ? (((size_t)cap * 8 + (size_t)64 * M * 2 + 15) & ~size_t(15)) : 0; }
 
 int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool last, uint32_t blocks,
                    uint32_t threads, hipStream_t st) {
@@ -745,9 +796,9 @@ int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
     return BAMM_OK;
 }
 
-int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads,
-                   hipStream_t st) {
-    const size_t lds = m_slice_lds_bytes(j1 - j0, a.Y, a.logC);
+int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool r_reversed, uint32_t blocks,
+                   uint32_t threads, hipStream_t st) {
+    const size_t lds = m_slice_lds_bytes(j1 - j0, a.Y, a.logC) + (size_t)a.sparse_wave_bytes * (threads / 64u);
     if (lds > 160 * 1024 || j1 <= j0) { set_error("bad M slice [%u,%u)", j0, j1); return BAMM_ERR_UNSUPPORTED; }
     switch (mclass) {
 #define X(idx, M, T)                                                                                   \
@@ -755,7 +806,7 @@ int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
         if (lds > 64 * 1024)                                                                           \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m_slice<M, T>),                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        hipLaunchKernelGGL((k_m_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1);        \
+        hipLaunchKernelGGL((k_m_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1, r_reversed ? 1 : 0); \
         break;
         BAMM_FOR_EACH_MCLASS(X)
 #undef X
