@@ -50,9 +50,16 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int I> struct IntC { static constexpr int value = I; };
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {           // f(IntC<0>{}), f(IntC<1>{}), ... : compile-time indices
+    if constexpr (I < N) { f(IntC<I>{}); static_for<N, I + 1>(f); }
+}
+
+template <int OFF>
 __device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
-    asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %0, %1\n\ts_mov_b64 exec, -1"
-                 :: "v"(byte_addr), "v"(v), "s"(mask) : "memory");
+    asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+                 :: "v"(byte_addr), "v"(v), "s"(mask), "n"(OFF) : "memory");
 }
 
 template <int OFF>
@@ -145,7 +152,9 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Rtot][Tq][4]
     float* s1 = reinterpret_cast<float*>(lds_raw + g.off_s1);                             // [W][Y+1]
     double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
-    unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);   // [T][Rtot][C]
+    // count table [Rtot][C][T], groups stored last to first: the M-step walks them in that order and
+    // reaches a (row, copy)'s next group through the add's immediate offset
+    unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);
     unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]: counts of the virtual rows
     const uint32_t logC = ACCUM ? a.logC : 0u;
 
@@ -187,7 +196,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
     const uint32_t vbase = g.R0 + wave * g.Bv;
     const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
-    const uint32_t strideT = (Rtot << logC) * 8u;
 
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0;
@@ -370,32 +378,33 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 
             {
                 unsigned long long nz[M];
-                uint32_t rad[M];                             // byte offset of (row, private copy) inside a group table
+                uint32_t rad[M];                             // byte address of (row, private copy), group T-1
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
-                    rad[m] = ((row[m] << logC) + copy) * 8u;
+                    rad[m] = ng_base + (((row[m] << logC) + copy) * T) * 8u;
                 }
-                uint32_t col = ng_base + (T - 1u) * strideT;
                 // F is a ring: after s steps logical slot m lives in F[(m + G*s) mod M]; the G slots
-                // that arrive from the next lane are shifted in place with one DPP pair each
+                // that arrive from the next lane are shifted in place with one DPP pair each, and their
+                // non-zero masks with them (lane l takes lane l+1's value: mask >> 1)
                 for (uint32_t sb = 0; sb < T; sb += M) {
-#pragma unroll
-                    for (int u = 0; u < M; u++) {
+                    static_for<M>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
                         if (sb + u < T) {
-                            const int off = (G * u) % M;
+                            constexpr int off = (G * u) % M;
 #pragma unroll
                             for (int m = 0; m < M; m++)
-                                lds_add_u64_exec(col + rad[m], F[(m + off) % M], nz[(m + off) % M]);
+                                lds_add_u64_exec<8 * u>(rad[m], F[(m + off) % M], nz[(m + off) % M]);
 #pragma unroll
                             for (int c = 0; c < G; c++) {
                                 const int idx = (M - G + c + G * (u + 1)) % M;
                                 F[idx] = wave_shl1_u64(F[idx]);
-                                nz[idx] = __ballot(F[idx] != 0ull);
+                                nz[idx] >>= 1;
                             }
-                            col -= strideT;
                         }
-                    }
+                    });
+#pragma unroll
+                    for (int m = 0; m < M; m++) rad[m] += 8u * M;
                 }
             }
             // ---- virtual count rows -> single-column bins (exact: one window per cell)
@@ -403,8 +412,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 wave_lds_sync();
                 if (fix) {
                     unsigned long long acc = 0ull;
-                    unsigned long long* cell = ng + (((size_t)lane_t * Rtot + vbase + lane_b) << logC);
-                    for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[c]; cell[c] = 0ull; }
+                    unsigned long long* cell = ng + ((size_t)((vbase + lane_b) << logC)) * T + (T - 1u - lane_t);
+                    for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[(size_t)c * T]; cell[(size_t)c * T] = 0ull; }
                     if (acc != 0ull) {
 #pragma unroll
                         for (int c = 0; c < G; c++) {
@@ -433,7 +442,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             const uint32_t j = i / Y, yy = i - j * Y;
             const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
             unsigned long long acc = n1[i];
-            const unsigned long long* tab = ng + (((size_t)t * Rtot) << logC);
+            const unsigned long long* tab = ng + (T - 1u - t);          // + ((row << logC) + copy) * T
             // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free
             {
                 const uint32_t lowd = 2u * ((uint32_t)G - 1u - c);
@@ -442,7 +451,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
                         // h digits above y overlap y's own upper digits unless c digits are really free:
                         // the (K+G)-mer has exactly c digits above y_c, so the mask above is a no-op
-                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[((size_t)row << logC) + cc];
+                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
                     }
             }
 #pragma unroll
@@ -453,7 +462,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     for (uint32_t h = 0; h < (1u << (2u * c)); h++)
                         for (uint32_t l = 0; l < (1u << lowd); l++) {
                             const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
-                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[((size_t)row << logC) + cc];
+                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
                         }
                 }
             }
