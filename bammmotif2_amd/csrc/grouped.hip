@@ -29,11 +29,11 @@
 // (groups first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
 //
 // Things measured and left out: a compacted list of the non-zero windows for
-// the M-step (its scratch does not fit next to the 1024-row tables, and at 256 rows it is no faster
-// than the dense walk here); the virtual-row counts as no-return atomics on an HBM table instead of
-// the LDS one (+0.19 ms per pass: ~20 L2 atomics per sequence); per-step guards on the run-time
-// group count in the E-chain (each merge point costs M register moves: the chain is straight-line
-// over padded neutral slots instead).
+// the M-step (built three ways; an LDS add costs in proportion to its active lanes, so 14 full adds
+// plus the list's writes, row reads and waits never beat the 49 sparse ones); the virtual-row counts
+// as no-return atomics on an HBM table instead of the LDS one (+0.19 ms per pass); per-step guards on
+// the run-time group count in the E-chain (each merge point costs M register moves: the chain is
+// straight-line over padded neutral slots instead).
 
 #include "device_utils.h"
 
