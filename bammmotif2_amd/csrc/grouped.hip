@@ -161,20 +161,24 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // ---- block prologue: single-column table, grouped table, zeroed counts
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < T * (Rn + 1u); i += blockDim.x) {
-        const uint32_t t = i / (Rn + 1u), row = i - t * (Rn + 1u);
+    for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
         uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
         if (row < g.Rf) { nreal = G; code = row; }
 #pragma unroll
         for (int d = 0; d < G - 1; d++)
             if (row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = G - 1 - d; code = row - g.base[d]; }
-        float f = 1.0f;
+        uint32_t yc[G];
 #pragma unroll
-        for (int c = 0; c < G; c++) {
-            const int col = (int)(G * t + c) - (int)delta;
-            if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + ((code >> (2u * (nreal - 1u - c))) & (Y - 1u))];
+        for (int c = 0; c < G; c++) yc[c] = (code >> (2u * ((nreal - 1u - c) & 15u))) & (Y - 1u);
+        for (uint32_t t = 0; t < T; t++) {
+            float f = 1.0f;
+#pragma unroll
+            for (int c = 0; c < G; c++) {
+                const int col = (int)(G * t + c) - (int)delta;
+                if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
+            }
+            sg[row * g.rowstride + pad + t] = f;
         }
-        sg[row * g.rowstride + pad + t] = f;
     }
     // neutral slots of every row, and the virtual rows as a whole (their real slots are rewritten per sequence)
     for (uint32_t i = threadIdx.x; i < Rtot * g.rowstride; i += blockDim.x) {
