@@ -1,5 +1,7 @@
 // Evaluation side of the BaMMmotif drop-in: negative-set sampler, FDR / PR statistics and window
 // p-values.  Restated from the reference lines cited in bamm_host.h; fp32 expression order kept.
+#include <omp.h>
+
 #include <algorithm>
 #include <charconv>
 #include <cassert>
@@ -234,6 +236,44 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
         for (size_t i = 0; i < n_seqs; i++) total += (off[i + 1] - off[i]) * m_fold;
         codes_out.reserve(total);
         off_out.reserve(n_seqs * m_fold + 1);
+    }
+    // Every negative consumes exactly L draws of the one rand() stream, in order, so where each positive
+    // sequence's draws start is known up front.  With the restated generator (stream.fast) the stream
+    // is cut into contiguous ranges: a serial pass only advances the generator to record the state at
+    // every range start, then the ranges are sampled on separate threads -- same draws, same negatives.
+    std::vector<uint64_t> d0(n_seqs + 1, 0);
+    for (size_t i = 0; i < n_seqs; i++) d0[i + 1] = d0[i] + (uint64_t)(off[i + 1] - off[i]) * m_fold;
+    const int threads = omp_get_max_threads();
+    if (g.stream.fast && threads > 1 && n_seqs >= 256) {
+        const size_t P = (size_t)threads;
+        std::vector<size_t> first(P + 1, n_seqs);
+        first[0] = 0;
+        for (size_t p = 1; p < P; p++)                        // ranges of about equal numbers of draws
+            first[p] = (size_t)(std::lower_bound(d0.begin(), d0.end(), d0[n_seqs] * p / P) - d0.begin());
+        for (size_t p = 1; p <= P; p++) first[p] = std::max(first[p], first[p - 1]);
+        first[P] = n_seqs;
+        std::vector<decltype(g.stream)> start(P, g.stream);
+        for (size_t p = 0; p < P; p++) {
+            start[p] = g.stream;
+            for (uint64_t k = d0[first[p + 1]] - d0[first[p]]; k > 0; k--) (void)g.stream.next_fast();
+        }
+        codes_out.assign((size_t)d0[n_seqs], 0);
+        off_out.resize(n_seqs * m_fold + 1);
+        for (size_t i = 0; i < n_seqs; i++)
+            for (size_t f = 0; f < m_fold; f++) off_out[i * m_fold + f + 1] = d0[i] + (off[i + 1] - off[i]) * (f + 1);
+#pragma omp parallel for schedule(static, 1)
+        for (long p = 0; p < (long)P; p++) {
+            NegSampler w = g;                                  // own tables (rescale writes them), own stream position
+            w.stream = start[(size_t)p];
+            std::vector<float> rnd2;
+            std::vector<size_t> ctx2;
+            for (size_t i = first[(size_t)p]; i < first[(size_t)p + 1]; i++) {
+                const size_t L = off[i + 1] - off[i];
+                if (!generic) w.rescale(y_s + off[i], L);
+                w.draw_many(L, m_fold, codes_out.data() + d0[i], rnd2, ctx2);
+            }
+        }
+        return 0;
     }
     for (size_t i = 0; i < n_seqs; i++) {
         const size_t L = off[i + 1] - off[i];

@@ -2,6 +2,8 @@
 // drive the FASTA reader, the seeders and the model-file writers through ctypes.
 #include <cstring>
 
+#include <omp.h>
+
 #include "bamm_host.h"
 
 using namespace bammhost;
@@ -98,6 +100,9 @@ int bh_load_seed_dev(const char* path, const char* tag, uint32_t l_flank, uint32
     return load_seed_impl(path, tag, l_flank, r_flank, K, alpha, max_pwm, glob_q, bg_order, vbg, packed, index, n_motifs,
                           w_out, q_out, v_out, v_cap, &dev);
 }
+
+// OpenMP threads of the host-side loops (the CLI's --threads)
+void bh_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
 
 const char* bh_base_name(const char* path) {
     g_err = base_name(path);

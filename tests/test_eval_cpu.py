@@ -44,6 +44,28 @@ def test_negative_sampler_matches_reference(tag, generic, host, g):
     assert np.array_equal(codes, g[tag + "_codes"])
 
 
+@pytest.mark.parametrize("generic", [0, 1])
+def test_negative_sampler_does_not_depend_on_threads(generic, host):
+    """Above 256 positives the sampler cuts the rand() stream into ranges and samples them on
+    several threads (host/fdr.cpp): same draws, same negatives as the single-threaded walk."""
+    from tests.cases import Case
+    c = Case(name="neg_thr", N=700, L0=60, W=8, K=2, ragged=25)
+    packed = bm.PackedSeqs.from_codes(c.codes, c.in_off, False, seed=42)
+    out = []
+    for threads in (1, 5):
+        host.bh_set_threads(threads)
+        n, m = C.c_uint64(), C.c_uint64()
+        assert host.bh_sample_negatives(packed._p, 2, C.c_uint64(3), generic, C.byref(n), C.byref(m), None, None) == 0
+        codes = np.zeros(m.value, np.uint8)
+        off = np.zeros(n.value + 1, np.uint64)
+        assert host.bh_sample_negatives(packed._p, 2, C.c_uint64(3), generic, C.byref(n), C.byref(m),
+                                        codes.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)) == 0
+        out.append((codes, off))
+    host.bh_set_threads(4)
+    assert out[0][0].size > 0 and out[0][0].min() >= 1 and out[0][0].max() <= 4
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+
+
 def test_fdr_statistics_and_files_match_reference(host, g, tmp_path):
     """FDR::calculatePR / calculatePvalues / write (FDR.cpp:147-410) on the reference's own scores."""
     rc = host.bh_fdr_stats(fp(g["fdr_pos_max"]), C.c_uint64(len(g["fdr_pos_max"])), fp(g["fdr_neg_max"]),
