@@ -29,6 +29,11 @@ GROUPED_CASES = [
     dict(name="g_k2_m16", N=24, L0=480, W=21, K=2, n_frac=0.001, ragged=60),
     dict(name="g_k1_ss_m4", N=64, L0=250, W=12, K=1, ss=True, ragged=30),
     dict(name="g_k2_wide", N=32, L0=200, W=31, K=2, ragged=0),
+    # the remaining length classes (6, 8, 12, 14 positions per lane)
+    dict(name="g_k2_m6", N=24, L0=180, W=10, K=2, n_frac=0.002, ragged=8),
+    dict(name="g_k1_m8", N=24, L0=230, W=9, K=1, ragged=8),
+    dict(name="g_k2_m12", N=24, L0=370, W=14, K=2, ragged=10),
+    dict(name="g_k0_m14", N=24, L0=430, W=11, K=0, n_frac=0.002, ragged=10),
 ]
 
 
