@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "common.h"
 
@@ -76,6 +77,8 @@ struct bamm_ctx {
 struct bamm_seqs {
     bamm_ctx* ctx = nullptr;
     int refs = 1;
+    std::mutex mu;                              // guards refs and the lazily built per-order tables (handles may be
+                                                // created on one set from several host threads, FDR.cpp:37)
     uint64_t n = 0, total_len = 0;
     uint32_t max_len = 0, min_len = 0;
     uint64_t hbm_bytes = 0;
@@ -181,6 +184,7 @@ SeqView make_view(const bamm_seqs* s, const ExcK* exc, const EmBucket& b, const 
 // build (once per order) the list of positions whose kmer_ mod 4^(K+1) differs from what the
 // 2-bit stream gives
 int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
+    std::lock_guard<std::mutex> lock(s->mu);
     auto it = s->exc_by_order.find(K);
     if (it != s->exc_by_order.end()) { *out = &it->second; return BAMM_OK; }
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
@@ -211,6 +215,7 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
 // records of the grouped kernel for group size G (built once per (order, G)): x = first exception
 // position | B << 12, y/z/w = exact y of the positions lo-G+1 .. lo+B-1, 7 bits each, 4 per word
 int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XRec** out) {
+    std::lock_guard<std::mutex> lock(s->mu);
     auto it = k->xrec.find(G);
     if (it != k->xrec.end()) { *out = &it->second; return BAMM_OK; }
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
@@ -558,7 +563,10 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
 
 int bamm_seqs_destroy(bamm_seqs* s) {
     if (!s) return BAMM_OK;
-    if (--s->refs > 0) return BAMM_OK;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        if (--s->refs > 0) return BAMM_OK;
+    }
     (void)hipSetDevice(s->ctx->device);
     delete s;
     return BAMM_OK;
@@ -621,7 +629,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     bamm_em* em = new bamm_em();
     em->ctx = c;
     em->seqs = seqs;
-    seqs->refs++;
+    { std::lock_guard<std::mutex> lock(seqs->mu); seqs->refs++; }
     em->prm = *prm;
     if (em->prm.max_iterations == 0) em->prm.max_iterations = 1000;
     em->Y = Y;

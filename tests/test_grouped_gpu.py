@@ -152,3 +152,34 @@ def test_grouped_with_fold_mask_and_optimize(gpu_ctx, orc):
     assert em.iteration() == res["iterations"]
     np.testing.assert_allclose(em.getV(), res["v"], rtol=5e-5, atol=1e-8)
     em.close(); ss.close()
+
+
+def test_handles_created_from_several_host_threads(gpu_ctx, orc):
+    """FDR::evaluateMotif builds its EM objects on one sequence set from up to four host threads
+    (FDR.cpp:37): handle creation (which builds the per-order tables of the shared set lazily) and the
+    runs themselves must be safe to issue concurrently."""
+    import threading
+    c = Case(name="g_thr", N=500, L0=200, W=12, K=2)
+    seq, kmer, off, vbg = c.encode(orc)
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ss = bm.SeqSet(gpu_ctx, pk)
+    folds = 4
+    out = [None] * folds
+
+    def run(f):
+        mask = (np.arange(c.N) % folds != f).astype(np.uint8)
+        em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, mask=mask)
+        em.iterate(5)
+        out[f] = em.getV()
+        em.close()
+
+    th = [threading.Thread(target=run, args=(f,)) for f in range(folds)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for f in range(folds):                                   # the same folds one after the other
+        mask = (np.arange(c.N) % folds != f).astype(np.uint8)
+        em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, mask=mask)
+        em.iterate(5)
+        assert np.array_equal(em.getV(), out[f])
+        em.close()
+    ss.close()
