@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     extern __shared__ __align__(16) float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     const uint32_t Wq = (W + 3u) >> 2;
+    const uint32_t pad = 4u * Wq - W;
     // odds table as [W/4][Y+1][4]: one ds_read_b128 fetches the row of FOUR motif columns for a
     // position (2.3 LDS cycles per column instead of 4.2 for ds_read_b32, tools/lds_bench2.hip);
     // row Y and the padding columns are 1.0f
@@ -70,7 +71,10 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 
     for (uint32_t i = threadIdx.x; i < Wq * Ys * 4u; i += blockDim.x) {
         const uint32_t jq = i / (Ys * 4u), rem = i - jq * Ys * 4u, yy = rem >> 2, j = jq * 4u + (rem & 3u);
-        s_lds[i] = (j < W) ? a.s[(size_t)j * Ys + yy] : 1.0f;
+        // the 4*Wq - W padding columns sit in FRONT of column 0 and hold 1.0f: every quad then takes all
+        // four chain steps without a guard (a guard between two steps costs M register moves at the
+        // merge point), and slot p still ends up with window p-(W-1)
+        s_lds[i] = (j >= pad) ? a.s[(size_t)(j - pad) * Ys + yy] : 1.0f;
     }
     if (ACCUM)
         for (uint32_t i = threadIdx.x; i < (W * Ys) << logC; i += blockDim.x) n_lds[i] = 0ull;
@@ -109,9 +113,9 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             // long-sequence classes: 4*M live floats per quad would spill (256 VGPRs); read the
             // same [W/4][Y+1][4] table one column at a time instead
 #pragma unroll
-            for (int m = 0; m < M; m++) U[m] = s_lds[y[m] * 4u];
+            for (int m = 0; m < M; m++) U[m] = s_lds[(size_t)(pad >> 2) * Ys * 4u + (pad & 3u) + y[m] * 4u];
             for (uint32_t j = 1; j < W; j++) {
-                const float* sj = s_lds + (size_t)(j >> 2) * Ys * 4u + (j & 3u);
+                const float* sj = s_lds + (size_t)((j + pad) >> 2) * Ys * 4u + ((j + pad) & 3u);
                 const float carry = wave_shr1(1.0f, U[M - 1]);
 #pragma unroll
                 for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m] * 4u];
@@ -122,36 +126,36 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         const uint32_t s_base = lds_offset(s_lds);
 #pragma unroll
         for (int m = 0; m < M; m++) sa[m] = s_base + y[m] * 16u;
-        for (uint32_t jq = 0; jq < Wq; jq++) {
+#define BAMM_SEQ_STEP(COMP)                                                     \
+            { const float c = wave_shr1(1.0f, U[M - 1]);                        \
+              _Pragma("unroll") for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].COMP; \
+              U[0] = c * sv[0].COMP; }
+        {                                                // first quad: its column 0 starts the chain
             f32x4 sv[M];
 #pragma unroll
             for (int m = 0; m < M; m++) sv[m] = lds_read_b128(sa[m]);
 #pragma unroll
             for (int m = 0; m < M; m++) sa[m] += Ys * 16u;
             lds_wait<M>(sv);
-            // the padding columns of the last quad hold 1.0f: multiplying by them is exact
-            if (jq == 0) {
 #pragma unroll
-                for (int m = 0; m < M; m++) U[m] = sv[m].x;             // column 0 starts the chain
-            } else {
-                const float c = wave_shr1(1.0f, U[M - 1]);
-#pragma unroll
-                for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].x;
-                U[0] = c * sv[0].x;
-            }
-            if (jq * 4u + 1u < W) { const float c = wave_shr1(1.0f, U[M - 1]);
-#pragma unroll
-              for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].y;
-              U[0] = c * sv[0].y; }
-            if (jq * 4u + 2u < W) { const float c = wave_shr1(1.0f, U[M - 1]);
-#pragma unroll
-              for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].z;
-              U[0] = c * sv[0].z; }
-            if (jq * 4u + 3u < W) { const float c = wave_shr1(1.0f, U[M - 1]);
-#pragma unroll
-              for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].w;
-              U[0] = c * sv[0].w; }
+            for (int m = 0; m < M; m++) U[m] = sv[m].x;
+            BAMM_SEQ_STEP(y)
+            BAMM_SEQ_STEP(z)
+            BAMM_SEQ_STEP(w)
         }
+        for (uint32_t jq = 1; jq < Wq; jq++) {
+            f32x4 sv[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) sv[m] = lds_read_b128(sa[m]);
+#pragma unroll
+            for (int m = 0; m < M; m++) sa[m] += Ys * 16u;
+            lds_wait<M>(sv);
+            BAMM_SEQ_STEP(x)
+            BAMM_SEQ_STEP(y)
+            BAMM_SEQ_STEP(z)
+            BAMM_SEQ_STEP(w)
+        }
+#undef BAMM_SEQ_STEP
         }
         // slot p now holds the product of window start i = p-(W-1); valid for W-1 <= p < L
         const float pos_i = q / (float)LW1;              // EM.cpp:160
