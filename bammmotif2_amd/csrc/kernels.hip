@@ -103,9 +103,13 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
 
+        // wave priorities by phase, as in k_em_grp (grouped.hip): the LDS-bound M-step ahead of the
+        // VALU-bound E-step in the issue arbitration
+        __builtin_amdgcn_s_setprio(0);
         uint32_t y[M];
         // EM.cpp:167: only positions ij < LW1 take part; everything beyond reads the neutral row
         decode_raw<M>(cur, a.sv, Y, LW1, lane, y);
+        __builtin_amdgcn_s_setprio(2);
 
         // ---- E-step: U[m] after column j = prod_{j'<=j} s[j'][y(p-j+j')]  (EM.cpp:167-176)
         float U[M];
@@ -158,6 +162,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 #undef BAMM_SEQ_STEP
         }
         // slot p now holds the product of window start i = p-(W-1); valid for W-1 <= p < L
+        __builtin_amdgcn_s_setprio(1);
         const float pos_i = q / (float)LW1;              // EM.cpp:160
         float zpart = 0.0f;
 #pragma unroll
@@ -185,6 +190,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         }
 
         if (ACCUM) {
+            __builtin_amdgcn_s_setprio(3);
             // ---- M-step (EM.cpp:236-242): position p, column j receives r(i = p-j), which
             // sits in slot p+(W-1-j): walk j downwards and shift the slots one step per column.
             // Counts are accumulated as 64-bit fixed point (2^-40 units) with ds_add_u64: LDS
