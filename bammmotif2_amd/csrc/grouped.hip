@@ -367,7 +367,9 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const float invZ = 1.0f / Z;
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187
-        llh_acc += (double)logf(Z);                      // EM.cpp:195 (v_log_f32 alone loses ~1e-6 absolute near Z = 1)
+        // EM.cpp:195.  v_log_f32 (log2, 1 ulp of its result) times ln 2: as close to logf(Z) as Z itself is
+        // known (Z carries half an ulp of its own); the sum runs in fp64
+        llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);
         sumr_acc += (double)invZ;                        // sum_i r[i] = 1 - (1-q)/Z  (EM.cpp:509-513), finished below
         seq_cnt++;
 
