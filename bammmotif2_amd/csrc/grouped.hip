@@ -203,6 +203,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0;
+    uint32_t last_LW1 = 0;
+    float pos_i = 0.0f;
 
     uint32_t t = blockIdx.x * waves_per_block + wave;
     RawSeqG<M> nxt{};
@@ -354,7 +356,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             }
         }
         __builtin_amdgcn_s_setprio(1);                       // normalisation, statistics
-        const float pos_i = q / (float)LW1;              // EM.cpp:160
+        if (LW1 != last_LW1) {                           // EM.cpp:160; one IEEE division per distinct length
+            pos_i = q / (float)LW1;
+            last_LW1 = LW1;
+        }
         float zpart = 0.0f;
 #pragma unroll
         for (int m = 0; m < M; m++) {
@@ -364,7 +369,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             zpart += U[m];
         }
         const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
-        const float invZ = 1.0f / Z;
+        // 1/Z: v_rcp_f32 (1 ulp) + one Newton step (error well below an ulp; r = U * invZ stays within
+        // 1.5 ulp of the reference's U / Z, EM.cpp:185-187)
+        float invZ = __builtin_amdgcn_rcpf(Z);
+        invZ = fmaf(fmaf(-Z, invZ, 1.0f), invZ, invZ);
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187
         // EM.cpp:195.  v_log_f32 (log2, 1 ulp of its result) times ln 2: as close to logf(Z) as Z itself is
