@@ -23,9 +23,8 @@ __device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x
 __device__ __forceinline__ unsigned long long to_fixed40(float r) {
     // exact power-of-two scalings and an exact split; the last unit (2^-40) is truncated
     const float a = r * 256.0f;
-    const float hi_f = floorf(a);
-    const uint32_t hi = (uint32_t)hi_f;
-    const uint32_t lo = (uint32_t)((a - hi_f) * 4294967296.0f);
+    const uint32_t hi = (uint32_t)a;                                           // truncation = floor for a >= 0
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(a) * 4294967296.0f);   // v_fract_f32: a - floor(a), exact
     return ((unsigned long long)hi << 32) | lo;
 }
 constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
