@@ -48,6 +48,7 @@ struct ExcK {                    // exceptions relevant at one model order
     struct XRec {                         // grouped kernel (grouped.hip), one set per group size G
         uint4* d_xrec = nullptr;          // per-sequence record
         std::vector<uint8_t> h_B;         // group ends that need a virtual row (0 = no exception, 255 = too many)
+        std::vector<uint32_t> h_lo;       // first of them
     };
     std::map<uint32_t, XRec> xrec;
 };
@@ -221,6 +222,7 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
     ExcK::XRec x;
     x.h_B.assign(s->n, 0);
+    x.h_lo.assign(s->n, 0);
     std::vector<uint4> xrec(s->n, make_uint4(0, 0, 0, 0));
     auto stream_y = [&](uint64_t n, int64_t pos) -> uint32_t {      // kmer_ mod 4^(K+1) as the stream alone gives it
         uint32_t y = 0;
@@ -240,6 +242,7 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
         const uint32_t B = hiB - lo + 1u;
         if (B > 8u || B + G - 1u > 12u || lo >= 4096u) { x.h_B[n] = 255; continue; }
         x.h_B[n] = (uint8_t)B;
+        x.h_lo[n] = lo;
         uint32_t w3[3] = {0, 0, 0};
         uint64_t e = e0;
         for (uint32_t i = 0; i < B + G - 1u; i++) {
@@ -705,7 +708,11 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         if (want_grouped && grp_supported_class(Mcls, prm->K) && grp_plan(prm->K, prm->W, Mcls, threads / 64u, &gG, &glogc) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, threads / 64u, true, glogc, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
-            auto capable = [&](uint32_t n) { return (uint32_t)xr->h_B[n] <= gg.Bv; };
+            // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge
+            auto capable = [&](uint32_t n) {
+                const uint32_t B = xr->h_B[n];
+                return B == 0u || (B <= gg.Bj && xr->h_lo[n] + B + gg.G <= seqs->h_len[n] - prm->W + 1u);
+            };
             bool all = true;
             for (uint32_t i = 0; i < b.count && all; i++) all = capable(b.d_idx ? b.h_idx[i] : i);
             if (!all)

@@ -71,9 +71,8 @@ struct EmKernelArgs {
 struct GrpGeom {
     uint32_t G, T, Tq, delta;    // group size, groups = ceil(W/G), quads of groups, G*T - W neutral front columns
     uint32_t Rf;                 // full rows = 4^(K+G)
-    uint32_t base[3], psize[3];  // partial class d (d+1 trailing positions neutral): first row, rows = 4^(K+G-1-d)
-    uint32_t Rn, R0, Bv, Rtot;   // neutral row, first virtual row, virtual rows per wave, rows in all
-    uint32_t rowstride;          // floats per row of the odds table [Rtot][Tq][4]
+    uint32_t Rn, R0, Bj, Bv, Rtot;   // neutral row, first virtual row, virtual rows per wave for exceptions / in all, rows
+    uint32_t rowstride;          // floats per row of the odds table [Rtot][Tq | 1][4] (odd number of quads)
     uint32_t off_sg, off_s1, off_stat, off_ng, off_n1, off_wave, wave_bytes;   // LDS byte offsets
     uint32_t cap;                // unused (the grouped kernel has no sparse M-step)
     uint32_t lds_bytes;

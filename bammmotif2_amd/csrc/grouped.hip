@@ -162,20 +162,17 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
     __syncthreads();
     for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
-        uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
-        if (row < g.Rf) { nreal = G; code = row; }
-#pragma unroll
-        for (int d = 0; d < G - 1; d++)
-            if (row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = G - 1 - d; code = row - g.base[d]; }
         uint32_t yc[G];
 #pragma unroll
-        for (int c = 0; c < G; c++) yc[c] = (code >> (2u * ((nreal - 1u - c) & 15u))) & (Y - 1u);
+        for (int c = 0; c < G; c++) yc[c] = (row >> (2u * (uint32_t)(G - 1 - c))) & (Y - 1u);
         for (uint32_t t = 0; t < T; t++) {
             float f = 1.0f;
+            if (row < g.Rf) {                                   // row Rn = Rf: neutral
 #pragma unroll
-            for (int c = 0; c < G; c++) {
-                const int col = (int)(G * t + c) - (int)delta;
-                if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
+                for (int c = 0; c < G; c++) {
+                    const int col = (int)(G * t + c) - (int)delta;
+                    if (col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
+                }
             }
             sg[row * g.rowstride + pad + t] = f;
         }
@@ -183,7 +180,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // neutral slots of every row, and the virtual rows as a whole (their real slots are rewritten per sequence)
     for (uint32_t i = threadIdx.x; i < Rtot * g.rowstride; i += blockDim.x) {
         const uint32_t row = i / g.rowstride, slot = i - row * g.rowstride;
-        if (slot < pad || row > Rn) sg[i] = 1.0f;
+        if (slot < 4u * Tq && (slot < pad || row > Rn)) sg[i] = 1.0f;
     }
     if (ACCUM) {
         for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
@@ -225,13 +222,14 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
 
-        // ---- row index of every position
+        // ---- row index of every position; sE = the 32-bit stream window that ends at position LW1-1
         uint32_t row[M];
+        uint32_t sE;
         {
             constexpr int NSEL = RawSeqG<M>::NSEL;
             const uint32_t wi0 = p0 >> 4;
-            // bits a position needs: its (K+G)-mer, shifted by up to G-1 digits for a partial row
-            constexpr bool kOneWindow = 2 * (M - 1) + 10 + 2 * (G - 1) <= 32;    // rows are at most 10 bits (K+G <= 5)
+            const uint32_t pE = LW1 - 1u, lpE = pE / (uint32_t)M;            // lane that holds position LW1-1
+            constexpr bool kOneWindow = 2 * (M - 1) + 10 <= 32;               // rows are at most 10 bits (K+G <= 5)
             if constexpr (kOneWindow) {
                 // one 32-bit window of the stream ending at the lane's LAST position; position p0+m
                 // is that window shifted by a compile-time 2*(M-1-m) bits
@@ -247,19 +245,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
                 for (int m = 0; m < M; m++)
                     row[m] = (p0 + m < LW1) ? ((X >> (2 * (M - 1 - m))) & (g.Rf - 1u)) : Rn;   // EM.cpp:167
-                // groups cut by the LW1 edge: G-1 positions of the whole sequence, patched by their lane
-#pragma unroll
-                for (int dd = 0; dd < G - 1; dd++) {
-                    const uint32_t pp = LW1 + (uint32_t)dd;
-                    if (pp < L) {
-                        const uint32_t lp = pp / (uint32_t)M, ms = pp - lp * (uint32_t)M;
-                        const uint32_t patch = g.base[dd] + ((X >> (2u * ((uint32_t)(M - 1) - ms) + 2u * (dd + 1))) & (g.psize[dd] - 1u));
-                        const bool mine = (uint32_t)lane == lp;
-#pragma unroll
-                        for (int m = 0; m < M; m++) row[m] = (mine && ms == (uint32_t)m) ? patch : row[m];
-                    }
-                }
+                // lane lpE's window, shifted so that it ends at pE (at least 32 - 2(M-1) >= 10 bits stay valid)
+                sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
             } else {
+                uint32_t vE = 0;
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     const uint32_t p = p0 + m;
@@ -271,44 +260,52 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
                     }
                     const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (p & 15u));   // kmer_[p] mod 4^16
-                    uint32_t r = v & (g.Rf - 1u);
-                    if (p >= LW1) {                              // EM.cpp:167: positions >= LW1 take no part
-                        r = Rn;
-                        const uint32_t d = p - LW1;
-#pragma unroll
-                        for (int dd = 0; dd < G - 1; dd++)
-                            if (d == (uint32_t)dd && p < L) r = g.base[dd] + ((v >> (2u * (dd + 1))) & (g.psize[dd] - 1u));
-                    }
-                    row[m] = r;
+                    row[m] = (p < LW1) ? (v & (g.Rf - 1u)) : Rn;                                  // EM.cpp:167
+                    vE = (p == pE) ? v : vE;
                 }
+                sE = (uint32_t)__builtin_amdgcn_readlane((int)vE, (int)lpE);
             }
         }
 
-        // ---- exceptions (Sequence.cpp:38): virtual rows for the group ends next to them.  The
-        // record carries the exact y of the positions [lo-G+1, lo+B), 7 bits each (Y = none)
+        // ---- group ends that no table row describes get per-wave VIRTUAL rows:
+        //   * next to an N exception (Sequence.cpp:38): B positions from xlo on; the record carries the
+        //     exact y of the positions [xlo-G+1, xlo+B), 7 bits each (Y = none)
+        //   * cut by the EM.cpp:167 edge: positions LW1 .. LW1+G-2, whose groups keep only the columns
+        //     at positions < LW1 (y from the stream window sE; bamm_em_create keeps sequences with
+        //     exceptions next to the edge out of this kernel)
         const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
-        const uint32_t B = (xw >> 12) & 0xfu;                // group ends that need a virtual row (0: none)
+        const uint32_t B = (xw >> 12) & 0xfu;                // group ends next to exceptions (0: none)
         const uint32_t xlo = xw & 0xfffu;
+        const uint32_t nE = min((uint32_t)(G - 1), L - LW1);  // group ends cut by the edge (W-1 positions lie behind it)
         uint32_t yfix[G];
 #pragma unroll
         for (int c = 0; c < G; c++) yfix[c] = Y;
-        const bool fix = lane_b < B;
-        if (B != 0u) {
+        const bool fixJ = lane_b < B;                         // fix lanes: (b, t) = virtual row b, group t
+        const bool fixE = lane_b >= g.Bj && lane_b < g.Bj + nE;
+        const bool fix = fixJ || fixE;
+        {
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                const uint32_t k2 = p0 + m - xlo;
+                const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
                 if (k2 < B) row[m] = vbase + k2;
+                if (k3 < nE) row[m] = vbase + g.Bj + k3;
             }
             if (fix) {
                 float f = 1.0f;
 #pragma unroll
                 for (int c = 0; c < G; c++) {
                     const int col = (int)(G * lane_t + c) - (int)delta;
-                    const uint32_t k = lane_b + (uint32_t)c;               // entry of position lo-G+1+k
-                    const uint32_t pos = xlo + k - (uint32_t)(G - 1);      // wraps for positions before the sequence
-                    const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
-                    uint32_t yc = (word >> (7u * (k & 3u))) & 0x7fu;
-                    if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167
+                    uint32_t yc, pos;
+                    if (fixJ) {
+                        const uint32_t k = lane_b + (uint32_t)c;           // entry of position xlo-G+1+k
+                        pos = xlo + k - (uint32_t)(G - 1);                 // wraps for positions before the sequence
+                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                    } else {
+                        pos = LW1 + (lane_b - g.Bj) - (uint32_t)(G - 1) + (uint32_t)c;
+                        yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);   // only used when pos < LW1
+                    }
+                    if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
                     yfix[c] = yc;
                     if (yc != Y) f *= s1[(uint32_t)col * Ys + yc];
                 }
@@ -431,7 +428,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 }
             }
             // ---- virtual count rows -> single-column bins (exact: one window per cell)
-            if (B != 0u) {
+            {
                 wave_lds_sync();
                 if (fix) {
                     unsigned long long acc = 0ull;
@@ -476,18 +473,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         // the (K+G)-mer has exactly c digits above y_c, so the mask above is a no-op
                         for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
                     }
-            }
-#pragma unroll
-            for (int d = 0; d < G - 1; d++) {                // partial rows: positions c < G-1-d are real
-                const uint32_t nreal = (uint32_t)(G - 1 - d);
-                if (c < nreal) {
-                    const uint32_t lowd = 2u * (nreal - 1u - c);
-                    for (uint32_t h = 0; h < (1u << (2u * c)); h++)
-                        for (uint32_t l = 0; l < (1u << lowd); l++) {
-                            const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
-                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
-                        }
-                }
             }
             out[i] = acc;
         }
@@ -534,23 +519,24 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
     g.Tq = (g.T + 3u) / 4u;
     g.delta = g.G * g.T - W;
     g.Rf = 1u << (2u * (K + g.G));
-    uint32_t r = g.Rf;
-    for (uint32_t d = 0; d + 1u < g.G; d++) {
-        g.base[d] = r;
-        g.psize[d] = 1u << (2u * (K + g.G - 1u - d));
-        r += g.psize[d];
-    }
-    g.Rn = r;
-    g.R0 = r + 1u;
-    // one N makes K exceptions in a row (B = K-1+G group ends); two more rows cover "NN" and "N.N"
-    g.Bv = std::min(std::min(8u, K + g.G + 1u), 64u / g.T);
-    if (g.Bv < g.G) return false;
+    g.Rn = g.Rf;                                             // neutral row
+    g.R0 = g.Rf + 1u;
+    // virtual rows per wave: Bj for the group ends next to N exceptions (one N makes K exceptions in a
+    // row, i.e. K-1+G group ends; two more rows cover "NN" and "N.N"), G-1 for the group ends cut by
+    // the LW1 edge; one fix lane per (row, group)
+    g.Bj = std::min(8u, K + g.G + 1u);
+    while (g.Bj > 0u && (g.Bj + g.G - 1u) * g.T > 64u) g.Bj--;
+    if ((g.Bj + g.G - 1u) * g.T > 64u) return false;
+    g.Bv = g.Bj + g.G - 1u;
     g.Rtot = g.R0 + waves * g.Bv;
     const uint32_t Y = 1u << (2u * (K + 1u));
     auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
     uint32_t off = 0;
-    g.rowstride = g.Tq * 4u;
-    g.off_sg = off; off = up16(off + g.Tq * g.Rtot * 16u);
+    // an odd number of quads per row: rows then start on all 16 bank-quads, not on every 2nd / 4th one,
+    // and the 16 lanes of a ds_read_b128 group that read the same quad index of random rows spread over
+    // all of them (with 2 quads per row a group shared 8)
+    g.rowstride = (g.Tq | 1u) * 4u;
+    g.off_sg = off; off = up16(off + g.rowstride * g.Rtot * 4u);
     g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
     g.off_stat = off; off = up16(off + 16u * 3u * 8u);
     g.off_ng = off;
