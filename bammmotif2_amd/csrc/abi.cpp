@@ -59,6 +59,7 @@ struct EmBucket {                // one kernel launch of an EM pass
     const uint32_t* d_idx = nullptr;
     bool grouped = false;        // k_em_grp instead of k_em_seq
     uint32_t G = 0;              // its group size
+    uint32_t layout = 0;         // table layout (grp_geometry)
     const uint4* d_xrec = nullptr;
     uint32_t blocks = 0, logc = 0, sparse_cap = 0, sparse_bytes = 0;
     double work = 0;
@@ -315,7 +316,7 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
     a.sparse_cap = 0; a.sparse_wave_bytes = 0;
     ga.e = a;
     ga.xrec = eb.d_xrec;
-    if (!grp_geometry(em->prm.K, em->prm.W, eb.G, kMClasses[eb.mclass], threads / 64u, accum, accum ? eb.logc : 0u, &ga.g)) {
+    if (!grp_geometry(em->prm.K, em->prm.W, eb.G, kMClasses[eb.mclass], threads / 64u, accum, accum ? eb.logc : 0u, eb.layout, &ga.g)) {
         set_error("grouped kernel geometry does not fit (K=%u W=%u)", em->prm.K, em->prm.W);
         return BAMM_ERR_UNSUPPORTED;
     }
@@ -705,13 +706,21 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         uint32_t glogc = 0, gG = 0;
         const ExcK::XRec* xr = nullptr;
         std::vector<uint32_t> yes, no;
-        if (want_grouped && grp_supported_class(Mcls, prm->K) && grp_plan(prm->K, prm->W, Mcls, threads / 64u, &gG, &glogc) &&
-            grp_geometry(prm->K, prm->W, gG, Mcls, threads / 64u, true, glogc, &gg)) {
+        uint32_t glayout = 0;
+        // do most sequences of this bucket carry exceptions (a double-stranded set: all of them)?
+        size_t with_exc = 0;
+        for (uint32_t i = 0; i < b.count; i++) {
+            const uint32_t n = b.d_idx ? b.h_idx[i] : i;
+            with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
+        }
+        if (want_grouped && grp_supported_class(Mcls, prm->K) &&
+            grp_plan(prm->K, prm->W, Mcls, threads / 64u, 2 * with_exc > b.count, &gG, &glogc, &glayout) &&
+            grp_geometry(prm->K, prm->W, gG, Mcls, threads / 64u, true, glogc, glayout, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge
             auto capable = [&](uint32_t n) {
                 const uint32_t B = xr->h_B[n];
-                return B == 0u || (B <= gg.Bj && xr->h_lo[n] + B + gg.G <= seqs->h_len[n] - prm->W + 1u);
+                return B == 0u || (B <= gg.Bj && (gg.np != 0u || xr->h_lo[n] + B + gg.G <= seqs->h_len[n] - prm->W + 1u));
             };
             bool all = true;
             for (uint32_t i = 0; i < b.count && all; i++) all = capable(b.d_idx ? b.h_idx[i] : i);
@@ -721,7 +730,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
                     (capable(n) ? yes : no).push_back(n);
                 }
             EmBucket eb;
-            eb.mclass = b.mclass; eb.grouped = true; eb.logc = glogc; eb.G = gG; eb.d_xrec = xr->d_xrec;
+            eb.mclass = b.mclass; eb.grouped = true; eb.logc = glogc; eb.G = gG; eb.layout = glayout; eb.d_xrec = xr->d_xrec;
             if (all) { eb.count = b.count; eb.d_idx = b.d_idx; }
             else {
                 uint32_t* d = nullptr;

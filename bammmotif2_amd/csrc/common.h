@@ -71,6 +71,8 @@ struct EmKernelArgs {
 struct GrpGeom {
     uint32_t G, T, Tq, delta;    // group size, groups = ceil(W/G), quads of groups, G*T - W neutral front columns
     uint32_t Rf;                 // full rows = 4^(K+G)
+    uint32_t layout, np;         // see grp_geometry(); partial classes of table rows (0 or G-1)
+    uint32_t base[3], psize[3];  // partial class d (d+1 trailing positions neutral): first row, rows = 4^(K+G-1-d)
     uint32_t Rn, R0, Bj, Bv, Rtot;   // neutral row, first virtual row, virtual rows per wave for exceptions / in all, rows
     uint32_t rowstride;          // floats per row of the odds table [Rtot][Tq | 1][4] (odd number of quads)
     uint32_t off_sg, off_s1, off_stat, off_ng, off_n1, off_wave, wave_bytes;   // LDS byte offsets
@@ -86,8 +88,10 @@ struct GrpKernelArgs {
 };
 
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply
-bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out);
-bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, uint32_t* G, uint32_t* logC);   // false: use k_em_seq
+bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
+                  GrpGeom* out);
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t* G, uint32_t* logC,
+              uint32_t* layout);   // false: use k_em_seq
 bool grp_supported_class(int M, uint32_t K);
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st);

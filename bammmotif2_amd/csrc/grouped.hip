@@ -162,17 +162,19 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
     __syncthreads();
     for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
+        uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
+        if (row < g.Rf) { nreal = G; code = row; }
+        for (uint32_t d = 0; d < g.np; d++)
+            if (row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = (uint32_t)G - 1u - d; code = row - g.base[d]; }
         uint32_t yc[G];
 #pragma unroll
-        for (int c = 0; c < G; c++) yc[c] = (row >> (2u * (uint32_t)(G - 1 - c))) & (Y - 1u);
+        for (int c = 0; c < G; c++) yc[c] = (code >> (2u * ((nreal - 1u - c) & 15u))) & (Y - 1u);
         for (uint32_t t = 0; t < T; t++) {
             float f = 1.0f;
-            if (row < g.Rf) {                                   // row Rn = Rf: neutral
 #pragma unroll
-                for (int c = 0; c < G; c++) {
-                    const int col = (int)(G * t + c) - (int)delta;
-                    if (col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
-                }
+            for (int c = 0; c < G; c++) {
+                const int col = (int)(G * t + c) - (int)delta;
+                if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
             }
             sg[row * g.rowstride + pad + t] = f;
         }
@@ -245,6 +247,21 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
                 for (int m = 0; m < M; m++)
                     row[m] = (p0 + m < LW1) ? ((X >> (2 * (M - 1 - m))) & (g.Rf - 1u)) : Rn;   // EM.cpp:167
+                if (g.np != 0u) {
+                    // groups cut by the LW1 edge read partial rows: G-1 positions of the whole sequence,
+                    // patched by their lane
+#pragma unroll
+                    for (int dd = 0; dd < G - 1; dd++) {
+                        const uint32_t pp = LW1 + (uint32_t)dd;
+                        if (pp < L) {
+                            const uint32_t lp = pp / (uint32_t)M, ms = pp - lp * (uint32_t)M;
+                            const uint32_t patch = g.base[dd] + ((X >> (2u * ((uint32_t)(M - 1) - ms) + 2u * (dd + 1))) & (g.psize[dd] - 1u));
+                            const bool mine = (uint32_t)lane == lp;
+#pragma unroll
+                            for (int m = 0; m < M; m++) row[m] = (mine && ms == (uint32_t)m) ? patch : row[m];
+                        }
+                    }
+                }
                 // lane lpE's window, shifted so that it ends at pE (at least 32 - 2(M-1) >= 10 bits stay valid)
                 sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
             } else {
@@ -260,7 +277,14 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
                     }
                     const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (p & 15u));   // kmer_[p] mod 4^16
-                    row[m] = (p < LW1) ? (v & (g.Rf - 1u)) : Rn;                                  // EM.cpp:167
+                    uint32_t r = (p < LW1) ? (v & (g.Rf - 1u)) : Rn;                              // EM.cpp:167
+                    if (g.np != 0u && p >= LW1) {
+                        const uint32_t d = p - LW1;
+#pragma unroll
+                        for (int dd = 0; dd < G - 1; dd++)
+                            if (d == (uint32_t)dd && p < L) r = g.base[dd] + ((v >> (2u * (dd + 1))) & (g.psize[dd] - 1u));
+                    }
+                    row[m] = r;
                     vE = (p == pE) ? v : vE;
                 }
                 sE = (uint32_t)__builtin_amdgcn_readlane((int)vE, (int)lpE);
@@ -276,14 +300,16 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
         const uint32_t B = (xw >> 12) & 0xfu;                // group ends next to exceptions (0: none)
         const uint32_t xlo = xw & 0xfffu;
-        const uint32_t nE = min((uint32_t)(G - 1), L - LW1);  // group ends cut by the edge (W-1 positions lie behind it)
+        // group ends cut by the edge that need a virtual row: none when the table has partial rows for them
+        const uint32_t nE = g.np != 0u ? 0u : min((uint32_t)(G - 1), L - LW1);
         uint32_t yfix[G];
 #pragma unroll
         for (int c = 0; c < G; c++) yfix[c] = Y;
         const bool fixJ = lane_b < B;                         // fix lanes: (b, t) = virtual row b, group t
         const bool fixE = lane_b >= g.Bj && lane_b < g.Bj + nE;
         const bool fix = fixJ || fixE;
-        {
+        const bool any_fix = (B | nE) != 0u;                 // wave-uniform
+        if (any_fix) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
@@ -428,7 +454,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 }
             }
             // ---- virtual count rows -> single-column bins (exact: one window per cell)
-            {
+            if (any_fix) {
                 wave_lds_sync();
                 if (fix) {
                     unsigned long long acc = 0ull;
@@ -474,6 +500,17 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
                     }
             }
+            for (uint32_t d = 0; d < g.np; d++) {            // partial rows: positions c < G-1-d are real
+                const uint32_t nreal = (uint32_t)G - 1u - d;
+                if (c < nreal) {
+                    const uint32_t lowd = 2u * (nreal - 1u - c);
+                    for (uint32_t h = 0; h < (1u << (2u * c)); h++)
+                        for (uint32_t l = 0; l < (1u << lowd); l++) {
+                            const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
+                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
+                        }
+                }
+            }
             out[i] = acc;
         }
     }
@@ -510,7 +547,10 @@ void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t b
 // length classes the grouped kernel is instantiated for: 4..16 positions per lane (M >= G)
 bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 4 && M <= 16; }
 
-bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, GrpGeom* out) {
+// layout: bit 0 = groups cut by the LW1 edge as per-wave virtual rows (else partial table rows),
+//         bit 1 = odd number of quads per table row
+bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
+                  GrpGeom* out) {
     if (K > 2u || W == 0u || G < 2u || G > 4u || K + G > 5u || (int)G > M) return false;
     GrpGeom g{};
     g.G = G;
@@ -519,23 +559,32 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
     g.Tq = (g.T + 3u) / 4u;
     g.delta = g.G * g.T - W;
     g.Rf = 1u << (2u * (K + g.G));
-    g.Rn = g.Rf;                                             // neutral row
-    g.R0 = g.Rf + 1u;
+    g.layout = layout;
+    g.np = (layout & 1u) ? 0u : g.G - 1u;
+    uint32_t r = g.Rf;
+    for (uint32_t d = 0; d < g.np; d++) {                   // partial class d: d+1 trailing positions neutral
+        g.base[d] = r;
+        g.psize[d] = 1u << (2u * (K + g.G - 1u - d));
+        r += g.psize[d];
+    }
+    g.Rn = r;                                                // neutral row
+    g.R0 = r + 1u;
     // virtual rows per wave: Bj for the group ends next to N exceptions (one N makes K exceptions in a
-    // row, i.e. K-1+G group ends; two more rows cover "NN" and "N.N"), G-1 for the group ends cut by
-    // the LW1 edge; one fix lane per (row, group)
+    // row, i.e. K-1+G group ends; two more rows cover "NN" and "N.N"), G-1 more for the group ends cut
+    // by the LW1 edge when the table has no partial rows for them; one fix lane per (row, group)
+    const uint32_t edge = (layout & 1u) ? g.G - 1u : 0u;
     g.Bj = std::min(8u, K + g.G + 1u);
-    while (g.Bj > 0u && (g.Bj + g.G - 1u) * g.T > 64u) g.Bj--;
-    if ((g.Bj + g.G - 1u) * g.T > 64u) return false;
-    g.Bv = g.Bj + g.G - 1u;
+    while (g.Bj > 0u && (g.Bj + edge) * g.T > 64u) g.Bj--;
+    if ((g.Bj + edge) * g.T > 64u) return false;
+    g.Bv = g.Bj + edge;
     g.Rtot = g.R0 + waves * g.Bv;
     const uint32_t Y = 1u << (2u * (K + 1u));
     auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
     uint32_t off = 0;
-    // an odd number of quads per row: rows then start on all 16 bank-quads, not on every 2nd / 4th one,
+    // layout bit 1, an odd number of quads per row: rows then start on all 16 bank-quads, not on every 2nd / 4th one,
     // and the 16 lanes of a ds_read_b128 group that read the same quad index of random rows spread over
     // all of them (with 2 quads per row a group shared 8)
-    g.rowstride = (g.Tq | 1u) * 4u;
+    g.rowstride = ((layout & 2u) ? (g.Tq | 1u) : g.Tq) * 4u;
     g.off_sg = off; off = up16(off + g.rowstride * g.Rtot * 4u);
     g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
     g.off_stat = off; off = up16(off + 16u * 3u * 8u);
@@ -555,15 +604,28 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
 
 // group size and private copies for (K, W): wider groups first (fewer gathers / adds per window),
 // then as many private copies of the count table as the 160 KiB hold
-bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, uint32_t* G_out, uint32_t* logC_out) {
+// `many_exceptions`: most sequences of the launch carry exceptions anyway (double-stranded sets: the
+// strand junction), so the fix lanes run per sequence whether or not the edge rows are virtual.
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t* G_out, uint32_t* logC_out,
+              uint32_t* layout_out) {
     const uint32_t forced = getenv("BAMM_GRP_G") ? (uint32_t)atoi(getenv("BAMM_GRP_G")) : 0u;
+    const int forced_layout = getenv("BAMM_GRP_LAYOUT") ? atoi(getenv("BAMM_GRP_LAYOUT")) : -1;
+    // layouts in order of preference.  Sets with exceptions everywhere run the fix lanes per sequence
+    // anyway: virtual edge rows cost them nothing extra, save the decode's partial-row patches and make
+    // the tables small enough for the odd stride (K=2: 1.08 -> 1.01 ms, K=1: 1.05 -> 0.98 ms).  Clean
+    // sets (single strand, K=0) would pay the fix lanes for the edge alone (+11 %): partial rows there.
+    const uint32_t order_exc[3] = {3u, 2u, 0u}, order_clean[3] = {2u, 0u, 3u};
     for (uint32_t G = 5u - K; G >= 2u && G + 1u >= 5u - K; G--) {          // G = 5-K, then 4-K
         if (G > 4u || (forced && G != forced)) continue;
-        for (int lc = 2; lc >= 0; lc--) {
-            GrpGeom g;
-            if (grp_geometry(K, W, G, M, waves, true, (uint32_t)lc, &g)) {
-                *G_out = G; *logC_out = (uint32_t)lc;
-                return true;
+        for (int li = 0; li < 3; li++) {
+            const uint32_t layout = many_exceptions ? order_exc[li] : order_clean[li];
+            if (forced_layout >= 0 && (uint32_t)forced_layout != layout) continue;
+            for (int lc = 2; lc >= 0; lc--) {
+                GrpGeom g;
+                if (grp_geometry(K, W, G, M, waves, true, (uint32_t)lc, layout, &g)) {
+                    *G_out = G; *logC_out = (uint32_t)lc; *layout_out = layout;
+                    return true;
+                }
             }
         }
     }

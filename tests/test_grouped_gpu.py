@@ -183,3 +183,19 @@ def test_handles_created_from_several_host_threads(gpu_ctx, orc):
         assert np.array_equal(em.getV(), out[f])
         em.close()
     ss.close()
+
+
+@pytest.mark.parametrize("layout", [0, 2, 3])
+@pytest.mark.parametrize("spec", [GROUPED_CASES[1], GROUPED_CASES[9], GROUPED_CASES[4]],
+                         ids=["k2_ds_N", "k1_ss", "k0_ds_w2"])
+def test_every_table_layout_matches_exact_arithmetic(spec, layout, gpu_ctx, orc, monkeypatch):
+    """The table layouts the planner chooses between (grp_geometry: partial rows or per-wave virtual rows
+    for the groups cut by the LW1 edge, even or odd number of quads per row) compute the same thing."""
+    monkeypatch.setenv("BAMM_GRP_LAYOUT", str(layout))
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    assert em.plan()[0] > 0
+    v64, *_ = orc.em_step_f64(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+    em.iterate(1)
+    np.testing.assert_allclose(em.getV(), v64, rtol=1e-6, atol=1e-9)
+    em.close(); ss.close()
