@@ -13,8 +13,10 @@
 //   nG[t][row(p)] += r(window)                  (marginalised to n[j][y] once per block)
 //
 // What keeps this exact:
-//   * EM.cpp:167 truncation (positions >= L-W+1 take no part): a group cut by that edge reads a
-//     "partial" row that only carries its leading columns; beyond it the neutral row.
+//   * EM.cpp:167 truncation (positions >= L-W+1 take no part): a group cut by that edge only carries
+//     its leading columns.  Two table layouts (grp_geometry, chosen per launch): "partial" table rows
+//     for those G-1 group ends, or per-wave virtual rows like the ones below; beyond the edge the
+//     neutral row.
 //   * N randomisation (Sequence.cpp:38): next to an exception the k-mers of neighbouring positions
 //     disagree, so no (K+G)-mer describes the group.  Those group ends (a handful per sequence:
 //     the strand junction) get per-wave VIRTUAL rows: a few "fix" lanes compute their G-column
@@ -27,6 +29,11 @@
 //     result is bit-identical to k_em_seq's for the same responsibilities.
 // Window products are rounded in a different order than the reference's left-to-right product
 // (groups first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
+//
+// What makes it fast beyond the smaller instruction count: wave priorities by
+// phase (the LDS-bound M-step ahead of the VALU-bound E-step), table rows padded to an odd number of
+// quads (rows start on all 16 bank-quads), a straight-line E-chain, the group index of the count
+// table in the add's immediate offset.
 //
 // Things measured and left out: a compacted list of the non-zero windows for
 // the M-step (built three ways; an LDS add costs in proportion to its active lanes, so 14 full adds
