@@ -350,19 +350,27 @@ int bamm_bg_model(const bamm_packed* p, uint32_t K, const float* alpha, float* v
     const uint32_t maskK = (uint32_t)(ipow4(K + 1) - 1);
     std::vector<uint64_t> top(ipow4(K + 1), 0);               // counts of the highest order
     std::vector<std::vector<uint64_t>> cnt(K + 1);
-    for (uint64_t n = 0; n < p->n_seqs; n++) {
-        const uint32_t* w = p->words + p->word_off[n];
-        uint64_t e = p->exc_off[n];
-        const uint64_t e1 = p->exc_off[n + 1];
-        uint32_t roll = 0;
-        for (uint32_t i = 0; i < p->len[n]; i++) {
-            const uint32_t base = (w[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
-            roll = (roll << 2) | base;
-            uint32_t y = roll & maskK;
-            if (e < e1 && p->exc_pos[e] == i) { y = p->exc_kmer[e] & maskK; e++; }
-            top[y]++;
+    // integer counts: ranges of sequences on host threads, per-thread tables summed afterwards
+    const uint32_t T = std::max<uint32_t>(1, std::min<uint64_t>(host_threads(), p->n_seqs / 1024 + 1));
+    std::vector<std::vector<uint64_t>> part(T, std::vector<uint64_t>(ipow4(K + 1), 0));
+    parallel_ranges(p->n_seqs, T, [&](uint32_t t, uint64_t n0, uint64_t n1) {
+        std::vector<uint64_t>& mine = part[t];
+        for (uint64_t n = n0; n < n1; n++) {
+            const uint32_t* w = p->words + p->word_off[n];
+            uint64_t e = p->exc_off[n];
+            const uint64_t e1 = p->exc_off[n + 1];
+            uint32_t roll = 0;
+            for (uint32_t i = 0; i < p->len[n]; i++) {
+                const uint32_t base = (w[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
+                roll = (roll << 2) | base;
+                uint32_t y = roll & maskK;
+                if (e < e1 && p->exc_pos[e] == i) { y = p->exc_kmer[e] & maskK; e++; }
+                mine[y]++;
+            }
         }
-    }
+    });
+    for (uint32_t t = 0; t < T; t++)
+        for (size_t y = 0; y < top.size(); y++) top[y] += part[t][y];
     // lower orders: kmer mod 4^(k+1) = y_K mod 4^(k+1)
     cnt[K] = top;
     for (uint32_t k = K; k > 0; k--) {

@@ -39,59 +39,90 @@ static inline uint8_t base_code(char c) {
 }
 
 int read_fasta(const std::string& path, FastaSet& out, std::string& err) {
-    std::ifstream file(path.c_str());
-    if (!file.is_open()) { err = "Error: Cannot open FASTA file: " + path; return 1; }
-    out = FastaSet();
-    out.off.push_back(0);
-    size_t max_len = 0, min_len = SIZE_MAX;
-    size_t counts[4] = {0, 0, 0, 0};
-    std::string line, header, sequence;
-    auto flush = [&]() {
-        if (header.empty()) return;
-        if (sequence.empty()) {
-            fprintf(stderr, "Warning: Ignore FASTA entry without sequence: %s\n", path.c_str());
-            header.clear();
-            return;
-        }
-        const size_t L = sequence.size();
-        max_len = std::max(max_len, L);
-        min_len = std::min(min_len, L);
-        for (char c : sequence) {
-            const uint8_t code = base_code(c);
-            out.codes.push_back(code);
-            if (code) counts[code - 1]++;
-        }
-        out.off.push_back(out.codes.size());
-        out.headers.push_back(header);
-        sequence.clear();
-        header.clear();
-    };
-    while (std::getline(file, line)) {
-        if (line.empty()) continue;                          // blank lines are skipped
-        if (line[0] == '>') {
-            flush();
-            if (line.size() == 1) {
-                header = ">";
-            } else {                                         // up to the first TAB, then up to the first CR
-                header = line.substr(0, line.find('\t'));
-                header = header.substr(0, header.find('\r'));
-            }
-        } else if (!header.empty()) {
-            if (line.find(' ') != std::string::npos) {
-                err = "Error: FASTA sequence contains space character: " + path;
-                return 1;
-            }
-            sequence += line;
-        } else {
-            err = "Error: Wrong FASTA format: " + path;
+    // the whole file in one read, then a walk over its lines with memchr: same rules as the
+    // getline-based loop of SequenceSet::readFASTA (SequenceSet.cpp:67-225), without a string per line
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { err = "Error: Cannot open FASTA file: " + path; return 1; }
+    std::vector<char> buf;
+    {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        buf.resize(sz > 0 ? (size_t)sz : 0);
+        if (!buf.empty() && fread(buf.data(), 1, buf.size(), f) != buf.size()) {
+            fclose(f);
+            err = "Error: Cannot open FASTA file: " + path;
             return 1;
         }
+        fclose(f);
+    }
+    uint8_t lut[256];
+    for (int c = 0; c < 256; c++) lut[c] = base_code((char)c);
+    out = FastaSet();
+    out.off.push_back(0);
+    out.codes.reserve(buf.size());
+    size_t max_len = 0, min_len = SIZE_MAX;
+    size_t counts[5] = {0, 0, 0, 0, 0};                      // [0] = unknown bases
+    std::string header;
+    bool have_header = false;
+    size_t rec_start = 0;                                    // codes of the record being read start here
+    auto flush = [&]() {
+        if (!have_header) return;
+        have_header = false;
+        const size_t L = out.codes.size() - rec_start;
+        if (L == 0) {
+            fprintf(stderr, "Warning: Ignore FASTA entry without sequence: %s\n", path.c_str());
+            return;
+        }
+        max_len = std::max(max_len, L);
+        min_len = std::min(min_len, L);
+        out.off.push_back(out.codes.size());
+        out.headers.push_back(header);
+    };
+    const char* p = buf.data();
+    const char* const endp = p + buf.size();
+    while (p < endp) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(endp - p));
+        const char* le = nl ? nl : endp;                     // line = [p, le)
+        const size_t n = (size_t)(le - p);
+        if (n != 0) {                                        // blank lines are skipped
+            if (p[0] == '>') {
+                flush();
+                have_header = true;
+                rec_start = out.codes.size();
+                if (n == 1) {
+                    header = ">";
+                } else {                                     // up to the first TAB, then up to the first CR
+                    const char* tab = (const char*)memchr(p, '\t', n);
+                    const size_t h1 = tab ? (size_t)(tab - p) : n;
+                    const char* cr = (const char*)memchr(p, '\r', h1);
+                    header.assign(p, cr ? (size_t)(cr - p) : h1);
+                }
+            } else if (have_header) {
+                if (memchr(p, ' ', n)) {
+                    err = "Error: FASTA sequence contains space character: " + path;
+                    return 1;
+                }
+                const size_t o = out.codes.size();
+                out.codes.resize(o + n);
+                uint8_t* dst = out.codes.data() + o;
+                for (size_t i = 0; i < n; i++) {
+                    const uint8_t code = lut[(unsigned char)p[i]];
+                    dst[i] = code;
+                    counts[code]++;
+                }
+            } else {
+                err = "Error: Wrong FASTA format: " + path;
+                return 1;
+            }
+        }
+        p = nl ? nl + 1 : endp;
     }
     flush();
     out.max_len = max_len;
     out.min_len = out.size() ? min_len : 0;
-    const size_t sum = counts[0] + counts[1] + counts[2] + counts[3];
-    for (int i = 0; i < 4; i++) out.base_freq[i] = (float)counts[i] / (float)sum;
+    const size_t sum = counts[1] + counts[2] + counts[3] + counts[4];
+    for (int i = 0; i < 4; i++) out.base_freq[i] = (float)counts[i + 1] / (float)sum;
     return 0;
 }
 
