@@ -34,6 +34,10 @@ GROUPED_CASES = [
     dict(name="g_k1_m8", N=24, L0=230, W=9, K=1, ragged=8),
     dict(name="g_k2_m12", N=24, L0=370, W=14, K=2, ragged=10),
     dict(name="g_k0_m14", N=24, L0=430, W=11, K=0, n_frac=0.002, ragged=10),
+    # more than 16 groups (the E-chain's loop beyond four quads), single strand so that no sequence
+    # needs more virtual rows than 64 / T fix lanes allow
+    dict(name="g_k2_w40_ss", N=32, L0=400, W=40, K=2, ss=True, ragged=20),
+    dict(name="g_k1_w50_ss", N=32, L0=400, W=50, K=1, ss=True, ragged=20),
 ]
 
 
