@@ -640,7 +640,7 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
 }
 
 #define BAMM_FOR_EACH_GCLASS(X) \
-    X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) X(7, 8, 1024) X(8, 10, 512) X(9, 12, 512) X(10, 14, 512) X(11, 16, 512)
+    X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) X(7, 8, 1024) X(8, 10, 768) X(9, 12, 768) X(10, 14, 768) X(11, 16, 768)
 
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st) {
