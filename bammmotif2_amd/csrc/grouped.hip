@@ -171,8 +171,9 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
         uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
         if (row < g.Rf) { nreal = G; code = row; }
-        for (uint32_t d = 0; d < g.np; d++)
-            if (row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = (uint32_t)G - 1u - d; code = row - g.base[d]; }
+#pragma unroll
+        for (uint32_t d = 0; d < (uint32_t)(G - 1); d++)       // compile-time indices: no scratch copy of the arrays
+            if (d < g.np && row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = (uint32_t)G - 1u - d; code = row - g.base[d]; }
         uint32_t yc[G];
 #pragma unroll
         for (int c = 0; c < G; c++) yc[c] = (code >> (2u * ((nreal - 1u - c) & 15u))) & (Y - 1u);
@@ -507,9 +508,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
                     }
             }
-            for (uint32_t d = 0; d < g.np; d++) {            // partial rows: positions c < G-1-d are real
+#pragma unroll
+            for (uint32_t d = 0; d < (uint32_t)(G - 1); d++) {   // partial rows: positions c < G-1-d are real
                 const uint32_t nreal = (uint32_t)G - 1u - d;
-                if (c < nreal) {
+                if (d < g.np && c < nreal) {
                     const uint32_t lowd = 2u * (nreal - 1u - c);
                     for (uint32_t h = 0; h < (1u << (2u * c)); h++)
                         for (uint32_t l = 0; l < (1u << lowd); l++) {
