@@ -33,6 +33,7 @@ constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
 // (tools/lds_bench2.hip), so the read is issued by hand; lds_wait() retires all of them and
 // ties the results to the wait so that no consumer can be scheduled above it.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte global access at 4-byte alignment
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
 }

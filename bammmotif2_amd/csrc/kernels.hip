@@ -182,10 +182,26 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 
         if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
             float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
+            bool done = false;
+            if constexpr (M % 4 == 0) {
+                // a lane's M slots are M consecutive floats (descending): four at a time, 16-byte stores
+                // at 4-byte alignment, instead of M scattered dwords per lane
+                if (p0 + (uint32_t)M <= L) {
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const uint32_t p = p0 + m;
-                if (p < L) ro[L - 1u - p] = U[m];
+                    for (int m = 0; m < M; m += 4) {
+                        f32x4u v;
+                        v.x = U[m + 3]; v.y = U[m + 2]; v.z = U[m + 1]; v.w = U[m];
+                        *reinterpret_cast<f32x4u*>(ro + (L - 1u - (p0 + (uint32_t)m + 3u))) = v;
+                    }
+                    done = true;
+                }
+            }
+            if (!done) {
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const uint32_t p = p0 + m;
+                    if (p < L) ro[L - 1u - p] = U[m];
+                }
             }
         }
 
@@ -406,10 +422,23 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
         decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);
         const uint32_t shift = W - j1;                               // slot offset at column j1-1
         unsigned long long F[M];
+        bool loaded = false;
+        if constexpr (M % 4 == 0) {
+            if (r_reversed && p0 + (uint32_t)M + shift <= L) {     // the lane's M values in 16-byte loads
 #pragma unroll
-        for (int m = 0; m < M; m++) {
-            const uint32_t slot = p0 + m + shift;
-            F[m] = to_fixed40(slot < L ? rs[r_reversed ? L - 1u - slot : slot] : 0.0f);
+                for (int m = 0; m < M; m += 4) {
+                    const f32x4u v = *reinterpret_cast<const f32x4u*>(rs + (L - 1u - (p0 + (uint32_t)m + 3u + shift)));
+                    F[m] = to_fixed40(v.w); F[m + 1] = to_fixed40(v.z); F[m + 2] = to_fixed40(v.y); F[m + 3] = to_fixed40(v.x);
+                }
+                loaded = true;
+            }
+        }
+        if (!loaded) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t slot = p0 + m + shift;
+                F[m] = to_fixed40(slot < L ? rs[r_reversed ? L - 1u - slot : slot] : 0.0f);
+            }
         }
         bool dense = true;
         if (a.sparse_cap != 0u) {
