@@ -250,9 +250,18 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                         const unsigned long long Fe = ok ? listF[idx] : 0ull;
                         uint32_t q = ok ? (uint32_t)listP[idx] - (W - 1u) : 0u;     // window start i
                         unsigned long long* ncol = n_lds + copy;
-                        for (uint32_t j = 0; j < W; j++, q++, ncol += (Ys << logC)) {
-                            const uint32_t yq = ybuf[q];
-                            if (ok && yq != Y) atomicAdd(&ncol[yq << logC], Fe);
+                        // eight columns' y first, then their adds: one LDS round trip per batch instead of
+                        // one per column (row Y of a column is never read: adds that land there are dropped)
+                        const uint32_t cstride = Ys << logC;
+                        if (ok) {
+                            for (uint32_t jb = 0; jb < W; jb += 8u, q += 8u, ncol += 8u * cstride) {
+                                uint32_t yy[8];
+#pragma unroll
+                                for (int u = 0; u < 8; u++) yy[u] = (jb + u < W) ? (uint32_t)ybuf[q + u] : Y;
+#pragma unroll
+                                for (int u = 0; u < 8; u++)
+                                    if (jb + u < W) atomicAdd(&ncol[(size_t)u * cstride + (yy[u] << logC)], Fe);
+                            }
                         }
                     }
                 }
@@ -471,9 +480,16 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
                         // started at q - (j1-1); that window's column j is at q - (j1-1) + j
                         uint32_t q = (uint32_t)(ent >> 48) + j0 + 1u - j1;
                         unsigned long long* ncol = n_lds + copy;
-                        for (uint32_t j = j0; j < j1; j++, q++, ncol += (Ys << logC)) {
-                            const uint32_t yq = ybuf[q];
-                            if (yq != Y) atomicAdd(&ncol[yq << logC], Fe);
+                        // eight columns' y first, then their adds: one LDS round trip per batch instead of
+                        // one per column (row Y of every column is a dump nobody reads: no check)
+                        const uint32_t cstride = Ys << logC;
+                        for (uint32_t jb = j0; jb < j1; jb += 8u, q += 8u, ncol += 8u * cstride) {
+                            uint32_t yy[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) yy[u] = (jb + u < j1) ? (uint32_t)ybuf[q + u] : Y;
+#pragma unroll
+                            for (int u = 0; u < 8; u++)
+                                if (jb + u < j1) atomicAdd(&ncol[(size_t)u * cstride + (yy[u] << logC)], Fe);
                         }
                     }
                 }
