@@ -359,18 +359,19 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
                                         i + 1 == em->e_slices.size(), bk.blocks, threads, st);
             }
             a.logC = em->m_slice_logc;
+            const uint32_t mthreads = threads;
             {   // this bucket's list capacity: what fits next to the widest slice's count table
                 uint32_t widest = 0;
                 for (auto& sl : em->m_slices) widest = std::max(widest, sl.second - sl.first);
                 const size_t table = m_slice_lds_bytes(widest, em->Y, em->m_slice_logc);
                 uint32_t cap = em->m_slice_cap;
-                while (cap && table + (threads / 64u) * m_slice_wave_bytes(kMClasses[bk.mclass], cap) > 160u * 1024u) cap -= 64u;
+                while (cap && table + (mthreads / 64u) * m_slice_wave_bytes(kMClasses[bk.mclass], cap) > 160u * 1024u) cap -= 64u;
                 a.sparse_cap = cap;
                 a.sparse_wave_bytes = (uint32_t)m_slice_wave_bytes(kMClasses[bk.mclass], cap);
             }
             for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
                 rc = launch_m_slice(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second, em->e_fused,
-                                    bk.blocks, threads, st);
+                                    bk.blocks, mthreads, st);
         }
         if (rc) return rc;
         block_base += bk.blocks;
@@ -656,12 +657,14 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         const size_t scratch = getenv("BAMM_NO_SPARSE") ? 0 : m_slice_wave_bytes(Mmax, 256) * waves;
         uint32_t m_cols_sparse = 0;
         while (scratch && m_cols_sparse < prm->W && m_slice_lds_bytes(m_cols_sparse + 1, Y, 0) + scratch <= kLds) m_cols_sparse++;
-        if (m_cols_sparse && (prm->W + m_cols_sparse - 1) / m_cols_sparse == (prm->W + m_cols - 1) / m_cols) {
-            m_cols = m_cols_sparse;
-            em->m_slice_cap = 256;
-        }
+        // ... and when it would, the widest slices stay and every bucket takes the longest list that still
+        // fits beside them (run_accumulate): at k=4, W=30 a 128-entry list next to the 120 KB count slice
+        // is worth 20 % of the iteration
+        const bool roomy = m_cols_sparse && (prm->W + m_cols_sparse - 1) / m_cols_sparse == (prm->W + m_cols - 1) / m_cols;
+        if (roomy) m_cols = m_cols_sparse;
+        if (scratch) em->m_slice_cap = 256;
         const uint32_t per_m = cut(m_cols, em->m_slices);
-        const size_t used = em->m_slice_cap ? scratch : 0;
+        const size_t used = roomy ? scratch : std::min(scratch, kLds - std::min(kLds, m_slice_lds_bytes(per_m, Y, 0)));
         while (em->m_slice_logc < 4 && m_slice_lds_bytes(per_m, Y, em->m_slice_logc + 1) + used <= kLds) em->m_slice_logc++;
     }
     hipStream_t st = c->stream;
