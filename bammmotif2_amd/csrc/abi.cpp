@@ -532,7 +532,7 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
     for (uint64_t n = 0; n < s->n; n++) {
         int mc = m_class_for_len(s->h_len[n]);
         if (mc < 0) {
-            set_error("sequence %llu has %u positions; the kernels cover L <= %d (incl. reverse complement)",
+            set_error("sequence %llu has %u positions; the kernels cover L <= %d (reverse complement and separator included)",
                       (unsigned long long)(begin + n), s->h_len[n], 64 * kMClasses[kNumMClasses - 1]);
             return BAMM_ERR_UNSUPPORTED;
         }

@@ -32,9 +32,9 @@ inline size_t bg_offset(size_t k) { return (ipow4(k + 1) - 4) / 3; }
 inline size_t bg_size(size_t K) { return bg_offset(K + 1); }
 
 // positions-per-lane classes the sequence kernels are instantiated for (L <= 64*M)
-constexpr int kNumMClasses = 20;
+constexpr int kNumMClasses = 23;
 extern const int kMClasses[kNumMClasses];
-int m_class_for_len(uint32_t L);  // index into kMClasses, or -1 when L > 64*64
+int m_class_for_len(uint32_t L);  // index into kMClasses, or -1 when L > 64*128
 
 // ---------------------------------------------------------------- device views ----------
 struct SeqView {                 // one length bucket of a resident sequence set

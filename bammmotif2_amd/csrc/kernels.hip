@@ -34,7 +34,7 @@
 
 namespace bamm {
 
-const int kMClasses[kNumMClasses] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64};
+const int kMClasses[kNumMClasses] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64, 80, 96, 128};
 
 int m_class_for_len(uint32_t L) {
     for (int i = 0; i < kNumMClasses; i++)
@@ -44,7 +44,7 @@ int m_class_for_len(uint32_t L) {
 
 uint32_t max_threads_for_mclass(int mclass) {
     int M = kMClasses[mclass];
-    return M <= 8 ? 1024u : (M <= 20 ? 768u : 512u);   // 4 / 3 / 2 waves per SIMD: what the VGPR use of the class allows
+    return M <= 8 ? 1024u : (M <= 20 ? 768u : (M <= 64 ? 512u : 256u));   // 4 / 3 / 2 / 1 waves per SIMD: what the VGPR use of the class allows
 }
 
 namespace {
@@ -812,7 +812,8 @@ uint32_t pick_log_copies(uint32_t W, uint32_t Y, uint32_t blocks_per_cu, size_t 
 #define BAMM_FOR_EACH_MCLASS(X) \
     X(0, 1, 1024) X(1, 2, 1024) X(2, 3, 1024) X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) \
     X(7, 8, 1024) X(8, 10, 768) X(9, 12, 768) X(10, 14, 768) X(11, 16, 768) X(12, 20, 768)             \
-    X(13, 24, 512) X(14, 28, 512) X(15, 32, 512) X(16, 40, 512) X(17, 48, 512) X(18, 56, 512) X(19, 64, 512)
+    X(13, 24, 512) X(14, 28, 512) X(15, 32, 512) X(16, 40, 512) X(17, 48, 512) X(18, 56, 512) X(19, 64, 512) \
+    X(20, 80, 256) X(21, 96, 256) X(22, 128, 256)
 
 int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks,
                   uint32_t threads, hipStream_t st) {

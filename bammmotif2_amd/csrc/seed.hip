@@ -155,6 +155,7 @@ int launch_seed_pwm(SeedKernelArgs a, uint32_t num_cus, hipStream_t st) {
     a.wave_bytes = (uint32_t)seed_wave_bytes(a.max_len);
     const size_t want_counts = ((size_t)a.vsize * sizeof(int) + 15) & ~size_t(15);
     a.count_bytes = want_counts <= 48 * 1024 ? (uint32_t)want_counts : 0u;
+    if ((size_t)a.table_bytes + a.count_bytes + a.wave_bytes > kLds) a.count_bytes = 0u;   // long sequences: counts straight to HBM
     const size_t fixed = (size_t)a.table_bytes + a.count_bytes;
     if (fixed + a.wave_bytes > kLds) {
         set_error("PWM seeding: a sequence of %u positions does not fit the per-wave LDS arrays", a.max_len);

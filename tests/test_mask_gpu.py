@@ -14,7 +14,8 @@ from tests.test_parity_gpu import make_em
 
 pytestmark = pytest.mark.gpu
 
-CASES = [d for d in SMALL_CASES if d["W"] >= 2]
+CASES = [d for d in SMALL_CASES if d["W"] >= 2] + [
+    dict(name="m_long", N=6, L0=6100, W=12, K=2, ss=True, ragged=2000, n_frac=0.0005)]      # M = 80..128
 
 
 @pytest.mark.parametrize("oq", [False, True], ids=["fixq", "optq"])
