@@ -221,13 +221,14 @@ def main():
         avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
         alg_bytes = ALG_BYTES_PER_POSITION * local_positions
         achieved = alg_bytes / avg_kernel_s / 1e9
-        traffic = None
+        traffic, lds_busy = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("positions_per_launch") == local_positions:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    lds_busy = (tj.get("derived") or {}).get("lds_busy_frac")
             except Exception:
                 traffic = None
         out = {
@@ -254,6 +255,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         "lds_busy_frac": lds_busy,   # PMC: SQ_LDS_IDX_ACTIVE per CU / kernel cycles (profiles/hbm_traffic.json)
                          "note": "2-bit stream only; the kernel is LDS / VALU issue bound (DESIGN.md section 4)"},
             "llh_last": float(llh[-1]) if len(llh) else None,
         }

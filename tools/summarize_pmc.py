@@ -28,5 +28,15 @@ if main and "FETCH_SIZE" in summary[main] and "WRITE_SIZE" in summary[main]:
     res.update(kernel=main, fetch_size_kib=f, write_size_kib=w,
                hbm_bytes_per_launch=(2.0 * f + w) * 1024.0,
                hbm_bytes_per_launch_uncorrected=(f + w) * 1024.0)
+m = summary.get(main, {}) if main else {}
+if all(c in m for c in ("GRBM_GUI_ACTIVE", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_VALU")):
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs, the SQ_* counters over the 256 CUs (cycles of the CU's
+    # LDS / VALU pipes being busy): busy fraction = per-CU busy cycles / kernel cycles
+    XCDS, CUS = 8.0, 256.0
+    cyc = m["GRBM_GUI_ACTIVE"] / XCDS
+    res["derived"] = {"gpu_cycles_per_launch": cyc,
+                      "lds_busy_frac": m["SQ_LDS_IDX_ACTIVE"] / CUS / cyc,
+                      "lds_bank_conflict_frac": m["SQ_LDS_BANK_CONFLICT"] / CUS / cyc,
+                      "valu_busy_frac": m["SQ_ACTIVE_INST_VALU"] / CUS / cyc}
 json.dump(res, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_mean_counters"}))
