@@ -312,6 +312,10 @@ class EM:
         m = min(int(n.value), cap)
         return llh[:m].copy(), vd[:m].copy(), q[:m].copy()
 
+    def set_kernel_timing(self, every: int):
+        """Time passes 0, every, 2*every, ... of each call with HIP events (0 = none, 1 = all)."""
+        check(self.lib.bamm_em_set_kernel_timing(self.h, every))
+
     def kernel_time(self):
         ms, n = C.c_float(), C.c_uint32()
         check(self.lib.bamm_em_kernel_time(self.h, C.byref(ms), C.byref(n)))

@@ -218,7 +218,7 @@ def main():
                    "k_em_seq (fused E+M)" if g_seqs == 0 else "k_em_grp + k_em_seq (fused E+M)")
     if rank == 0:
         its = args.steps / dt
-        avg_kernel_s = kernel_ms / max(launches, 1) * 1e-3
+        avg_kernel_s = kernel_ms / launches * 1e-3 if launches else float('nan')
         alg_bytes = ALG_BYTES_PER_POSITION * local_positions
         achieved = alg_bytes / avg_kernel_s / 1e9
         traffic, lds_busy = None, None

@@ -186,8 +186,11 @@ int  bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64
  * (EM.cpp:112-115).  Returns up to cap entries, *n = entries available.                      */
 int  bamm_em_get_trace(bamm_em* em, float* llh, float* v_diff, float* q, uint32_t cap, uint32_t* n);
 /* device time of the sequence kernel over the last iterate()/optimize() call (HIP events on
- * the context's stream): total milliseconds and number of launches.                          */
+ * the context's stream): total milliseconds over the timed passes and their number.  Passes
+ * 0, every, 2*every, ... of a call are timed (default every = 8; 1 = all, 0 = none): an event
+ * pair takes ~6 us of stream time, which a short iteration would notice.                     */
 int  bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches);
+int  bamm_em_set_kernel_timing(bamm_em* em, uint32_t every);
 /* how one pass is laid out: sequences that go through the grouped-column kernel (grouped.hip)
  * and through the one-column-at-a-time kernel (kernels.hip), and the kernel launches per pass. */
 int  bamm_em_plan(bamm_em* em, uint64_t* grouped_seqs, uint64_t* percolumn_seqs, uint32_t* launches);
