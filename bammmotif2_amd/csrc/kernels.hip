@@ -590,19 +590,48 @@ __global__ void __launch_bounds__(THREADS) k_score(ScoreKernelArgs a) {
 }
 
 // ---- reduce the per-block partial tables (deterministic, fp64) ------------------------------
-// grid.x = ceil(W*Y/64) (+1 block when there are no cells), 1024 threads = 64 cells x 16 groups
+// grid.x = ceil(W*Y/64) blocks of 64 cells x 16 groups, + one block for the three statistics
 __global__ void __launch_bounds__(1024) k_reduce_partials(const unsigned long long* partial_n, const double* partial_stat,
                                                           uint32_t blocks, uint32_t W, uint32_t Y, double* red) {
     __shared__ double sh[16][64];
     const uint32_t C = partial_n ? W * Y : 0u;
+    if (blockIdx.x + 1u == gridDim.x) {
+        // statistics: llh, sum_r, n_seqs -- 256 groups of 4 lanes, summed over the lanes of a wave by
+        // shuffles (a fixed tree: the same bits every run), then over the 16 waves
+        const uint32_t k = threadIdx.x & 3u, grp = threadIdx.x >> 2;
+        double t = 0.0;
+        if (k < 3u)
+            for (uint32_t b = grp; b < blocks; b += 256u) t += partial_stat[(size_t)b * 4 + k];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+        if ((threadIdx.x & 63u) < 4u) sh[threadIdx.x >> 6][threadIdx.x & 3u] = t;
+        __syncthreads();
+        if (threadIdx.x < 3u) {
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; w++) acc += sh[w][threadIdx.x];
+            red[(size_t)W * Y + threadIdx.x] = acc;
+        }
+        return;
+    }
     const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t g = threadIdx.x >> 6;
     double acc = 0.0;
     if (c < C) {
-        // four loads in flight per thread (the chain of dependent loads was most of this kernel's 8.6 us);
-        // the partials are integers: the sums are exact below 2^53 whatever the order
+        // sixteen loads in flight per thread: with 256 partial tables the whole sum is one round trip
+        // (a chain of dependent loads was most of this kernel's 8.6 us).  The partials are integers:
+        // the sums are exact below 2^53 whatever the order
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         uint32_t b = g;
+        for (; b + 240u < blocks; b += 256u) {
+            unsigned long long x[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) x[u] = partial_n[(size_t)(b + 16u * (uint32_t)u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                a0 += (double)x[u]; a1 += (double)x[u + 1]; a2 += (double)x[u + 2]; a3 += (double)x[u + 3];
+            }
+        }
         for (; b + 48u < blocks; b += 64u) {
             a0 += (double)partial_n[(size_t)b * C + c];
             a1 += (double)partial_n[(size_t)(b + 16u) * C + c];
@@ -620,22 +649,6 @@ __global__ void __launch_bounds__(1024) k_reduce_partials(const unsigned long lo
         for (int i = 0; i < 16; i++) t += sh[i][threadIdx.x];
         const uint32_t j = c / Y, y = c % Y;               // LDS layout [j][y] -> ABI layout [y][j]
         red[(size_t)y * W + j] = t * kFixedScaleInv;
-    }
-    if (blockIdx.x == 0) {
-        __syncthreads();
-        // statistics: llh, sum_r, n_seqs
-        const uint32_t k = threadIdx.x & 3u, grp = threadIdx.x >> 2;   // 256 groups
-        double a2 = 0.0;
-        if (k < 3u)
-            for (uint32_t b = grp; b < blocks; b += 256u) a2 += partial_stat[(size_t)b * 4 + k];
-        double* flat = &sh[0][0];
-        flat[threadIdx.x] = a2;
-        __syncthreads();
-        if (threadIdx.x < 3u) {
-            double t = 0.0;
-            for (uint32_t i = 0; i < 256u; i++) t += flat[i * 4 + threadIdx.x];
-            red[(size_t)W * Y + threadIdx.x] = t;
-        }
     }
 }
 
@@ -922,7 +935,7 @@ int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t
 int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks, uint32_t W,
                            uint32_t Y, double* red, hipStream_t st) {
     const uint32_t C = partial_n ? W * Y : 0u;
-    const uint32_t grid = C ? (C + 63u) / 64u : 1u;
+    const uint32_t grid = (C + 63u) / 64u + 1u;             // + the statistics block
     hipLaunchKernelGGL(k_reduce_partials, dim3(grid), dim3(1024), 0, st, partial_n, partial_stat, blocks, W, Y, red);
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;
