@@ -195,6 +195,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # HIP events around every `every`-th pass: at least 16 samples of the sequence kernel over the timed
+    # region, at most one pair per two passes (a pair takes ~6 us of stream time)
+    em.set_kernel_timing(max(2, min(8, args.steps // 16)))
     em.iterate(args.warmup)
     barrier()
     t0 = time.perf_counter()

@@ -12,6 +12,8 @@ print("%s | %.3f ms/iter | %.1f it/s | %.2e pos/s | %s" % (d["config"]["workload
 run --nseq 50000
 run --nseq 1000000 --ss
 run --nseq 200000
-run --nseq 1000000 --len 500 --width 30 --order 4 --steps 5 --warmup 1
+run --nseq 1000000 --len 500 --width 30 --order 4 --steps 12 --warmup 12
 run --nseq 1000000 --order 1
 run --nseq 1000000 --order 0
+run --nseq 1000000 --order 3
+run --nseq 1000000 --len 500
