@@ -4,6 +4,8 @@ hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo
 """
 from __future__ import annotations
 
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -34,10 +36,29 @@ def is_stale() -> bool:
     return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """One builder at a time: the ranks of a multi-GPU run all pass through here at start-up."""
+    os.makedirs(OBJDIR, exist_ok=True)
+    with open(os.path.join(OBJDIR, ".lock"), "w") as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """One object per source (rebuilt only when it or a header changed, in parallel), then link."""
     if not force and not is_stale():
         return LIB
+    with _build_lock():
+        if not force and not is_stale():                     # another rank built it while this one waited
+            return LIB
+        return _build_library_locked(force, verbose)
+
+
+def _build_library_locked(force: bool, verbose: bool) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the gfx950 extension")
