@@ -109,7 +109,9 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
 
 /* ------------------------------------------------------------------ sequences ----------- */
 /* Uploads sequences [begin,end) of `p`; they stay resident and are shared (ref-counted) by
- * any number of EM handles -- CV folds pass a mask instead of copying (FDR.cpp:49-57).       */
+ * any number of EM handles -- CV folds pass a mask instead of copying (FDR.cpp:49-57).
+ * Envelope: every sequence at most 8192 positions (reverse complement and separator
+ * included, i.e. 4095 bp in the default double-strand mode); BAMM_ERR_UNSUPPORTED otherwise. */
 int  bamm_seqs_upload(bamm_ctx* ctx, const bamm_packed* p, uint64_t begin, uint64_t end,
                       bamm_seqs** out);
 int  bamm_seqs_destroy(bamm_seqs* s);
