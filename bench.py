@@ -179,13 +179,14 @@ def main():
         keep.append(red)
 
         def allreduce(_ptr, _n, _stream):
-            with torch.cuda.stream(tstream):   # RCCL waits for the count kernels, the update waits for RCCL
-                if args.dist_backend == "nccl":
-                    dist.all_reduce(red)
-                else:                          # self-test path: through the host
-                    host = red.cpu()
-                    dist.all_reduce(host)
-                    red.copy_(host)
+            # called with `tstream` current (see iterate() below): RCCL waits for the count kernels,
+            # the update waits for RCCL
+            if args.dist_backend == "nccl":
+                dist.all_reduce(red)
+            else:                              # self-test path: through the host
+                host = red.cpu()
+                dist.all_reduce(host)
+                red.copy_(host)
             return 0
 
         em.set_allreduce(allreduce)
@@ -198,12 +199,13 @@ def main():
     # HIP events around every `every`-th pass: at least 16 samples of the sequence kernel over the timed
     # region, at most one pair per two passes (a pair takes ~6 us of stream time)
     em.set_kernel_timing(max(2, min(8, args.steps // 16)))
-    em.iterate(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    em.iterate(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    with torch.cuda.stream(tstream):       # the context's stream is torch's current one for the callback
+        em.iterate(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        em.iterate(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
