@@ -276,6 +276,12 @@ uint32_t default_threads(const bamm_ctx* c, int mclass) {
     return std::min(t, max_threads_for_mclass(mclass));
 }
 
+// block size of one launch: the grouped kernel's longer length classes are built for fewer waves
+uint32_t bucket_threads(const bamm_ctx* c, const EmBucket& b) {
+    const uint32_t t = default_threads(c, b.mclass);
+    return b.grouped ? std::min(t, grp_max_threads(kMClasses[b.mclass])) : t;
+}
+
 uint32_t default_blocks(const bamm_ctx* c, uint32_t threads) {
     if (c->blocks) return c->blocks;
     const uint32_t cus = c->num_cus > 0 ? (uint32_t)c->num_cus : 256u;
@@ -351,7 +357,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
         a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
         a.partial_stat = em->d_partial_stat + (size_t)block_base * 4;
         a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
-        const uint32_t threads = default_threads(em->ctx, bk.mclass);
+        const uint32_t threads = bucket_threads(em->ctx, bk);
         if (!em->sliced) {
             rc = launch_fused(em, bk, accum, false, a, threads, st);
         } else {
@@ -726,8 +732,8 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
         }
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
-            grp_plan(prm->K, prm->W, Mcls, threads / 64u, 2 * with_exc > b.count, &gG, &glogc, &glayout) &&
-            grp_geometry(prm->K, prm->W, gG, Mcls, threads / 64u, true, glogc, glayout, &gg)) {
+            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, &gG, &glogc, &glayout) &&
+            grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge
             auto capable = [&](uint32_t n) {
@@ -771,7 +777,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     for (auto& b : em->ebuckets) total_work += b.work;
     em->total_blocks = 0;
     for (auto& b : em->ebuckets) {
-        const uint32_t threads = default_threads(c, b.mclass);
+        const uint32_t threads = bucket_threads(c, b);
         // 16 waves per CU saturate the LDS pipe (tools/lds_bench2.hip); the LDS left over goes
         // into private copies of the count table
         const uint32_t blocks_per_cu = sliced ? 1u : std::max(1u, 1024u / threads);
@@ -1151,7 +1157,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         a.s = em->s_last; a.q = em->q_last;                 // the E pass the caller last ran (EM.cpp:521)
         a.partial_n = nullptr; a.partial_stat = d_stat;
         a.r_out = d_r; a.r_base = base; a.seq_begin = (uint32_t)begin; a.seq_end = (uint32_t)end;
-        rc = launch_fused(em, bk, false, true, a, default_threads(em->ctx, bk.mclass), st);
+        rc = launch_fused(em, bk, false, true, a, bucket_threads(em->ctx, bk), st);
     }
     if (!rc) {
         hipError_t e = hipMemcpyAsync(out, d_r, total * sizeof(float), hipMemcpyDeviceToHost, st);

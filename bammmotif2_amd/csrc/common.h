@@ -93,6 +93,9 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
 bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t* G, uint32_t* logC,
               uint32_t* layout);   // false: use k_em_seq
 bool grp_supported_class(int M, uint32_t K);
+int launch_em_grp_long(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
+                       hipStream_t st);   // grouped_long.hip: 20..32 positions per lane
+uint32_t grp_max_threads(int M);   // block size the grouped kernel of this length class is built for
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st);
 

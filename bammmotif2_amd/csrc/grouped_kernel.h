@@ -1,0 +1,564 @@
+// gfx950 kernel of the fused EM pass with GROUPED motif columns (orders K <= 2).
+//
+// Same computation as k_em_seq (kernels.hip): EM::EStep refinement/EM.cpp:149-196, EM::MStep
+// EM.cpp:231-243 and the sum over r of EM.cpp:509-513 -- file:line relative to /root/reference/src.
+//
+// k_em_seq is bound by the LDS pipe: per (position, column) one odds-table gather and one count
+// add.  Here G neighbouring columns share ONE table row.  The row index of position p is the
+// (K+G)-mer ending at p -- 5 bases (1024 rows, G = 5-K) when the tables fit the 160 KiB of a CU,
+// else 4 bases (256 rows, G = 4-K) -- and the table entry of group t is the product of its G column
+// odds, so a window costs T = ceil(W/G) gathers / adds instead of W (7 instead of 20 at K=2, W=20):
+//
+//   U_t(p) = U_{t-1}(p-G) * sG[row(p)][t],      row(p) = kmer_[p] mod 4^(K+G)
+//   nG[t][row(p)] += r(window)                  (marginalised to n[j][y] once per block)
+//
+// What keeps this exact:
+//   * EM.cpp:167 truncation (positions >= L-W+1 take no part): a group cut by that edge only carries
+//     its leading columns.  Two table layouts (grp_geometry, chosen per launch): "partial" table rows
+//     for those G-1 group ends, or per-wave virtual rows like the ones below; beyond the edge the
+//     neutral row.
+//   * N randomisation (Sequence.cpp:38): next to an exception the k-mers of neighbouring positions
+//     disagree, so no (K+G)-mer describes the group.  Those group ends (a handful per sequence:
+//     the strand junction) get per-wave VIRTUAL rows: a few "fix" lanes compute their G-column
+//     products from the single-column table before the chain starts (the exact y of the positions
+//     involved travels inline with the sequence record), and after the M-step move what the
+//     virtual count rows collected into single-column bins.  The chain itself never sees an
+//     exception.  Sequences whose exceptions span more than the virtual rows go through k_em_seq
+//     instead (bamm_em_create splits the buckets).
+//   * counts are 64-bit fixed point (2^-40) as in k_em_seq: sums are exact and order-free, so the
+//     result is bit-identical to k_em_seq's for the same responsibilities.
+// Window products are rounded in a different order than the reference's left-to-right product
+// (groups first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
+//
+// What makes it fast beyond the smaller instruction count: wave priorities by
+// phase (the LDS-bound M-step ahead of the VALU-bound E-step), table rows padded to an odd number of
+// quads (rows start on all 16 bank-quads), a straight-line E-chain, the group index of the count
+// table in the add's immediate offset.
+//
+// Things measured and left out: a compacted list of the non-zero windows for
+// the M-step (built three ways; an LDS add costs in proportion to its active lanes, so 14 full adds
+// plus the list's writes, row reads and waits never beat the 49 sparse ones); the virtual-row counts
+// as no-return atomics on an HBM table instead of the LDS one (+0.19 ms per pass); per-step guards on
+// the run-time group count in the E-chain (each merge point costs M register moves: the chain is
+// straight-line over padded neutral slots instead).
+
+#pragma once
+#include "device_utils.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace bamm {
+namespace {
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // DS operations of one wave retire in order; this only pins the compiler's ordering
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int I> struct IntC { static constexpr int value = I; };
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {           // f(IntC<0>{}), f(IntC<1>{}), ... : compile-time indices
+    if constexpr (I < N) { f(IntC<I>{}); static_for<N, I + 1>(f); }
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
+    asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
+                 :: "v"(byte_addr), "v"(v), "s"(mask), "n"(OFF) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_b128_off(uint32_t byte_addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
+}
+
+template <int M>
+struct RawSeqG {
+    static constexpr int NSEL = (M + 14) / 16 + 1;
+    uint32_t seq, L;
+    uint32_t w[NSEL + 1];
+    uint4 xr;
+    bool ok;
+};
+
+template <int M>
+__device__ __forceinline__ RawSeqG<M> fetch_seq_g(const SeqView& sv, const uint4* xrec, uint32_t t, int lane) {
+    RawSeqG<M> r;
+    r.seq = pick_sequence(sv, t);
+    r.ok = !(sv.mask && !sv.mask[r.seq]);
+    r.L = sv.len[r.seq];
+    r.xr = xrec[r.seq];
+    // words past the sequence's end only feed positions >= L, whose rows are overridden; the
+    // stream buffer carries 80 words of slack behind the last sequence (bamm_seqs_upload)
+    const uint32_t* wp = sv.words + sv.word_off[r.seq];
+    const uint32_t wi0 = ((uint32_t)lane * M) >> 4;
+    r.w[0] = (wi0 >= 1u) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+    for (int i = 0; i < RawSeqG<M>::NSEL; i++) r.w[i + 1] = wp[wi0 + i];
+    return r;
+}
+
+// One step of the E-step chain: slots move up by G, the G lowest come from the previous lane.
+template <int M, int G>
+__device__ __forceinline__ void grp_step(float (&U)[M], const float (&f)[M]) {
+    float cy[G];
+#pragma unroll
+    for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]);
+#pragma unroll
+    for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * f[m];
+#pragma unroll
+    for (int m = 0; m < G; m++) U[m] = cy[m] * f[m];
+}
+
+// E-step chain over NQ quads of group slots, straight-line: EVERY slot of a quad is multiplied in
+// (the slots in front of the first real group hold 1.0f), so no branch sits between two steps and
+// the shift by G slots per step is pure register renaming.  A guard per step (T is a run-time
+// value) makes the compiler move all M registers at every merge point.
+template <int M, int G, int NQ>
+__device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]) {
+    static_assert(NQ >= 1 && NQ <= 4, "quads");
+#define BAMM_GRP_QUAD(JQ)                                                                       \
+    if constexpr (NQ > (JQ)) {                                                                  \
+        f32x4 sv[M];                                                                            \
+        _Pragma("unroll") for (int m = 0; m < M; m++) sv[m] = lds_read_b128_off<(JQ) * 16>(ra[m]); \
+        lds_wait<M>(sv);                                                                        \
+        float f[M];                                                                             \
+        if constexpr ((JQ) == 0) {                                                              \
+            _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = sv[m].x;                       \
+        } else {                                                                                \
+            _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].x;                       \
+            grp_step<M, G>(U, f);                                                               \
+        }                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].y;                           \
+        grp_step<M, G>(U, f);                                                                   \
+        _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].z;                           \
+        grp_step<M, G>(U, f);                                                                   \
+        _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = sv[m].w;                           \
+        grp_step<M, G>(U, f);                                                                   \
+    }
+    BAMM_GRP_QUAD(0)
+    BAMM_GRP_QUAD(1)
+    BAMM_GRP_QUAD(2)
+    BAMM_GRP_QUAD(3)
+#undef BAMM_GRP_QUAD
+}
+
+template <int M, int G, int KG, bool ACCUM, bool WRITE_R, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
+    static_assert(M >= G, "a group must not span more than two lanes");
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const EmKernelArgs& a = ga.e;
+    const GrpGeom& g = ga.g;
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
+    const uint32_t T = g.T, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
+    const uint32_t pad = 4u * Tq - T;                     // neutral table slots in front of the first real group
+    float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Rtot][Tq][4]
+    float* s1 = reinterpret_cast<float*>(lds_raw + g.off_s1);                             // [W][Y+1]
+    double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
+    // count table [Rtot][C][T], groups stored last to first: the M-step walks them in that order and
+    // reaches a (row, copy)'s next group through the add's immediate offset
+    unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);
+    unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]: counts of the virtual rows
+    const uint32_t logC = ACCUM ? a.logC : 0u;
+
+    // ---- block prologue: single-column table, grouped table, zeroed counts
+    for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
+    __syncthreads();
+    for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
+        uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
+        if (row < g.Rf) { nreal = G; code = row; }
+#pragma unroll
+        for (uint32_t d = 0; d < (uint32_t)(G - 1); d++)       // compile-time indices: no scratch copy of the arrays
+            if (d < g.np && row >= g.base[d] && row < g.base[d] + g.psize[d]) { nreal = (uint32_t)G - 1u - d; code = row - g.base[d]; }
+        uint32_t yc[G];
+#pragma unroll
+        for (int c = 0; c < G; c++) yc[c] = (code >> (2u * ((nreal - 1u - c) & 15u))) & (Y - 1u);
+        for (uint32_t t = 0; t < T; t++) {
+            float f = 1.0f;
+#pragma unroll
+            for (int c = 0; c < G; c++) {
+                const int col = (int)(G * t + c) - (int)delta;
+                if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
+            }
+            sg[row * g.rowstride + pad + t] = f;
+        }
+    }
+    // neutral slots of every row, and the virtual rows as a whole (their real slots are rewritten per sequence)
+    for (uint32_t i = threadIdx.x; i < Rtot * g.rowstride; i += blockDim.x) {
+        const uint32_t row = i / g.rowstride, slot = i - row * g.rowstride;
+        if (slot < 4u * Tq && (slot < pad || row > Rn)) sg[i] = 1.0f;
+    }
+    if (ACCUM) {
+        for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const float q = *a.q;
+    const float one_minus_q = 1.0f - q;
+    const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
+    const uint32_t vbase = g.R0 + wave * g.Bv;
+    const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+
+    double llh_acc = 0.0, sumr_acc = 0.0;
+    uint32_t seq_cnt = 0;
+    uint32_t last_LW1 = 0;
+    float pos_i = 0.0f;
+
+    uint32_t t = blockIdx.x * waves_per_block + wave;
+    RawSeqG<M> nxt{};
+    if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
+    for (; t < a.sv.count; t += total_waves) {
+        const RawSeqG<M> cur = nxt;
+        if (t + total_waves < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t + total_waves, lane);   // prefetch
+        const uint32_t seq = cur.seq;
+        if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
+        if (!cur.ok) continue;
+        // Wave priorities by phase (s_setprio): the M-step is LDS bound and issues few VALU instructions,
+        // the E-step is VALU bound.  With the M-step waves ahead in the issue arbitration the LDS pipe
+        // stays fed while the E-step waves take the VALU slots left over; staggering the E-step's own
+        // phases helps as well.  Measured on the bench workload: 1.26 -> 1.13 ms per pass (any order of
+        // priorities beats none; this one is the best of those tried).
+        __builtin_amdgcn_s_setprio(0);                       // decode, fix lanes
+        const uint32_t L = __builtin_amdgcn_readfirstlane(cur.L);   // one sequence per wave: uniform
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+
+        // ---- row index of every position; sE = the 32-bit stream window that ends at position LW1-1
+        uint32_t row[M];
+        uint32_t sE;
+        {
+            constexpr int NSEL = RawSeqG<M>::NSEL;
+            const uint32_t wi0 = p0 >> 4;
+            const uint32_t pE = LW1 - 1u, lpE = pE / (uint32_t)M;            // lane that holds position LW1-1
+            constexpr bool kOneWindow = 2 * (M - 1) + 10 <= 32;               // rows are at most 10 bits (K+G <= 5)
+            if constexpr (kOneWindow) {
+                // one 32-bit window of the stream ending at the lane's LAST position; position p0+m
+                // is that window shifted by a compile-time 2*(M-1-m) bits
+                const uint32_t pe = p0 + (uint32_t)(M - 1);
+                const uint32_t sel = (pe >> 4) - wi0;
+                uint32_t lo = cur.w[1], hi = cur.w[0];
+#pragma unroll
+                for (int c = 1; c < NSEL; c++) {
+                    lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
+                    hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
+                }
+                const uint32_t X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
+#pragma unroll
+                for (int m = 0; m < M; m++)
+                    row[m] = (p0 + m < LW1) ? ((X >> (2 * (M - 1 - m))) & (g.Rf - 1u)) : Rn;   // EM.cpp:167
+                if (g.np != 0u) {
+                    // groups cut by the LW1 edge read partial rows: G-1 positions of the whole sequence,
+                    // patched by their lane
+#pragma unroll
+                    for (int dd = 0; dd < G - 1; dd++) {
+                        const uint32_t pp = LW1 + (uint32_t)dd;
+                        if (pp < L) {
+                            const uint32_t lp = pp / (uint32_t)M, ms = pp - lp * (uint32_t)M;
+                            const uint32_t patch = g.base[dd] + ((X >> (2u * ((uint32_t)(M - 1) - ms) + 2u * (dd + 1))) & (g.psize[dd] - 1u));
+                            const bool mine = (uint32_t)lane == lp;
+#pragma unroll
+                            for (int m = 0; m < M; m++) row[m] = (mine && ms == (uint32_t)m) ? patch : row[m];
+                        }
+                    }
+                }
+                // lane lpE's window, shifted so that it ends at pE (at least 32 - 2(M-1) >= 10 bits stay valid)
+                sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
+            } else {
+                uint32_t vE = 0;
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    const uint32_t p = p0 + m;
+                    const uint32_t sel = (p >> 4) - wi0;
+                    uint32_t lo = cur.w[1], hi = cur.w[0];
+#pragma unroll
+                    for (int c = 1; c < NSEL; c++) {
+                        lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
+                        hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
+                    }
+                    const uint32_t v = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (p & 15u));   // kmer_[p] mod 4^16
+                    uint32_t r = (p < LW1) ? (v & (g.Rf - 1u)) : Rn;                              // EM.cpp:167
+                    if (g.np != 0u && p >= LW1) {
+                        const uint32_t d = p - LW1;
+#pragma unroll
+                        for (int dd = 0; dd < G - 1; dd++)
+                            if (d == (uint32_t)dd && p < L) r = g.base[dd] + ((v >> (2u * (dd + 1))) & (g.psize[dd] - 1u));
+                    }
+                    row[m] = r;
+                    vE = (p == pE) ? v : vE;
+                }
+                sE = (uint32_t)__builtin_amdgcn_readlane((int)vE, (int)lpE);
+            }
+        }
+
+        // ---- group ends that no table row describes get per-wave VIRTUAL rows:
+        //   * next to an N exception (Sequence.cpp:38): B positions from xlo on; the record carries the
+        //     exact y of the positions [xlo-G+1, xlo+B), 7 bits each (Y = none)
+        //   * cut by the EM.cpp:167 edge: positions LW1 .. LW1+G-2, whose groups keep only the columns
+        //     at positions < LW1 (y from the stream window sE; bamm_em_create keeps sequences with
+        //     exceptions next to the edge out of this kernel)
+        const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
+        const uint32_t B = (xw >> 12) & 0xfu;                // group ends next to exceptions (0: none)
+        const uint32_t xlo = xw & 0xfffu;
+        // group ends cut by the edge that need a virtual row: none when the table has partial rows for them
+        const uint32_t nE = g.np != 0u ? 0u : min((uint32_t)(G - 1), L - LW1);
+        uint32_t yfix[G];
+#pragma unroll
+        for (int c = 0; c < G; c++) yfix[c] = Y;
+        const bool fixJ = lane_b < B;                         // fix lanes: (b, t) = virtual row b, group t
+        const bool fixE = lane_b >= g.Bj && lane_b < g.Bj + nE;
+        const bool fix = fixJ || fixE;
+        const bool any_fix = (B | nE) != 0u;                 // wave-uniform
+        if (any_fix) {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
+                if (k2 < B) row[m] = vbase + k2;
+                if (k3 < nE) row[m] = vbase + g.Bj + k3;
+            }
+            if (fix) {
+                float f = 1.0f;
+#pragma unroll
+                for (int c = 0; c < G; c++) {
+                    const int col = (int)(G * lane_t + c) - (int)delta;
+                    uint32_t yc, pos;
+                    if (fixJ) {
+                        const uint32_t k = lane_b + (uint32_t)c;           // entry of position xlo-G+1+k
+                        pos = xlo + k - (uint32_t)(G - 1);                 // wraps for positions before the sequence
+                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                    } else {
+                        pos = LW1 + (lane_b - g.Bj) - (uint32_t)(G - 1) + (uint32_t)c;
+                        yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);   // only used when pos < LW1
+                    }
+                    if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
+                    yfix[c] = yc;
+                    if (yc != Y) f *= s1[(uint32_t)col * Ys + yc];
+                }
+                sg[(vbase + lane_b) * g.rowstride + pad + lane_t] = f;
+            }
+            wave_lds_sync();
+        }
+
+        // ---- E-step: slot p after group t holds the product of groups 0..t of the window whose
+        // group t ends at p (EM.cpp:167-176); after the last group that is window p-(W-1)
+        __builtin_amdgcn_s_setprio(2);                       // chain
+        float U[M];
+        {
+            uint32_t ra[M];
+            const uint32_t sg_base = lds_offset(sg);
+#pragma unroll
+            for (int m = 0; m < M; m++) ra[m] = sg_base + row[m] * (g.rowstride * 4u);
+            switch (Tq) {
+                case 1: grp_chain<M, G, 1>(ra, U); break;
+                case 2: grp_chain<M, G, 2>(ra, U); break;
+                case 3: grp_chain<M, G, 3>(ra, U); break;
+                case 4: grp_chain<M, G, 4>(ra, U); break;
+                default: {                                   // more than 16 groups: plain loop
+                    grp_chain<M, G, 4>(ra, U);
+                    for (uint32_t jq = 4; jq < Tq; jq++) {
+                        f32x4 sv[M];
+#pragma unroll
+                        for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m] + jq * 16u);
+                        lds_wait<M>(sv);
+                        float f[M];
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].x;
+                        grp_step<M, G>(U, f);
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].y;
+                        grp_step<M, G>(U, f);
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].z;
+                        grp_step<M, G>(U, f);
+#pragma unroll
+                        for (int m = 0; m < M; m++) f[m] = sv[m].w;
+                        grp_step<M, G>(U, f);
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);                       // normalisation, statistics
+        if (LW1 != last_LW1) {                           // EM.cpp:160; one IEEE division per distinct length
+            pos_i = q / (float)LW1;
+            last_LW1 = LW1;
+        }
+        float zpart = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t p = p0 + m;
+            const bool valid = (p + 1u >= W) && (p < L);
+            U[m] = valid ? U[m] * pos_i : 0.0f;          // EM.cpp:180
+            zpart += U[m];
+        }
+        const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
+        // 1/Z: v_rcp_f32 (1 ulp) + one Newton step (error well below an ulp; r = U * invZ stays within
+        // 1.5 ulp of the reference's U / Z, EM.cpp:185-187)
+        float invZ = __builtin_amdgcn_rcpf(Z);
+        invZ = fmaf(fmaf(-Z, invZ, 1.0f), invZ, invZ);
+#pragma unroll
+        for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187
+        // EM.cpp:195.  v_log_f32 (log2, 1 ulp of its result) times ln 2: as close to logf(Z) as Z itself is
+        // known (Z carries half an ulp of its own); the sum runs in fp64
+        llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);
+        sumr_acc += (double)invZ;                        // sum_i r[i] = 1 - (1-q)/Z  (EM.cpp:509-513), finished below
+        seq_cnt++;
+
+        if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
+            float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                if (p < L) ro[L - 1u - p] = U[m];
+            }
+        }
+
+        if (ACCUM) {
+            // ---- M-step (EM.cpp:236-242), grouped: at group t slot p holds r of the window whose
+            // group t ends at p; it goes to nG[t][row(p)].  The neutral row is a sink nobody reads.
+            __builtin_amdgcn_s_setprio(3);                   // M-step
+            unsigned long long F[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
+            const uint32_t ng_base = lds_offset(ng);
+
+            {
+                unsigned long long nz[M];
+                uint32_t rad[M];                             // byte address of (row, private copy), group T-1
+#pragma unroll
+                for (int m = 0; m < M; m++) {
+                    nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
+                    rad[m] = ng_base + (((row[m] << logC) + copy) * T) * 8u;
+                }
+                // F is a ring: after s steps logical slot m lives in F[(m + G*s) mod M]; the G slots
+                // that arrive from the next lane are shifted in place with one DPP pair each, and their
+                // non-zero masks with them (lane l takes lane l+1's value: mask >> 1)
+                for (uint32_t sb = 0; sb < T; sb += M) {
+                    static_for<M>([&](auto uc) {
+                        constexpr int u = decltype(uc)::value;
+                        if (sb + u < T) {
+                            constexpr int off = (G * u) % M;
+#pragma unroll
+                            for (int m = 0; m < M; m++)
+                                lds_add_u64_exec<8 * u>(rad[m], F[(m + off) % M], nz[(m + off) % M]);
+#pragma unroll
+                            for (int c = 0; c < G; c++) {
+                                const int idx = (M - G + c + G * (u + 1)) % M;
+                                F[idx] = wave_shl1_u64(F[idx]);
+                                nz[idx] >>= 1;
+                            }
+                        }
+                    });
+#pragma unroll
+                    for (int m = 0; m < M; m++) rad[m] += 8u * M;
+                }
+            }
+            // ---- virtual count rows -> single-column bins (exact: one window per cell)
+            if (any_fix) {
+                wave_lds_sync();
+                if (fix) {
+                    unsigned long long acc = 0ull;
+                    unsigned long long* cell = ng + ((size_t)((vbase + lane_b) << logC)) * T + (T - 1u - lane_t);
+                    for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[(size_t)c * T]; cell[(size_t)c * T] = 0ull; }
+                    if (acc != 0ull) {
+#pragma unroll
+                        for (int c = 0; c < G; c++) {
+                            const int col = (int)(G * lane_t + c) - (int)delta;
+                            if (yfix[c] != Y) atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            }
+        }
+    }
+
+    // ---- block epilogue: marginalise the grouped counts to n[j][y], statistics
+    lds_drain();
+    if (lane == 0) {
+        stat_lds[wave * 3 + 0] = llh_acc;
+        stat_lds[wave * 3 + 1] = (double)seq_cnt - (double)one_minus_q * sumr_acc;
+        stat_lds[wave * 3 + 2] = (double)seq_cnt;
+    }
+    __syncthreads();
+    if (ACCUM) {
+        unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
+        const uint32_t C = 1u << logC;
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) {
+            const uint32_t j = i / Y, yy = i - j * Y;
+            const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
+            unsigned long long acc = n1[i];
+            const unsigned long long* tab = ng + (T - 1u - t);          // + ((row << logC) + copy) * T
+            // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free
+            {
+                const uint32_t lowd = 2u * ((uint32_t)G - 1u - c);
+                for (uint32_t h = 0; h < (1u << (2u * c)); h++)
+                    for (uint32_t l = 0; l < (1u << lowd); l++) {
+                        const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
+                        // h digits above y overlap y's own upper digits unless c digits are really free:
+                        // the (K+G)-mer has exactly c digits above y_c, so the mask above is a no-op
+                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
+                    }
+            }
+#pragma unroll
+            for (uint32_t d = 0; d < (uint32_t)(G - 1); d++) {   // partial rows: positions c < G-1-d are real
+                const uint32_t nreal = (uint32_t)G - 1u - d;
+                if (d < g.np && c < nreal) {
+                    const uint32_t lowd = 2u * (nreal - 1u - c);
+                    for (uint32_t h = 0; h < (1u << (2u * c)); h++)
+                        for (uint32_t l = 0; l < (1u << lowd); l++) {
+                            const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
+                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
+                        }
+                }
+            }
+            out[i] = acc;
+        }
+    }
+    if (threadIdx.x < 3) {
+        double acc = 0.0;
+        for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
+        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+    }
+}
+
+template <int M, int G, int KG, int THREADS>
+void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
+    const size_t lds = a.g.lds_bytes;
+    if (write_r) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_em_grp<M, G, KG, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    } else if (accum) {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    } else {
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, false, THREADS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_em_grp<M, G, KG, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+    }
+}
+
+}  // namespace
+}  // namespace bamm
+
+// one length class of the dispatch switch (key = class * 64 + G * 8 + K + G), every (G, K+G) the planner can ask for
+#define BAMM_GRP_CASES(idx, M, T)                                                                           \
+    case idx * 64 + 2 * 8 + 4: launch_variant<M, 2, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 3 * 8 + 4: launch_variant<M, 3, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 4 * 8 + 4: launch_variant<M, 4, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 3 * 8 + 5: launch_variant<M, 3, 5, T>(accum, write_r, a, blocks, threads, st); break;   \
+    case idx * 64 + 4 * 8 + 5: launch_variant<M, 4, 5, T>(accum, write_r, a, blocks, threads, st); break;

@@ -38,6 +38,11 @@ GROUPED_CASES = [
     # needs more virtual rows than 64 / T fix lanes allow
     dict(name="g_k2_w40_ss", N=32, L0=400, W=40, K=2, ss=True, ragged=20),
     dict(name="g_k1_w50_ss", N=32, L0=400, W=50, K=1, ss=True, ragged=20),
+    # 20, 24, 28 and 32 positions per lane (512-thread blocks): ds sequences of 513..1023 bp
+    dict(name="g_k2_m20_24", N=20, L0=640, W=20, K=2, n_frac=0.001, ragged=110),      # L 1061..1501
+    dict(name="g_k2_m28_32", N=16, L0=890, W=17, K=2, n_frac=0.001, ragged=125),      # L 1531..2031
+    dict(name="g_k1_m32_ss", N=16, L0=1900, W=12, K=1, ss=True, ragged=140),
+    dict(name="g_k0_m24_ss", N=16, L0=1400, W=9, K=0, ss=True, n_frac=0.002, ragged=120),
 ]
 
 
