@@ -46,8 +46,8 @@
 
 namespace bamm {
 
-// length classes the grouped kernel is instantiated for: 4..32 positions per lane (M >= G)
-bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 4 && M <= 32; }
+// length classes the grouped kernel is instantiated for: 2..32 positions per lane (a plan needs M >= G)
+bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 2 && M <= 32; }
 // 4 / 3 / 2 waves per SIMD: the grouped kernel's register budget runs out one class earlier than k_em_seq's
 uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : 512u); }
 
@@ -139,7 +139,7 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
 // 4..16 positions per lane are instantiated here, 20..32 in grouped_long.hip (a translation unit of its
 // own: the two halves compile side by side)
 #define BAMM_FOR_EACH_GCLASS(X) \
-    X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) X(7, 8, 1024) X(8, 10, 768) X(9, 12, 768) X(10, 14, 768) X(11, 16, 768)
+    X(1, 2, 1024) X(2, 3, 1024) X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) X(7, 8, 1024) X(8, 10, 768) X(9, 12, 768) X(10, 14, 768) X(11, 16, 768)
 
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st) {

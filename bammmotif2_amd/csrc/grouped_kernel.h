@@ -533,6 +533,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 
 template <int M, int G, int KG, int THREADS>
 void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
+    if constexpr (M < G) {                                   // grp_geometry never plans a group wider than a lane's run
+        (void)accum; (void)write_r; (void)a; (void)blocks; (void)threads; (void)st;
+        return;
+    } else {
     const size_t lds = a.g.lds_bytes;
     if (write_r) {
         if (lds > 64 * 1024)
@@ -550,6 +554,7 @@ void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t b
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_em_grp<M, G, KG, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
     }
+}
 }
 
 }  // namespace

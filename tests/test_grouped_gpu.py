@@ -43,6 +43,10 @@ GROUPED_CASES = [
     dict(name="g_k2_m28_32", N=16, L0=890, W=17, K=2, n_frac=0.001, ragged=125),      # L 1531..2031
     dict(name="g_k1_m32_ss", N=16, L0=1900, W=12, K=1, ss=True, ragged=140),
     dict(name="g_k0_m24_ss", N=16, L0=1400, W=9, K=0, ss=True, n_frac=0.002, ragged=120),
+    # 2 and 3 positions per lane (short reads: 65..192 positions), where a group is as wide as a lane's run
+    dict(name="g_k2_m2_ds", N=200, L0=40, W=12, K=2, n_frac=0.002, ragged=6),        # L 69..93: G = 2
+    dict(name="g_k2_m3_ds", N=160, L0=80, W=10, K=2, n_frac=0.002, ragged=12),       # L 137..185: G = 3
+    dict(name="g_k1_m3_ss", N=160, L0=160, W=8, K=1, ss=True, ragged=30),            # G = 3 (4 does not fit a lane)
 ]
 
 
