@@ -17,3 +17,7 @@ run --nseq 1000000 --order 1
 run --nseq 1000000 --order 0
 run --nseq 1000000 --order 3
 run --nseq 1000000 --len 500
+run --nseq 300000 --len 750 --steps 30 --warmup 10
+run --nseq 300000 --len 1000 --steps 30 --warmup 10
+run --nseq 4000000 --len 40 --width 12 --steps 30 --warmup 10
+run --nseq 2000000 --len 90 --steps 30 --warmup 10
