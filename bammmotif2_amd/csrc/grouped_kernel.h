@@ -187,11 +187,13 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             }
             sg[row * g.rowstride + pad + t] = f;
         }
+        for (uint32_t slot = 0; slot < pad; slot++) sg[row * g.rowstride + slot] = 1.0f;   // neutral slots in front
     }
-    // neutral slots of every row, and the virtual rows as a whole (their real slots are rewritten per sequence)
-    for (uint32_t i = threadIdx.x; i < Rtot * g.rowstride; i += blockDim.x) {
-        const uint32_t row = i / g.rowstride, slot = i - row * g.rowstride;
-        if (slot < 4u * Tq && (slot < pad || row > Rn)) sg[i] = 1.0f;
+    // the virtual rows as a whole (their real slots are rewritten per sequence); a table row's neutral
+    // slots were written with the row
+    for (uint32_t i = threadIdx.x; i < (Rtot - Rn - 1u) * 4u * Tq; i += blockDim.x) {
+        const uint32_t row = Rn + 1u + i / (4u * Tq), slot = i % (4u * Tq);
+        sg[row * g.rowstride + slot] = 1.0f;
     }
     if (ACCUM) {
         for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
