@@ -1,0 +1,90 @@
+"""Randomised parity sweep (GPU): random shapes through one E+M step against the oracle's fp64
+restatement (1e-6 on v, the bar of test_grouped_kernel_matches_exact_arithmetic; every third case with a
+CV-fold mask) and the scorer bit-exact against the oracle.  Not collected by pytest (no test_ prefix); run on the GPU box:
+
+    python -m tests.fuzz_parity --n 300 --seed 1
+
+Prints one line per failing configuration and a summary; exit code 1 if anything failed."""
+from __future__ import annotations
+
+import argparse
+import sys
+
+import numpy as np
+
+import bammmotif2_amd as bm
+from oracle import Oracle
+from tests.cases import Case
+
+
+def random_spec(rng, i, budget):
+    K = int(rng.choice([0, 1, 2, 2, 2, 3, 4]))
+    ss = bool(rng.integers(0, 2))
+    W = int(rng.integers(1, 41 if K <= 2 else 25))
+    # positions per lane from 1 to 128: log-uniform length
+    Lmax = int(2 ** rng.uniform(np.log2(max(W + 2, 20)), np.log2(3000 if K <= 3 else 900)))
+    rag = int(rng.integers(0, max(1, Lmax // 3)))
+    L0 = Lmax if ss else max((Lmax - 1) // 2, W + rag + 1)
+    L0 = max(L0, W + rag + 1)
+    N = int(np.clip(budget // (L0 * (1 if ss else 2)), 6, 20000))
+    n_frac = float(rng.choice([0.0, 0.0, 0.001, 0.004, 0.02]))
+    return dict(name=f"f{i}", N=N, L0=L0, W=W, K=K, ss=ss, ragged=rag, n_frac=n_frac,
+                bg_order=int(rng.integers(0, 4)), seed=int(rng.integers(1, 1 << 30)))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--budget", type=int, default=60000, help="positions per case (sets the number of sequences)")
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    orc = Oracle()
+    ctx = bm.Context(0)
+    bad = 0
+    kernels = {}
+    for i in range(args.n):
+        spec = random_spec(rng, i, args.budget)
+        try:
+            c = Case(**spec)
+            seq, kmer, off, vbg = c.encode(orc)
+            pk = bm.PackedSeqs.from_kmers(kmer, off)
+            ss = bm.SeqSet(ctx, pk)
+            mask = None
+            if rng.random() < 0.3:                           # a CV fold over the shared resident set (FDR.cpp:49-57)
+                mask = (rng.random(c.N) < 0.7).astype(np.uint8)
+                mask[int(rng.integers(0, c.N))] = 1
+            em = bm.EM(ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, mask=mask)
+            g, o, _ = em.plan()
+            kernels["grouped" if g and not o else "per-column/sliced" if o and not g else "mixed"] = \
+                kernels.get("grouped" if g and not o else "per-column/sliced" if o and not g else "mixed", 0) + 1
+            if mask is None:
+                km_e, off_e = kmer, off
+            else:
+                keep = np.nonzero(mask)[0]
+                lens = np.diff(off.astype(np.int64))
+                km_e = np.concatenate([kmer[int(off[n]):int(off[n + 1])] for n in keep])
+                off_e = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.uint64)
+            v64, n64, llh64, _ = orc.em_step_f64(km_e, off_e, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+            em.iterate(1)
+            np.testing.assert_allclose(em.getV(), v64, rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(em.getCounts(), n64, rtol=3e-6, atol=2e-7)
+            # log Z per sequence in fp32 (v_log_f32): ~1e-8 absolute per term, the terms may cancel in the sum
+            np.testing.assert_allclose(em.trace()[0][-1], llh64, rtol=2e-6, atol=1e-5 + 1e-7 * len(off_e))
+            v = em.getV()
+            Kb = min(c.bg_order, c.K)
+            mops_o, zoops_o, z_o = orc.logodds(kmer, off, c.K, c.W, orc.log_s(v, vbg, c.K, c.W, Kb))
+            mops, zoops, z = bm.logodds(ctx, ss, c.K, c.W, c.bg_order, v, vbg)
+            assert np.array_equal(mops, mops_o) and np.array_equal(zoops, zoops_o) and np.array_equal(z, z_o), "scorer"
+            em.close(); ss.close()
+        except Exception as e:  # noqa: BLE001 -- report and go on
+            bad += 1
+            print("FAIL", spec, "->", type(e).__name__, str(e).replace("\n", " ")[:300], flush=True)
+        if (i + 1) % 25 == 0:
+            print(f"[{i + 1}/{args.n}] failures so far: {bad}", flush=True)
+    print("kernels:", kernels, "failures:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
