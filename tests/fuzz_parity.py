@@ -32,19 +32,15 @@ def random_spec(rng, i, budget):
                 bg_order=int(rng.integers(0, 4)), seed=int(rng.integers(1, 1 << 30)))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--n", type=int, default=100)
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--budget", type=int, default=60000, help="positions per case (sets the number of sequences)")
-    args = ap.parse_args()
-    rng = np.random.default_rng(args.seed)
-    orc = Oracle()
-    ctx = bm.Context(0)
+def run(n, seed, budget, ctx=None, orc=None, verbose=True):
+    """(failures, kernels used) over n random cases."""
+    rng = np.random.default_rng(seed)
+    orc = orc or Oracle()
+    ctx = ctx or bm.Context(0)
     bad = 0
     kernels = {}
-    for i in range(args.n):
-        spec = random_spec(rng, i, args.budget)
+    for i in range(n):
+        spec = random_spec(rng, i, budget)
         try:
             c = Case(**spec)
             seq, kmer, off, vbg = c.encode(orc)
@@ -80,8 +76,18 @@ def main():
         except Exception as e:  # noqa: BLE001 -- report and go on
             bad += 1
             print("FAIL", spec, "->", type(e).__name__, str(e).replace("\n", " ")[:300], flush=True)
-        if (i + 1) % 25 == 0:
-            print(f"[{i + 1}/{args.n}] failures so far: {bad}", flush=True)
+        if verbose and (i + 1) % 25 == 0:
+            print(f"[{i + 1}/{n}] failures so far: {bad}", flush=True)
+    return bad, kernels
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--budget", type=int, default=60000, help="positions per case (sets the number of sequences)")
+    args = ap.parse_args()
+    bad, kernels = run(args.n, args.seed, args.budget)
     print("kernels:", kernels, "failures:", bad)
     sys.exit(1 if bad else 0)
 
