@@ -13,7 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbamm_em.so")
-SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "mask.hip", "seed.hip", "abi.cpp", "pack.cpp"]
+SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "mask.hip", "seed.hip", "abi.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(CSRC, "grouped_kernel.h"),
            os.path.join(HERE, "..", "include", "bamm_em.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",

@@ -95,6 +95,8 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
 bool grp_supported_class(int M, uint32_t K);
 int launch_em_grp_long(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                        hipStream_t st);   // grouped_long.hip: 20..32 positions per lane
+int launch_em_grp_xl(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
+                     hipStream_t st);     // grouped_xl.hip: 40 / 48 positions per lane
 uint32_t grp_max_threads(int M);   // block size the grouped kernel of this length class is built for
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st);

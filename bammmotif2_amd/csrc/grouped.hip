@@ -46,10 +46,10 @@
 
 namespace bamm {
 
-// length classes the grouped kernel is instantiated for: 2..32 positions per lane (a plan needs M >= G)
-bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 2 && M <= 32; }
-// 4 / 3 / 2 waves per SIMD: the grouped kernel's register budget runs out one class earlier than k_em_seq's
-uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : 512u); }
+// length classes the grouped kernel is instantiated for: 2..48 positions per lane (a plan needs M >= G)
+bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 2 && M <= 48; }
+// 4 / 3 / 2 / 1 waves per SIMD: the grouped kernel's register budget runs out one class earlier than k_em_seq's
+uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : (M <= 32 ? 512u : 256u)); }
 
 // layout: bit 0 = groups cut by the LW1 edge as per-wave virtual rows (else partial table rows),
 //         bit 1 = odd number of quads per table row
@@ -136,8 +136,8 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
     return false;
 }
 
-// 4..16 positions per lane are instantiated here, 20..32 in grouped_long.hip (a translation unit of its
-// own: the two halves compile side by side)
+// 2..16 positions per lane are instantiated here, 20..32 in grouped_long.hip and 40 / 48 in grouped_xl.hip
+// (translation units of their own: the three parts compile side by side)
 #define BAMM_FOR_EACH_GCLASS(X) \
     X(1, 2, 1024) X(2, 3, 1024) X(3, 4, 1024) X(4, 5, 1024) X(5, 6, 1024) X(6, 7, 1024) X(7, 8, 1024) X(8, 10, 768) X(9, 12, 768) X(10, 14, 768) X(11, 16, 768)
 

@@ -11,6 +11,7 @@ namespace bamm {
 // arguments checked by launch_em_grp
 int launch_em_grp_long(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                        hipStream_t st) {
+    if (kMClasses[mclass] > 32) return launch_em_grp_xl(mclass, accum, write_r, a, blocks, threads, st);
     const uint32_t KG = a.e.K + a.g.G;
     switch (mclass * 64 + (int)a.g.G * 8 + (int)KG) {
         BAMM_FOR_EACH_GCLASS_LONG(BAMM_GRP_CASES)

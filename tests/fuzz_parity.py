@@ -62,6 +62,15 @@ def run(n, seed, budget, ctx=None, orc=None, verbose=True):
                 km_e = np.concatenate([kmer[int(off[n]):int(off[n + 1])] for n in keep])
                 off_e = np.concatenate([[0], np.cumsum(lens[keep])]).astype(np.uint64)
             v64, n64, llh64, _ = orc.em_step_f64(km_e, off_e, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+            # the E-only and r-writing flavours of the same kernels (EStep, getR) against the fp32 oracle
+            em.EStep()
+            Kb0 = min(c.bg_order, c.K)
+            r_o, _ = orc.estep(km_e, off_e, c.K, c.W, orc.linear_s(c.v0, vbg, c.K, c.W, Kb0), c.q)
+            Lmax = int(np.diff(off_e.astype(np.int64)).max())
+            if mask is None:
+                # W <= 2: the reference's sequential fp32 Z sum over near-equal terms rounds one-sidedly (3e-5 seen)
+                np.testing.assert_allclose(em.getR(), r_o, rtol=(5e-5 if c.W <= 2 else 2e-5) * max(1.0, 4e-4 * Lmax), atol=1e-12)
+            np.testing.assert_allclose(em.getLLH(), llh64, rtol=2e-6, atol=1e-5 + 1e-7 * len(off_e))
             em.iterate(1)
             np.testing.assert_allclose(em.getV(), v64, rtol=1e-6, atol=1e-9)
             np.testing.assert_allclose(em.getCounts(), n64, rtol=3e-6, atol=2e-7)

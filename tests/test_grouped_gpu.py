@@ -43,6 +43,10 @@ GROUPED_CASES = [
     dict(name="g_k2_m28_32", N=16, L0=890, W=17, K=2, n_frac=0.001, ragged=125),      # L 1531..2031
     dict(name="g_k1_m32_ss", N=16, L0=1900, W=12, K=1, ss=True, ragged=140),
     dict(name="g_k0_m24_ss", N=16, L0=1400, W=9, K=0, ss=True, n_frac=0.002, ragged=120),
+    # 40 and 48 positions per lane (256-thread blocks): 2049..3072 positions
+    dict(name="g_k2_m40_48", N=10, L0=1280, W=20, K=2, n_frac=0.0005, ragged=240),    # L 2081..3041
+    dict(name="g_k1_m40_48_ss", N=10, L0=2600, W=14, K=1, ss=True, n_frac=0.0005, ragged=460),
+    dict(name="g_k0_m48", N=6, L0=1500, W=8, K=0, ragged=30),                        # L 2941..3061
     # 2 and 3 positions per lane (short reads: 65..192 positions), where a group is as wide as a lane's run
     dict(name="g_k2_m2_ds", N=200, L0=40, W=12, K=2, n_frac=0.002, ragged=6),        # L 69..93: G = 2
     dict(name="g_k2_m3_ds", N=160, L0=80, W=10, K=2, n_frac=0.002, ragged=12),       # L 137..185: G = 3
@@ -67,6 +71,10 @@ def test_grouped_kernel_matches_oracle(spec, gpu_ctx, orc):
     if c.n_frac >= 0.004 and not c.ss:
         assert other > 0, "sequences with scattered N must fall to the per-column kernel"
     Kb = min(c.bg_order, c.K)
+    # beyond ~2500 windows the reference's sequential fp32 Z sum (EM.cpp:179-182) is itself 1e-5 off, and
+    # every r of the sequence carries that factor (test_grouped_kernel_matches_exact_arithmetic has the
+    # tight bar for these lengths)
+    long_seq = max(1.0, 4e-4 * c.L0 * (1 if c.ss else 2))
     for it in range(3):
         v = em.getV()
         em.EStep()
@@ -74,19 +82,19 @@ def test_grouped_kernel_matches_oracle(spec, gpu_ctx, orc):
         r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, c.q)
         r_g = em.getR()
         # products are rounded group-wise, not left to right: a few 2^-24 per window
-        np.testing.assert_allclose(r_g, r_o, rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(r_g, r_o, rtol=1e-5 * long_seq, atol=1e-12)
         assert np.array_equal(r_g == 0, r_o == 0)
         # Z_n is a wave tree sum here and a sequential fp32 loop over L-W+1 near-equal terms in the
         # reference (EM.cpp:179-182), whose rounding is one-sided when the terms are alike (W <= 2
         # seeds): up to ~1e-6 absolute per sequence on log Z_n
-        np.testing.assert_allclose(em.getLLH(), llh_o, rtol=2e-6, atol=2e-6 * c.N)
+        np.testing.assert_allclose(em.getLLH(), llh_o, rtol=2e-6, atol=2e-6 * c.N * long_seq ** 2)
         em.MStep()
         n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
         # the oracle accumulates N*(L-W+1) fp32 addends per cell like the reference; with
         # W <= 2 every window carries weight, which is its worst case (~sqrt(n) * 2^-24)
-        np.testing.assert_allclose(em.getCounts(), n_o, rtol=3e-5 if c.W <= 2 else 1e-5, atol=1e-6)
+        np.testing.assert_allclose(em.getCounts(), n_o, rtol=(3e-5 if c.W <= 2 else 1e-5) * long_seq, atol=1e-6)
         np.testing.assert_allclose(em.getV(), orc.update_v(n_o, c.A, vbg, c.K, c.W),
-                                   rtol=3e-5 if c.W <= 2 else 1e-5, atol=1e-9)
+                                   rtol=(3e-5 if c.W <= 2 else 1e-5) * long_seq, atol=1e-9)
     em.close(); ss.close()
 
 
