@@ -50,6 +50,40 @@ uint32_t max_threads_for_mclass(int mclass) {
 namespace {
 
 
+// ---- dense M-step walk over `ncols` columns, last column first ---------------------------------
+// F is kept as a ring: after t shifts logical slot m lives in F[(m+t) mod M]; the shift itself is one
+// in-place DPP pair on F[t] (the value leaving becomes the value arriving from the next lane), so no
+// register moves.  The ring index must be a compile-time value, i.e. the walk is unrolled: up to 32
+// positions per lane over a whole turn (M steps, M*M adds); beyond that a turn would be thousands of
+// adds, the compiler gives up on the unrolling and the arrays land in scratch memory (5x slower).
+// Those classes unroll 8 steps and then turn the ring back by 8 places (2*M register moves per 8*M adds).
+template <int M>
+__device__ __forceinline__ void dense_count_walk(uint32_t ncols, uint32_t col, uint32_t stride, const uint32_t (&ya)[M],
+                                                 unsigned long long (&F)[M], unsigned long long (&nz)[M],
+                                                 const unsigned long long (&padm)[M], const uint32_t (&y)[M], uint32_t Y) {
+    constexpr int TB = M <= 32 ? M : 8;
+    for (uint32_t jb = 0; jb < ncols; jb += TB) {
+#pragma unroll
+        for (int t = 0; t < TB; t++) {
+            if (jb + t < ncols) {
+#pragma unroll
+                for (int m = 0; m < M; m++)
+                    lds_add_slot<M>(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M], y[m] != Y);
+                F[t] = wave_shl1_u64(F[t]);
+                nz[t] = __ballot(F[t] != 0ull);
+                col -= stride;
+            }
+        }
+        if constexpr (TB < M) {
+            unsigned long long Fr[M], nr[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) { Fr[m] = F[(m + TB) % M]; nr[m] = nz[(m + TB) % M]; }
+#pragma unroll
+            for (int m = 0; m < M; m++) { F[m] = Fr[m]; nz[m] = nr[m]; }
+        }
+    }
+}
+
 // ---- fused E+M sequence kernel --------------------------------------------------------------
 template <int M, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
@@ -275,23 +309,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                 padm[m] = __ballot(y[m] != Y);           // positions beyond LW1 take no part (EM.cpp:236)
                 ya[m] = ((y[m] << logC) + copy) * 8u;
             }
-            uint32_t col = lds_offset(n_lds) + (W - 1u) * stride;
-            // F is kept as a ring: after t shifts logical slot m lives in F[(m+t) mod M]; the
-            // shift itself is one in-place DPP pair on F[t] (the value leaving becomes the value
-            // arriving from the next lane), so no register moves
-            for (uint32_t jb = 0; jb < W; jb += M) {
-#pragma unroll
-                for (int t = 0; t < M; t++) {
-                    if (jb + t < W) {
-#pragma unroll
-                        for (int m = 0; m < M; m++)
-                            lds_add_slot<M>(col + ya[m], F[(m + t) % M], padm[m], nz[(m + t) % M], y[m] != Y);
-                        F[t] = wave_shl1_u64(F[t]);
-                        nz[t] = __ballot(F[t] != 0ull);
-                        col -= stride;
-                    }
-                }
-            }
+            dense_count_walk<M>(W, lds_offset(n_lds) + (W - 1u) * stride, stride, ya, F, nz, padm, y, Y);
             }
         }
     }
@@ -505,20 +523,7 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
                 ya[m] = ((y[m] << logC) + copy) * 8u;
             }
             const uint32_t stride = (Ys << logC) * 8u;
-            uint32_t col = lds_offset(n_lds) + (nc - 1u) * stride;
-            for (uint32_t jb = 0; jb < nc; jb += M) {
-#pragma unroll
-                for (int t2 = 0; t2 < M; t2++) {
-                    if (jb + t2 < nc) {
-#pragma unroll
-                        for (int m = 0; m < M; m++)
-                            lds_add_slot<M>(col + ya[m], F[(m + t2) % M], padm[m], nz[(m + t2) % M], y[m] != Y);
-                        F[t2] = wave_shl1_u64(F[t2]);
-                        nz[t2] = __ballot(F[t2] != 0ull);
-                        col -= stride;
-                    }
-                }
-            }
+            dense_count_walk<M>(nc, lds_offset(n_lds) + (nc - 1u) * stride, stride, ya, F, nz, padm, y, Y);
         }
     }
     lds_drain();
