@@ -22,7 +22,7 @@ def random_spec(rng, i, budget):
     ss = bool(rng.integers(0, 2))
     W = int(rng.integers(1, 41 if K <= 2 else 25))
     # positions per lane from 1 to 128: log-uniform length
-    Lmax = int(2 ** rng.uniform(np.log2(max(W + 2, 20)), np.log2(3000 if K <= 3 else 900)))
+    Lmax = int(2 ** rng.uniform(np.log2(max(W + 2, 20)), np.log2(3000 if K <= 3 else 2600)))
     rag = int(rng.integers(0, max(1, Lmax // 3)))
     L0 = Lmax if ss else max((Lmax - 1) // 2, W + rag + 1)
     L0 = max(L0, W + rag + 1)
