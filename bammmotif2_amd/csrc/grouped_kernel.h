@@ -444,8 +444,12 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 // F is a ring: after s steps logical slot m lives in F[(m + G*s) mod M]; the G slots
                 // that arrive from the next lane are shifted in place with one DPP pair each, and their
                 // non-zero masks with them (lane l takes lane l+1's value: mask >> 1)
-                for (uint32_t sb = 0; sb < T; sb += M) {
-                    static_for<M>([&](auto uc) {
+                // up to 32 positions per lane a whole turn of the ring (M steps) is unrolled; the longer classes
+                // unroll 16 steps (motifs have rarely more groups) and then turn the ring back by 16 steps' worth
+                // (48 positions per lane: 1.5e11 -> 1.9e11 positions/s; at 32 the same change cost 17 %)
+                constexpr int UB = M <= 32 ? M : 16;
+                for (uint32_t sb = 0; sb < T; sb += UB) {
+                    static_for<UB>([&](auto uc) {
                         constexpr int u = decltype(uc)::value;
                         if (sb + u < T) {
                             constexpr int off = (G * u) % M;
@@ -460,8 +464,15 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                             }
                         }
                     });
+                    if constexpr (UB < M) {
+                        unsigned long long Fr[M], nr[M];
 #pragma unroll
-                    for (int m = 0; m < M; m++) rad[m] += 8u * M;
+                        for (int m = 0; m < M; m++) { Fr[m] = F[(m + G * UB) % M]; nr[m] = nz[(m + G * UB) % M]; }
+#pragma unroll
+                        for (int m = 0; m < M; m++) { F[m] = Fr[m]; nz[m] = nr[m]; }
+                    }
+#pragma unroll
+                    for (int m = 0; m < M; m++) rad[m] += 8u * UB;
                 }
             }
             // ---- virtual count rows -> single-column bins (exact: one window per cell)
