@@ -21,3 +21,7 @@ run --nseq 300000 --len 750 --steps 30 --warmup 10
 run --nseq 300000 --len 1000 --steps 30 --warmup 10
 run --nseq 4000000 --len 40 --width 12 --steps 30 --warmup 10
 run --nseq 2000000 --len 90 --steps 30 --warmup 10
+run --nseq 200000 --len 1250 --steps 20 --warmup 10
+run --nseq 200000 --len 1500 --steps 20 --warmup 10
+run --nseq 200000 --len 1500 --order 3 --steps 20 --warmup 10
+run --nseq 200000 --len 2000 --steps 20 --warmup 10
