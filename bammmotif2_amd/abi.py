@@ -44,7 +44,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void
 SYMBOLS = [
     "bamm_last_error", "bamm_version", "bamm_pack_kmers", "bamm_pack_kmer_ptrs", "bamm_pack_codes",
     "bamm_unpack_y", "bamm_packed_free", "bamm_shard_range", "bamm_ctx_create", "bamm_ctx_destroy",
-    "bamm_ctx_sync", "bamm_ctx_device_name", "bamm_ctx_set_launch", "bamm_seqs_upload",
+    "bamm_ctx_sync", "bamm_ctx_device_name", "bamm_ctx_set_launch", "bamm_ctx_set_tuning", "bamm_seqs_upload",
     "bamm_seqs_destroy", "bamm_seqs_info", "bamm_em_default_params", "bamm_em_create",
     "bamm_em_destroy", "bamm_em_estep", "bamm_em_mstep", "bamm_em_optimize_q", "bamm_em_iterate",
     "bamm_em_optimize", "bamm_em_mask", "bamm_em_accumulate", "bamm_em_reduce_buffer", "bamm_em_update", "bamm_em_set_reduce_buffer",
@@ -86,6 +86,7 @@ def load() -> C.CDLL:
     L.bamm_ctx_sync.argtypes = [vp]
     L.bamm_ctx_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.bamm_ctx_set_launch.argtypes = [vp, u32, u32]
+    L.bamm_ctx_set_tuning.argtypes = [vp, C.c_char_p, i]
     L.bamm_seqs_upload.argtypes = [vp, P(Packed), u64, u64, P(vp)]
     L.bamm_seqs_destroy.argtypes = [vp]
     L.bamm_seqs_info.argtypes = [vp, P(u64), P(u64), P(u32), P(u64)]

@@ -6,7 +6,9 @@ from __future__ import annotations
 
 import contextlib
 import fcntl
+import json
 import os
+import re
 import shutil
 import subprocess
 
@@ -16,13 +18,88 @@ LIB = os.path.join(HERE, "libbamm_em.so")
 SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "mask.hip", "seed.hip", "abi.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(CSRC, "grouped_kernel.h"),
            os.path.join(HERE, "..", "include", "bamm_em.h")]
+# -Rpass-analysis=kernel-resource-usage: registers / scratch / spills of every kernel go to the compiler's
+# stderr, which is kept per translation unit (build/<tu>.remarks) and checked by check_resources().
+# No -Wno-pass-failed: a `#pragma unroll` the compiler gave up on is reported (and, for the kernels with
+# hand-issued LDS reads, refused) instead of silently turning register arrays into scratch memory.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
-         "-Wall", "-Wno-unused-result", "-Wno-pass-failed"]
+         "-Wall", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
 OBJDIR = os.path.join(HERE, "build")
+RESOURCES = os.path.join(OBJDIR, "resources.json")
 
 
 def _obj(src: str) -> str:
     return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+
+
+def _remarks(src: str) -> str:
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".remarks")
+
+
+def _diagnostics(text: str) -> str:
+    """The compiler's warnings / errors without the kernel-resource-usage remarks."""
+    keep, skip = [], 0
+    for line in text.splitlines():
+        if "[-Rpass-analysis=kernel-resource-usage]" in line:
+            skip = 2 if "Function Name" in line else 0       # the remark's source excerpt (2 lines) follows its first line
+            continue
+        if skip:
+            skip -= 1
+            continue
+        keep.append(line)
+    return "\n".join(keep).strip()
+
+
+class KernelResourceError(RuntimeError):
+    pass
+
+
+def parse_resources(text: str) -> dict:
+    """{mangled kernel name: {vgprs, agprs, sgprs, scratch, vgpr_spill, sgpr_spill, occupancy}} from the
+    -Rpass-analysis=kernel-resource-usage remarks of one translation unit."""
+    out, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch",
+            "Occupancy [waves/SIMD]": "occupancy", "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill",
+            "LDS Size [bytes/block]": "lds"}
+    for m in re.finditer(r"remark:\s+([A-Za-z \[\]/]+): (\S+) \[-Rpass-analysis=kernel-resource-usage\]", text):
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None and k in keys:
+            cur[keys[k]] = int(v)
+    return out
+
+
+def check_resources(sources, failed_unrolls_fatal: bool = True) -> dict:
+    """Refuse a build in which some instruction touches the destination of an LDS read that is still in
+    flight (kernel_audit.py: the hand-issued `ds_read_b128` gathers are not valid until their
+    `s_waitcnt`; a compiler that spills or copies them in between stores garbage -- round 1: the grouped
+    kernel at 56 / 64 positions per lane), or in which the compiler reports an unroll it did not perform
+    in the translation units of the grouped kernel (-Wpass-failed: register arrays become scratch memory).
+    Writes build/resources.json: per kernel the compiler's register / scratch / spill figures and the
+    number of scratch instructions actually emitted."""
+    from . import kernel_audit
+    table, bad = {}, []
+    for s in sources:
+        text = open(_remarks(s)).read()
+        res = parse_resources(text)
+        violations, stats = kernel_audit.audit_object(_obj(s), os.path.join(OBJDIR, "audit"))
+        for name, st in stats.items():
+            res.setdefault(name, {}).update(st)
+        table.update(res)
+        for kernel, lineno, ins, regs in violations[:20]:
+            bad.append(f"{kernel}: `{ins}` (disassembly line {lineno}) touches v{regs} while the LDS read that writes "
+                       f"them is in flight ({s})")
+        if len(violations) > 20:
+            bad.append(f"... and {len(violations) - 20} more in {s}")
+        if failed_unrolls_fatal and s.startswith("grouped"):
+            bad += [f"{s}: {line.strip()}" for line in text.splitlines() if "-Wpass-failed" in line]
+    os.makedirs(OBJDIR, exist_ok=True)
+    with open(RESOURCES, "w") as fh:
+        json.dump(table, fh, indent=0, sort_keys=True)
+    if bad:
+        raise KernelResourceError("kernel audit failed:\n  " + "\n  ".join(bad))
+    return table
 
 
 def _stale(target: str, deps) -> bool:
@@ -66,14 +143,23 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), _obj(s)
-        if force or _stale(obj, [src] + HEADERS):
+        if force or _stale(obj, [src] + HEADERS) or not os.path.exists(_remarks(s)):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            jobs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, proc in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
+            log = open(_remarks(s) + ".tmp", "w")
+            jobs.append((s, cmd, subprocess.Popen(cmd, stderr=log), log))
+    for s, cmd, proc, log in jobs:
+        rc = proc.wait()
+        log.close()
+        text = open(_remarks(s) + ".tmp").read()
+        diag = _diagnostics(text)
+        if rc != 0 or "warning:" in diag or "error:" in diag:
+            print(diag)
+        if rc != 0:
+            raise subprocess.CalledProcessError(rc, cmd)
+        os.replace(_remarks(s) + ".tmp", _remarks(s))
+    check_resources([s for s in SOURCES if s.endswith(".hip")])
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))

@@ -72,6 +72,10 @@ struct bamm_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint32_t blocks = 0, threads = 0;   // 0 = default
+    // bamm_ctx_set_tuning: kernel-selection switches for benchmarks and the cross-kernel parity tests
+    bool use_grouped = true, use_sparse = true, use_e_fused = true;
+    uint32_t group_size = 0;            // 0 = planner's choice
+    int group_layout = -1;              // -1 = planner's choice
     int num_cus = 0;
     std::string name;
 };
@@ -118,8 +122,11 @@ struct bamm_em {
     size_t vsz = 0, cells = 0;
     float *d_vbg = nullptr, *d_A = nullptr, *d_v = nullptr, *d_n = nullptr, *d_s = nullptr;
     float *d_q = nullptr, *d_status = nullptr, *d_trace = nullptr;
-    // double buffers: the odds table / q the most recent E pass used stay intact for getR()
-    float *d_s_alt = nullptr, *d_q_alt = nullptr;
+    // the odds table / q the most recent E pass used stay intact for getR() and MStep(): s is double
+    // buffered (only the update writes it), q lives in three slots because EM::optimize_q() may write
+    // it between any two of EStep / MStep / getR (EM.cpp:93-99,505-519) -- see q_write_slot()
+    float *d_s_alt = nullptr;
+    float *d_qbuf[3] = {nullptr, nullptr, nullptr};
     const float *s_last = nullptr, *q_last = nullptr;
     uint32_t* d_iteration = nullptr;
     uint8_t* d_mask = nullptr;
@@ -412,18 +419,31 @@ int run_allreduce(bamm_em* em) {
     return BAMM_OK;
 }
 
-int run_update(bamm_em* em) {
+// The slot a new q may be written to: never the one the last E pass read (q_last: getR() and the
+// MStep() replay recompute r from it, the reference's r_ keeps the EStep's q, EM.cpp:139-200), the
+// current slot when that is free, else the third one.
+float* q_write_slot(bamm_em* em) {
+    if (em->d_q != em->q_last) return em->d_q;
+    for (float* p : em->d_qbuf)
+        if (p != em->q_last) return p;
+    return em->d_q;
+}
+
+// q_window: this pass is one of the first five of its optimize() / iterate() call, where the reference
+// re-estimates q (`iteration` is local to EM::optimize, EM.cpp:75-99)
+int run_update(bamm_em* em, bool q_window) {
     UpdateArgs u{};
     u.K = em->prm.K; u.W = em->prm.W; u.Kbg = em->Kbg;
     u.red = em->d_red; u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s_alt;
-    u.q = em->d_q; u.q_out = em->d_q_alt; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
-    u.iteration = em->d_iteration; u.optimize_q = em->prm.optimize_q;
+    float* q_out = q_write_slot(em);
+    u.q = em->d_q; u.q_out = q_out; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
+    u.iteration = em->d_iteration; u.optimize_q = (em->prm.optimize_q && q_window) ? 1 : 0;
     u.n_seqs_override = (double)em->prm.n_seqs_global;
     int rc = use_device(em->ctx);
     if (!rc) rc = launch_update(u, em->ctx->stream);
     if (rc) return rc;
     std::swap(em->d_s, em->d_s_alt);
-    std::swap(em->d_q, em->d_q_alt);
+    em->d_q = q_out;
     em->host_iteration++;
     em->estep_done = false;
     return BAMM_OK;
@@ -502,6 +522,22 @@ int bamm_ctx_set_launch(bamm_ctx* c, uint32_t blocks, uint32_t threads) {
     if (!c || (threads & 63u) || threads > 1024u) { set_error("threads must be a multiple of 64 <= 1024"); return BAMM_ERR_ARG; }
     c->blocks = blocks;
     c->threads = threads;
+    return BAMM_OK;
+}
+
+int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
+    if (!c || !key) { set_error("bamm_ctx_set_tuning: null argument"); return BAMM_ERR_ARG; }
+    const std::string k(key);
+    if (k == "grouped") c->use_grouped = value != 0;
+    else if (k == "sparse") c->use_sparse = value != 0;
+    else if (k == "e_fused") c->use_e_fused = value != 0;
+    else if (k == "group_size") {
+        if (value != 0 && (value < 2 || value > 4)) { set_error("group_size must be 0 (auto) or 2..4"); return BAMM_ERR_ARG; }
+        c->group_size = (uint32_t)value;
+    } else if (k == "group_layout") {
+        if (value < -1 || value > 3) { set_error("group_layout must be -1 (auto) or 0..3"); return BAMM_ERR_ARG; }
+        c->group_layout = value;
+    } else { set_error("bamm_ctx_set_tuning: unknown key '%s'", key); return BAMM_ERR_ARG; }
     return BAMM_OK;
 }
 
@@ -606,9 +642,10 @@ int bamm_em_destroy(bamm_em* em) {
     if (!em) return BAMM_OK;
     (void)hipSetDevice(em->ctx->device);
     (void)hipStreamSynchronize(em->ctx->stream);
-    for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_q,
+    for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->red_external ? nullptr : em->d_red),
-                    (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt, (void*)em->d_q_alt,
+                    (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt,
+                    (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
                     (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})
         (void)hipFree(p);
@@ -664,12 +701,12 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             return per;
         };
         cut(e_cols, em->e_slices);
-        em->e_fused = em_lds_bytes(prm->W, Y, false, 0, 0) <= kLds && !getenv("BAMM_NO_EFUSED");
+        em->e_fused = em_lds_bytes(prm->W, Y, false, 0, 0) <= kLds && c->use_e_fused;
         // sparse M-slices: room for a list of 256 windows + the y of every position per wave (8 waves per
         // block at the longest length class) is taken off the column budget when that costs no extra slice
         const int Mmax = kMClasses[m_class_for_len(seqs->max_len ? seqs->max_len : 1)];
         const uint32_t waves = max_threads_for_mclass(m_class_for_len(seqs->max_len ? seqs->max_len : 1)) / 64u;
-        const size_t scratch = getenv("BAMM_NO_SPARSE") ? 0 : m_slice_wave_bytes(Mmax, 256) * waves;
+        const size_t scratch = !c->use_sparse ? 0 : m_slice_wave_bytes(Mmax, 256) * waves;
         uint32_t m_cols_sparse = 0;
         while (scratch && m_cols_sparse < prm->W && m_slice_lds_bytes(m_cols_sparse + 1, Y, 0) + scratch <= kLds) m_cols_sparse++;
         // ... and when it would, the widest slices stay and every bucket takes the longest list that still
@@ -692,8 +729,9 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if ((rc = dev_alloc(&em->d_n, em->vsz))) return fail(rc);
     if ((rc = dev_alloc(&em->d_s, (size_t)prm->W * (Y + 1)))) return fail(rc);
     if ((rc = dev_alloc(&em->d_s_alt, (size_t)prm->W * (Y + 1)))) return fail(rc);
-    if ((rc = dev_upload(&em->d_q, &prm->q, 1, st))) return fail(rc);
-    if ((rc = dev_upload(&em->d_q_alt, &prm->q, 1, st))) return fail(rc);
+    for (auto& slot : em->d_qbuf)
+        if ((rc = dev_upload(&slot, &prm->q, 1, st))) return fail(rc);
+    em->d_q = em->d_qbuf[0];
     if ((rc = dev_alloc(&em->d_status, 8))) return fail(rc);
     if ((rc = dev_alloc(&em->d_trace, (size_t)em->prm.max_iterations * 3))) return fail(rc);
     if ((rc = dev_alloc(&em->d_iteration, 1))) return fail(rc);
@@ -716,7 +754,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     memset(em->h_status, 0, 8 * sizeof(float));
     // launches of one pass: every length bucket, split into the sequences the grouped-column kernel
     // takes (no exception, or all of them within its virtual rows) and the rest
-    const bool want_grouped = !sliced && prm->K <= 2u && !getenv("BAMM_NO_GROUPED");
+    const bool want_grouped = !sliced && prm->K <= 2u && c->use_grouped;
     for (auto& b : seqs->buckets) {
         const int Mcls = kMClasses[b.mclass];
         const uint32_t threads = default_threads(c, b.mclass);
@@ -732,7 +770,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
         }
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
-            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, &gG, &glogc, &glayout) &&
+            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge
@@ -787,7 +825,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             const int Mcls = kMClasses[b.mclass];
             size_t scratch = sliced ? 0 : sparse_wave_bytes(Mcls) * (threads / 64u);
             uint32_t cap = sliced ? 0u : sparse_cap_for(Mcls);
-            if (getenv("BAMM_NO_SPARSE")) { cap = 0; scratch = 0; }
+            if (!c->use_sparse) { cap = 0; scratch = 0; }
             if (cap && (em_lds_bytes(prm->W, Y, true, 0, scratch) > kLds / blocks_per_cu ||
                         pick_log_copies(prm->W, Y, blocks_per_cu, scratch) + 1 < pick_log_copies(prm->W, Y, blocks_per_cu, 0))) {
                 cap = 0;
@@ -844,7 +882,7 @@ int bamm_em_mstep(bamm_em* em) {
     em->prm.optimize_q = 0;                           // EM::MStep never touches q
     int rc = run_accumulate(em, true, true);          // with the (s, q) the EStep saw, even if q moved since
     if (!rc) rc = run_allreduce(em);
-    if (!rc) rc = run_update(em);
+    if (!rc) rc = run_update(em, false);
     em->prm.optimize_q = oq;
     return rc;
 }
@@ -855,10 +893,13 @@ int bamm_em_optimize_q(bamm_em* em) {
     if (rc) return rc;
     const double nseq = em->prm.n_seqs_global ? (double)em->prm.n_seqs_global : (double)em->h_status[5];
     const float q = (float)((nseq - (double)em->h_status[4] + 1.0) / (nseq + 2.0));   // EM.cpp:515
-    // into the other q buffer: the one the last EStep used stays intact for MStep()/getR()
-    BAMM_HIP(hipMemcpyAsync(em->d_q_alt, &q, sizeof(float), hipMemcpyHostToDevice, em->ctx->stream));
+    // the slot the last EStep read stays intact for MStep()/getR(), in whatever order the caller
+    // runs MStep() and optimize_q() (EM.cpp:93-99 has MStep first)
+    float* slot = q_write_slot(em);
+    BAMM_HIP(hipSetDevice(em->ctx->device));
+    BAMM_HIP(hipMemcpyAsync(slot, &q, sizeof(float), hipMemcpyHostToDevice, em->ctx->stream));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
-    std::swap(em->d_q, em->d_q_alt);
+    em->d_q = slot;
     return BAMM_OK;
 }
 
@@ -891,7 +932,8 @@ int bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_doubles) {
 
 int bamm_em_update(bamm_em* em) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
-    return run_update(em);
+    // hand-driven passes have no optimize() call to be local to: the handle's first five updates
+    return run_update(em, em->host_iteration < 5u);
 }
 
 int bamm_em_iterate(bamm_em* em, uint32_t n) {
@@ -900,7 +942,7 @@ int bamm_em_iterate(bamm_em* em, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) {
         int rc = run_accumulate(em, true);
         if (!rc) rc = run_allreduce(em);
-        if (!rc) rc = run_update(em);
+        if (!rc) rc = run_update(em, i < 5u);
         if (rc) return rc;
     }
     return BAMM_OK;
@@ -917,7 +959,7 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
         const float llh_prev = llh;
         int rc = run_accumulate(em, true);
         if (!rc) rc = run_allreduce(em);
-        if (!rc) rc = run_update(em);
+        if (!rc) rc = run_update(em, iteration <= 5u);                  // EM.cpp:99
         if (!rc) rc = fetch_status(em);
         if (rc) return rc;
         llh = em->h_status[0];
@@ -1043,7 +1085,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
         if (!rc) rc = record_event(em, false);
         if (!rc) rc = launch_reduce_partials(em->d_mask_partial_n, em->d_mask_partial_stat, mblocks, W, Y, em->d_red, st);
         if (!rc) rc = run_allreduce(em);
-        if (!rc) rc = run_update(em);
+        if (!rc) rc = run_update(em, false);
         if (!rc) rc = fetch_status(em);
         if (rc) break;
         llh = em->h_status[0];

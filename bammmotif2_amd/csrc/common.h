@@ -25,6 +25,18 @@ void set_error(const char* fmt, ...);
         }                                                                                     \
     } while (0)
 
+// raise a kernel's dynamic-LDS limit above the 64 KiB default; a refusal is reported here with the
+// size that was asked for, not later as a generic launch error
+inline int allow_lds(const void* kernel, size_t lds) {
+    if (lds <= 64 * 1024) return BAMM_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %zu) failed: %s", lds, hipGetErrorString(e));
+        return BAMM_ERR_HIP;
+    }
+    return BAMM_OK;
+}
+
 inline size_t ipow4(size_t e) { return size_t(1) << (2 * e); }
 inline size_t v_offset(size_t k, size_t W) { return W * ((ipow4(k + 1) - 4) / 3); }
 inline size_t v_size(size_t K, size_t W) { return v_offset(K + 1, W); }
@@ -90,8 +102,8 @@ struct GrpKernelArgs {
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply
 bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
                   GrpGeom* out);
-bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t* G, uint32_t* logC,
-              uint32_t* layout);   // false: use k_em_seq
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t forced_G, int forced_layout,
+              uint32_t* G, uint32_t* logC, uint32_t* layout);   // false: use k_em_seq
 bool grp_supported_class(int M, uint32_t K);
 int launch_em_grp_long(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                        hipStream_t st);   // grouped_long.hip: 20..32 positions per lane
@@ -138,7 +150,7 @@ struct UpdateArgs {
     float* trace;                // [cap][3]
     uint32_t trace_cap;
     uint32_t* iteration;         // device counter
-    int32_t optimize_q;
+    int32_t optimize_q;          // re-estimate q in this pass (EM.cpp:99: the first five passes of an optimize() call)
     double n_seqs_override;      // >0: use instead of red[..+2]
 };
 

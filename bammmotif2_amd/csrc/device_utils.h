@@ -49,14 +49,15 @@ __device__ __forceinline__ void lds_wait(f32x4 (&v)[M]) {
     for (int m = 1; m < M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
 }
 
-// One predicated 64-bit LDS add: exec <- pad & nz (both wave masks in SGPR pairs), ds_add_u64,
-// exec <- all lanes.  Replaces the compiler's v_cmp_u64 / s_nor / s_and_saveexec / s_or sequence
-// per atomic; valid because the call sites run with every lane of the wave active.  The adds are
+// One predicated 64-bit LDS add: exec <- exec & pad & nz (both wave masks in SGPR pairs; the incoming
+// exec is saved and restored, so a divergent caller keeps its masked-off lanes off), ds_add_u64.
+// Replaces the compiler's v_cmp_u64 / s_nor / s_and_saveexec / s_or sequence per atomic.  The adds are
 // fire-and-forget (no return): lds_drain() must run before anyone reads the table.
 __device__ __forceinline__ void lds_add_u64_masked(uint32_t byte_addr, unsigned long long v,
                                                    unsigned long long pad_mask, unsigned long long nz_mask) {
-    asm volatile("s_and_b64 exec, %2, %3\n\tds_add_u64 %0, %1\n\ts_mov_b64 exec, -1"
-                 :: "v"(byte_addr), "v"(v), "s"(pad_mask), "s"(nz_mask) : "memory");
+    unsigned long long saved;
+    asm volatile("s_and_b64 %0, %3, %4\n\ts_and_saveexec_b64 %0, %0\n\tds_add_u64 %1, %2\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(byte_addr), "v"(v), "s"(pad_mask), "s"(nz_mask) : "memory", "scc");
 }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // One slot of one column.  The long-sequence classes (M > 16) keep 2*M wave masks, more than the

@@ -110,10 +110,9 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
 // then as many private copies of the count table as the 160 KiB hold
 // `many_exceptions`: most sequences of the launch carry exceptions anyway (double-stranded sets: the
 // strand junction), so the fix lanes run per sequence whether or not the edge rows are virtual.
-bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t* G_out, uint32_t* logC_out,
-              uint32_t* layout_out) {
-    const uint32_t forced = getenv("BAMM_GRP_G") ? (uint32_t)atoi(getenv("BAMM_GRP_G")) : 0u;
-    const int forced_layout = getenv("BAMM_GRP_LAYOUT") ? atoi(getenv("BAMM_GRP_LAYOUT")) : -1;
+// forced / forced_layout: bamm_ctx_set_tuning("group_size" / "group_layout"), 0 / -1 = the planner's choice
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t forced, int forced_layout,
+              uint32_t* G_out, uint32_t* logC_out, uint32_t* layout_out) {
     // layouts in order of preference.  Sets with exceptions everywhere run the fix lanes per sequence
     // anyway: virtual edge rows cost them nothing extra, save the decode's partial-row patches and make
     // the tables small enough for the odd stride (K=2: 1.08 -> 1.01 ms, K=1: 1.05 -> 0.98 ms).  Clean

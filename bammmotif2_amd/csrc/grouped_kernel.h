@@ -64,10 +64,14 @@ __device__ __forceinline__ void static_for(F&& f) {           // f(IntC<0>{}), f
     if constexpr (I < N) { f(IntC<I>{}); static_for<N, I + 1>(f); }
 }
 
+// One predicated 64-bit LDS add with the predicate in an SGPR pair: exec <- exec & mask (the incoming
+// exec is saved, not assumed to be all lanes), ds_add_u64, exec <- saved.  Same three instructions as
+// forcing exec back to -1, but a divergent or partial-wave caller keeps its masked-off lanes off.
 template <int OFF>
 __device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
-    asm volatile("s_mov_b64 exec, %2\n\tds_add_u64 %0, %1 offset:%3\n\ts_mov_b64 exec, -1"
-                 :: "v"(byte_addr), "v"(v), "s"(mask), "n"(OFF) : "memory");
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %0, %3\n\tds_add_u64 %1, %2 offset:%4\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(byte_addr), "v"(v), "s"(mask), "n"(OFF) : "memory", "scc");
 }
 
 template <int OFF>
@@ -545,29 +549,26 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 }
 
 template <int M, int G, int KG, int THREADS>
-void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
+int launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
     if constexpr (M < G) {                                   // grp_geometry never plans a group wider than a lane's run
         (void)accum; (void)write_r; (void)a; (void)blocks; (void)threads; (void)st;
-        return;
+        set_error("grouped kernel: group of %d columns wider than a lane's %d positions", G, M);
+        return BAMM_ERR_UNSUPPORTED;
     } else {
-    const size_t lds = a.g.lds_bytes;
-    if (write_r) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_em_grp<M, G, KG, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
-    } else if (accum) {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
-    } else {
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, false, THREADS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_em_grp<M, G, KG, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        const size_t lds = a.g.lds_bytes;
+        int rc;
+        if (write_r) {
+            if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>), lds))) return rc;
+            hipLaunchKernelGGL((k_em_grp<M, G, KG, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        } else if (accum) {
+            if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>), lds))) return rc;
+            hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        } else {
+            if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, false, THREADS>), lds))) return rc;
+            hipLaunchKernelGGL((k_em_grp<M, G, KG, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
+        }
+        return BAMM_OK;
     }
-}
 }
 
 }  // namespace
@@ -575,8 +576,8 @@ void launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t b
 
 // one length class of the dispatch switch (key = class * 64 + G * 8 + K + G), every (G, K+G) the planner can ask for
 #define BAMM_GRP_CASES(idx, M, T)                                                                           \
-    case idx * 64 + 2 * 8 + 4: launch_variant<M, 2, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
-    case idx * 64 + 3 * 8 + 4: launch_variant<M, 3, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
-    case idx * 64 + 4 * 8 + 4: launch_variant<M, 4, 4, T>(accum, write_r, a, blocks, threads, st); break;   \
-    case idx * 64 + 3 * 8 + 5: launch_variant<M, 3, 5, T>(accum, write_r, a, blocks, threads, st); break;   \
-    case idx * 64 + 4 * 8 + 5: launch_variant<M, 4, 5, T>(accum, write_r, a, blocks, threads, st); break;
+    case idx * 64 + 2 * 8 + 4: if (int rc = launch_variant<M, 2, 4, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
+    case idx * 64 + 3 * 8 + 4: if (int rc = launch_variant<M, 3, 4, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
+    case idx * 64 + 4 * 8 + 4: if (int rc = launch_variant<M, 4, 4, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
+    case idx * 64 + 3 * 8 + 5: if (int rc = launch_variant<M, 3, 5, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
+    case idx * 64 + 4 * 8 + 5: if (int rc = launch_variant<M, 4, 5, T>(accum, write_r, a, blocks, threads, st)) return rc; break;

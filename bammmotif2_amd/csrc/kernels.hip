@@ -757,7 +757,7 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         const uint32_t it = *a.iteration + 1u;
         *a.iteration = it;
         float q = *a.q;
-        if (a.optimize_q && it <= 5u)                      // EM.cpp:99, :515
+        if (a.optimize_q)                                  // EM.cpp:515; the host applies EM.cpp:99's `iteration <= 5`
             q = (float)((nseq - sum_r + 1.0) / (nseq + 2.0));
         *a.q_out = q;
         a.status[0] = (float)llh;
@@ -785,23 +785,18 @@ __global__ void k_stat_only(const double* red, uint32_t cells, float* status) {
 template <int M, int THREADS>
 int launch_em_variant(bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks, uint32_t threads,
                       size_t lds, hipStream_t st) {
-    if (write_r)
+    int rc;
+    if (write_r) {
+        if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_seq<M, false, true, THREADS>), lds))) return rc;
         hipLaunchKernelGGL((k_em_seq<M, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
-    else if (accum)
+    } else if (accum) {
+        if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_seq<M, true, false, THREADS>), lds))) return rc;
         hipLaunchKernelGGL((k_em_seq<M, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
-    else
+    } else {
+        if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_seq<M, false, false, THREADS>), lds))) return rc;
         hipLaunchKernelGGL((k_em_seq<M, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
-    return 0;
-}
-
-template <int M, int THREADS>
-void set_em_lds_attr(size_t lds) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_seq<M, true, false, THREADS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_seq<M, false, false, THREADS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_em_seq<M, false, true, THREADS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    return BAMM_OK;
 }
 
 }  // namespace
@@ -848,8 +843,7 @@ int launch_em_seq(int mclass, bool accum, bool write_r, const EmKernelArgs& a, u
     switch (mclass) {
 #define X(idx, M, T)                                                   \
     case idx:                                                          \
-        if (lds > 64 * 1024) set_em_lds_attr<M, T>(lds);               \
-        launch_em_variant<M, T>(accum, write_r, a, blocks, threads, lds, st); \
+        if (int rc = launch_em_variant<M, T>(accum, write_r, a, blocks, threads, lds, st)) return rc; \
         break;
         BAMM_FOR_EACH_MCLASS(X)
 #undef X
@@ -876,9 +870,7 @@ int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
     switch (mclass) {
 #define X(idx, M, T)                                                                                   \
     case idx:                                                                                          \
-        if (lds > 64 * 1024)                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_e_slice<M, T>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_e_slice<M, T>), lds)) return rc;                 \
         hipLaunchKernelGGL((k_e_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1, last ? 1 : 0); \
         break;
         BAMM_FOR_EACH_MCLASS(X)
@@ -896,9 +888,7 @@ int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
     switch (mclass) {
 #define X(idx, M, T)                                                                                   \
     case idx:                                                                                          \
-        if (lds > 64 * 1024)                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_m_slice<M, T>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_m_slice<M, T>), lds)) return rc;                 \
         hipLaunchKernelGGL((k_m_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1, r_reversed ? 1 : 0); \
         break;
         BAMM_FOR_EACH_MCLASS(X)
@@ -922,9 +912,7 @@ int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t
     switch (mclass) {
 #define X(idx, M, T)                                                                                   \
     case idx:                                                                                          \
-        if (lds > 64 * 1024)                                                                           \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_score<M, T>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_score<M, T>), lds)) return rc;                 \
         hipLaunchKernelGGL((k_score<M, T>), dim3(blocks), dim3(threads), lds, st, a);                  \
         break;
         BAMM_FOR_EACH_MCLASS(X)

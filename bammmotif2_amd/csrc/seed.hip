@@ -164,8 +164,7 @@ int launch_seed_pwm(SeedKernelArgs a, uint32_t num_cus, hipStream_t st) {
     const uint32_t waves = (uint32_t)std::min<size_t>(16, (kLds - fixed) / a.wave_bytes);
     const size_t lds = fixed + (size_t)waves * a.wave_bytes;
     const uint32_t blocks = std::max(1u, std::min(num_cus ? num_cus : 256u, (a.sv.count + waves - 1u) / waves));
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seed_pwm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (int rc = allow_lds(reinterpret_cast<const void*>(&k_seed_pwm), lds)) return rc;
     hipLaunchKernelGGL(k_seed_pwm, dim3(blocks), dim3(waves * 64u), lds, st, a);
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;

@@ -149,6 +149,12 @@ class Context:
     def set_launch(self, blocks: int = 0, threads: int = 0):
         check(self.lib.bamm_ctx_set_launch(self.h, blocks, threads))
 
+    def set_tuning(self, **kv):
+        """Kernel-selection switches for EM handles created afterwards (include/bamm_em.h:
+        grouped, group_size, group_layout, sparse, e_fused)."""
+        for k, v in kv.items():
+            check(self.lib.bamm_ctx_set_tuning(self.h, k.encode(), int(v)))
+
     def close(self):
         if self.h:
             self.lib.bamm_ctx_destroy(self.h)

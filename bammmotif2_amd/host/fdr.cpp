@@ -322,29 +322,35 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
         std::sort(negMax.begin(), negMax.end(), std::greater<float>());
         size_t ip = 0, in = 0, min_idx_pos = 0;
         const size_t posN_est = static_cast<size_t>(q * (float)posN);
-        const size_t n_top = (size_t)std::fmin(100, negN / 10);
+        // The strided CV split (FDR.cpp:49-60) drops the last posN % cvFold positives and keeps
+        // cvFold * floor(negN / cvFold) negative scores, so the lists can be shorter than posN / negN.  The
+        // reference walks posN + negN steps regardless and reads past the end of both (FDR.cpp:227-239);
+        // here the walk covers the scores that exist -- the same rows whenever the counts divide evenly.
+        const size_t nP = posMax.size(), nN = negMax.size();
+        size_t n_top = (size_t)std::fmin(100, negN / 10);
+        if (n_top >= nN) n_top = nN ? nN - 1 : 0;
         float lambda = 1e-16f;
         for (size_t l = 0; l < n_top; l++) lambda += negMax[l] - negMax[n_top];
         lambda /= n_top;
         float Sl = 0.f;
-        auto P = [&](size_t i) { return i < posMax.size() ? posMax[i] : -INFINITY; };
-        auto N = [&](size_t i) { return i < negMax.size() ? negMax[i] : -INFINITY; };
-        for (size_t i = 0; i < posN + negN; i++) {
-            if ((P(ip) > N(in) || ip == 0 || in == negN) && ip < posN) {
+        auto P = [&](size_t i) { return i < nP ? posMax[i] : -INFINITY; };
+        auto N = [&](size_t i) { return i < nN ? negMax[i] : -INFINITY; };
+        for (size_t i = 0; i < nP + nN; i++) {
+            if ((P(ip) > N(in) || ip == 0 || in >= nN) && ip < nP) {
                 Sl = posMax[ip];
                 ip++;
-            } else if (P(ip) == N(in) && rand() % 2 == 0 && ip < posN) {     // same evaluation order: rand() drawn on every tie
+            } else if (P(ip) == N(in) && rand() % 2 == 0 && ip < nP) {       // same evaluation order: rand() drawn on every tie
                 Sl = posMax[ip];
                 ip++;
             } else {
-                Sl = N(in);
+                Sl = negMax[in];                                             // in < nN: both lists cannot be exhausted inside the walk
                 in++;
             }
             const float TP = (float)ip, FP = (float)in / mFold;
             r.zoops_tp.push_back(TP);
             r.zoops_fp.push_back(FP);
             float p_value;
-            if (Sl <= negMax[n_top]) {
+            if (nN && Sl <= negMax[n_top]) {
                 auto lo = std::lower_bound(negMax.begin(), negMax.end(), Sl, std::greater<float>());
                 auto up = std::upper_bound(negMax.begin(), negMax.end(), Sl, std::greater<float>());
                 const float Sl_upper = (lo == negMax.begin()) ? Sl : *(lo - 1);
@@ -352,15 +358,17 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
                 // with its vectors that is untouched zero-filled heap, so 0 is what it computes with
                 const float Sl_lower = (up == negMax.end()) ? 0.0f : *up;
                 p_value = (in + (Sl_upper - Sl) / (Sl_upper - Sl_lower + 1e-5)) / (float)negN;
-            } else {
+            } else if (nN) {
                 p_value = n_top * expf((negMax[n_top] - Sl) / lambda) / negN;
+            } else {
+                p_value = 1.0f;                                              // no negative score at all
             }
             r.pn_pvalue.push_back(p_value);
             if (ip == posN_est) min_idx_pos = i;
             r.zoops_fdr.push_back(FP / (TP + FP));
             r.zoops_rec.push_back(TP / (float)posN);
         }
-        r.occ_frac = 1.0f - r.zoops_fp[min_idx_pos] / (float)posN;
+        r.occ_frac = r.zoops_fp.empty() ? 1.0f : 1.0f - r.zoops_fp[min_idx_pos] / (float)posN;
     }
     if (with_pvalues) {                                // FDR.cpp:278-333
         auto pv = [](std::vector<float>& pos, std::vector<float>& neg, std::vector<float>& out) {

@@ -47,6 +47,7 @@ void print_help() {
     printf("\t\t --EM   -q <FLOAT> (0.3)   --optimizeQ   --verbose   --saveBaMMs   --saveInitialBaMMs\n");
     printf("\t EXTENSIONS of this build:\n");
     printf("\t\t --maxEMIterations <INT> (1000)   -e, --epsilon <FLOAT> (0.01)   --device <INT> (0)\n");
+    printf("\t\t --timing (wall time per stage on stderr)   --hostSeeding (initFromPWM's pass on the host)\n");
     printf("\n==================================================================\n");
 }
 
@@ -134,6 +135,7 @@ struct Options {                       // Global.cpp:6-96 defaults
     size_t cvFold = 4, mFold = 1, sOrder = 2, threads = 4;
     uint32_t max_iter = 1000;
     int device = 0;
+    bool timing = false, hostSeeding = false;
 };
 
 template <class T>
@@ -234,6 +236,8 @@ Options parse(int nargs, char** args) {
     a.get(0, "maxEMIterations", o.max_iter);
     a.get('e', "epsilon", o.epsilon);
     a.get(0, "device", o.device);
+    o.timing = a.present(0, "timing");
+    o.hostSeeding = a.present(0, "hostSeeding");
     if (a.remain()) {
         print_help();
         std::cerr << "Oops! Unknown option(s) remaining... \n\n";
@@ -246,8 +250,8 @@ Options parse(int nargs, char** args) {
 
 int main(int nargs, char* args[]) {
     auto t0_wall = std::chrono::high_resolution_clock::now();
-    // BAMM_TIMING=1: wall time per stage on stderr (stdout stays the reference's)
-    const bool timing = getenv("BAMM_TIMING") != nullptr;
+    // --timing: wall time per stage on stderr (stdout stays the reference's)
+    bool timing = false;
     auto t_stage = t0_wall;
     auto stage = [&](const char* what) {
         if (!timing) return;
@@ -263,6 +267,7 @@ int main(int nargs, char* args[]) {
               << "======================================" << std::endl;
     srand(42);                                               // mainBaMM.cpp:22
     Options o = parse(nargs, args);
+    timing = o.timing;
     if (o.alphabet != "STANDARD") die("Error: this build supports --alphabet STANDARD only.");
     if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
     if (o.saveLogOdds) die("Error: --saveLogOdds is not ported.");
@@ -276,6 +281,19 @@ int main(int nargs, char* args[]) {
     bamm_packed* packed = nullptr;
     if (bamm_pack_codes(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, &packed)) die_abi("packing sequences");
     stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
+    // the sequence kernels hold one sequence per wavefront, at most 128 positions per lane (DESIGN.md
+    // section 4, envelope): name the records beyond that instead of failing at the upload
+    if ((o.EM || o.score || o.FDR) && packed->max_len > BAMM_MAX_SEQ_POSITIONS) {
+        size_t shown = 0, total = 0;
+        for (size_t n = 0; n < pos.size(); n++)
+            if (packed->len[n] > BAMM_MAX_SEQ_POSITIONS) {
+                if (shown++ < 5) std::cerr << "  " << pos.headers[n] << " (" << pos.off[n + 1] - pos.off[n] << " bp)" << std::endl;
+                total++;
+            }
+        die("Error: " + std::to_string(total) + " sequence(s) exceed the MI355X build's limit of " +
+            std::to_string(o.ss ? BAMM_MAX_SEQ_POSITIONS : (BAMM_MAX_SEQ_POSITIONS - 1) / 2) + " bp" +
+            (o.ss ? " (--ss)." : " (both strands; twice that with --ss).") + " Split or remove them.");
+    }
 
     if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
     BgModel bg;
@@ -295,7 +313,7 @@ int main(int nargs, char* args[]) {
     bamm_seqs* dseqs_all = nullptr;                          // every positive record, resident (seeding, then EM)
     SeedDevice seed_dev;
     std::vector<uint32_t> yK;
-    if (need_gpu && o.seed_tag == "PWM" && !getenv("BAMM_HOST_SEEDING")) {
+    if (need_gpu && o.seed_tag == "PWM" && !o.hostSeeding) {
         // Motif::initFromPWM's pass over the sequences runs on the device: upload first
         if (bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
         if (bamm_seqs_upload(ctx, packed, 0, packed->n_seqs, &dseqs_all)) die_abi("upload");

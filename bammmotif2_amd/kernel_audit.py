@@ -1,0 +1,123 @@
+"""Build-time audit of the gfx950 code objects (used by ``build.py``; no GPU needed).
+
+Why: the sequence kernels issue their LDS gathers by hand (``ds_read_b128`` in inline asm, the
+``s_waitcnt lgkmcnt(0)`` a few instructions later, csrc/device_utils.h ``lds_read_b128`` /
+csrc/grouped_kernel.h ``lds_read_b128_off``).  The compiler does not know that the destination
+registers are not valid until that wait: if register pressure makes it spill or copy one of them in
+between, the kernel silently computes garbage -- that is what happened to the grouped kernel at 56 / 64
+positions per lane in round 1.  A compiler bump can do the same to a class that is fine today.
+
+What is checked, on the disassembly of every kernel in the code object:
+
+* ``in-flight`` audit: the LGKM counter is modelled instruction by instruction (DS and scalar-memory
+  operations enter a queue, ``s_waitcnt lgkmcnt(N)`` retires all but the N youngest); any instruction that
+  names a destination register of a ``ds_read`` that has not been retired yet is a violation.
+* resources: scratch instructions per kernel and the compiler's own figures (registers, spills,
+  scratch bytes) from ``-Rpass-analysis=kernel-resource-usage`` go to ``build/resources.json``.
+"""
+from __future__ import annotations
+
+import os
+import re
+import subprocess
+
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+_FUNC = re.compile(r"^[0-9a-f]+ <([^>]+)>:")
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+_LGKM = re.compile(r"lgkmcnt\((\d+)\)")
+
+
+def extract_code_object(obj: str, workdir: str) -> str:
+    """The gfx950 code object bundled into a hipcc host object -> path of the extracted ELF."""
+    os.makedirs(workdir, exist_ok=True)
+    local = os.path.join(workdir, os.path.basename(obj))
+    if os.path.abspath(local) != os.path.abspath(obj):
+        if os.path.lexists(local):
+            os.remove(local)
+        os.symlink(os.path.abspath(obj), local)
+    subprocess.check_call([os.path.join(LLVM_BIN, "llvm-objdump"), "--offloading", local],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = f"{local}.0.{TARGET}"
+    if not os.path.exists(out):
+        raise RuntimeError(f"no {TARGET} bundle in {obj}")
+    return out
+
+
+def disassemble(code_object: str) -> str:
+    return subprocess.check_output([os.path.join(LLVM_BIN, "llvm-objdump"), "-d", code_object], text=True)
+
+
+def _vregs(text: str):
+    regs = set()
+    for m in _VREG.finditer(text):
+        if m.group(1) is not None:
+            regs.add(int(m.group(1)))
+        else:
+            regs.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return regs
+
+
+def audit_disassembly(text: str):
+    """Returns (violations, per-kernel stats).  A violation is (kernel, line number, instruction, registers)."""
+    violations, stats = [], {}
+    kernel = None
+    queue = []          # outstanding LGKM operations, oldest first: sets of destination VGPRs (empty for writes / SMEM)
+    inflight = set()
+    for lineno, raw in enumerate(text.splitlines(), 1):
+        m = _FUNC.match(raw)
+        if m:
+            kernel = m.group(1)
+            stats[kernel] = {"scratch_instructions": 0, "ds_reads": 0, "instructions": 0}
+            queue, inflight = [], set()
+            continue
+        if kernel is None or not raw.startswith("\t"):
+            continue
+        ins = raw.split("//")[0].strip()
+        if not ins:
+            continue
+        op, _, rest = ins.partition(" ")
+        st = stats[kernel]
+        st["instructions"] += 1
+        if op.startswith("scratch_"):
+            st["scratch_instructions"] += 1
+        if op == "s_waitcnt":
+            w = _LGKM.search(rest)
+            if w:
+                keep = int(w.group(1))
+                while len(queue) > keep:
+                    inflight -= queue.pop(0)
+            continue
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            queue, inflight = [], set()          # what follows is reached from elsewhere: state unknown, assume drained
+            continue
+        used = _vregs(rest)
+        if inflight and used & inflight:
+            violations.append((kernel, lineno, ins, sorted(used & inflight)))
+        if op.startswith("ds_"):
+            dest = set()
+            if op.startswith("ds_read") or "_rtn" in op or op.startswith("ds_bpermute") or op.startswith("ds_permute") \
+                    or op.startswith("ds_swizzle") or op.startswith("ds_consume") or op.startswith("ds_append"):
+                first = rest.split(",")[0]
+                dest = _vregs(first)
+                if op.startswith("ds_read"):
+                    st["ds_reads"] += 1
+            queue.append(dest)
+            inflight |= dest
+        elif op.startswith(("s_load_", "s_buffer_load_", "s_store_", "s_buffer_store_", "s_atomic", "s_memtime",
+                            "s_memrealtime", "s_dcache", "s_sendmsg")):
+            queue.append(set())                  # scalar memory returns out of order: the compiler waits for 0 on it
+    return violations, stats
+
+
+def audit_object(obj: str, workdir: str):
+    co = extract_code_object(obj, workdir)
+    try:
+        return audit_disassembly(disassemble(co))
+    finally:
+        for suffix in (f".0.{TARGET}", ".0.host-x86_64-unknown-linux-gnu-"):
+            try:
+                os.remove(os.path.join(workdir, os.path.basename(obj)) + suffix)
+            except OSError:
+                pass

@@ -42,6 +42,7 @@ extern "C" {
 #define BAMM_ERR_COMM       -6   /* the caller's all-reduce callback failed                     */
 
 #define BAMM_MAX_ORDER      10   /* kmer_ spans 11 bases (Sequence.cpp:37)                      */
+#define BAMM_MAX_SEQ_POSITIONS 8192u /* per sequence, reverse strand and separator included     */
 
 typedef struct bamm_ctx  bamm_ctx;   /* one device + one stream                                   */
 typedef struct bamm_seqs bamm_seqs;  /* a sequence set resident in HBM (2-bit packed)             */
@@ -107,6 +108,16 @@ int  bamm_ctx_device_name(bamm_ctx* ctx, char* buf, size_t cap);
 /* launch geometry of the sequence kernels (0 = default); exposed for tuning/benchmarks      */
 int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_block);
 
+/* kernel-selection switches, applied to EM handles created afterwards (benchmarks and the tests that
+ * compare one kernel with another; results agree within the parity bar whatever is chosen):
+ *   "grouped"      1/0  grouped-column kernel for K <= 2 (default 1; 0 = one column at a time)
+ *   "group_size"   0 = planner's choice, 2..4 = columns per table row
+ *   "group_layout" -1 = planner's choice, 0..3 = table layout (csrc/grouped.hip: grp_geometry)
+ *   "sparse"       1/0  compacted lists of the non-zero windows in the M-step (default 1)
+ *   "e_fused"      1/0  sliced path: whole-table E pass when the odds table fits LDS (default 1)
+ * There are no environment variables that change what the library computes or launches.          */
+int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
+
 /* ------------------------------------------------------------------ sequences ----------- */
 /* Uploads sequences [begin,end) of `p`; they stay resident and are shared (ref-counted) by
  * any number of EM handles -- CV folds pass a mask instead of copying (FDR.cpp:49-57).
@@ -124,7 +135,10 @@ typedef struct bamm_em_params {
     uint32_t W;              /* motif width             (Motif::getW)                        */
     uint32_t bg_order;       /* BackgroundModel::getOrder(); EM uses min(bg_order,K) EM.cpp:23 */
     float    q;              /* Motif::getQ()           (EM.cpp:12)                          */
-    int32_t  optimize_q;     /* EM ctor arg; q re-estimated while iteration <= 5 (EM.cpp:99) */
+    int32_t  optimize_q;     /* EM ctor arg; q re-estimated in the first 5 passes of every
+                              * optimize() / iterate() call (`iteration` is local to
+                              * EM::optimize, EM.cpp:75-99); hand-driven accumulate/update
+                              * passes: the handle's first 5                                  */
     float    epsilon;        /* EM.h:62  (0.01)                                              */
     uint32_t max_iterations; /* EM.h:63  (1000)                                              */
     uint64_t n_seqs_global;  /* N used by optimize_q (EM.cpp:515); 0 = this handle's own N   */
@@ -143,7 +157,9 @@ int  bamm_em_destroy(bamm_em* em);
 int  bamm_em_estep(bamm_em* em);
 /* EM::MStep (EM.cpp:217-259): counts from the responsibilities of the last EStep, updateV.   */
 int  bamm_em_mstep(bamm_em* em);
-/* EM::optimize_q (EM.cpp:505-519) from the responsibilities of the last EStep.               */
+/* EM::optimize_q (EM.cpp:505-519) from the responsibilities of the last EStep.  May be called
+ * before or after the MStep (the reference calls it after, EM.cpp:93-99): getR() and MStep() keep
+ * seeing the q that EStep used.                                                                */
 int  bamm_em_optimize_q(bamm_em* em);
 /* n fused EStep+MStep(+optimize_q while iteration<=5) passes, no convergence test, no host
  * round trip in between (benchmark / fixed-budget mode).                          */

@@ -97,3 +97,26 @@ def test_window_pvalues_and_occurrence_file(host, g, tmp_path):
                               C.c_uint64(120), 0, int(g["W"]), p.ctypes.data_as(C.c_void_p), e.ctypes.data_as(C.c_void_p),
                               C.c_float(0.02)) == 0
     assert open(tmp_path / "x.occurrence", "rb").read() == g["occ_file"].tobytes()
+
+
+def test_fdr_statistics_with_uneven_fold_split(host, tmp_path):
+    """posN % cvFold != 0 and negN % cvFold != 0: the strided split (FDR.cpp:49-60) yields fewer scores
+    than posN / negN.  The reference then reads past the end of its vectors (FDR.cpp:227-239); the
+    restatement walks the scores that exist: one finite row per score, monotone TP / FP."""
+    rng = np.random.default_rng(5)
+    posN, negN, cv = 103, 517, 5
+    pos = (rng.normal(2.0, 2.0, posN - posN % cv)).astype(np.float32)          # 100 test scores
+    neg = (rng.normal(0.0, 1.0, cv * (negN // cv))).astype(np.float32)        # 515 negative scores
+    rc = host.bh_fdr_stats(fp(pos), C.c_uint64(len(pos)), fp(neg), C.c_uint64(len(neg)), fp(pos), C.c_uint64(0),
+                           fp(neg), C.c_uint64(0), C.c_uint64(posN), C.c_uint64(negN), C.c_float(0.3), 0, 1, 1,
+                           str(tmp_path).encode(), b"u")
+    assert rc == 0, host.bh_last_error()
+    lines = open(tmp_path / "u.zoops.stats").read().strip().split("\n")
+    rows = np.array([[float(x) for x in l.split("\t") if x] for l in lines[1:]])
+    assert rows.shape == (len(pos) + len(neg), 5)
+    assert np.all(np.isfinite(rows))
+    assert np.all(np.diff(rows[:, 0]) >= 0) and np.all(np.diff(rows[:, 1]) >= 0)
+    assert rows[-1, 0] == len(pos) and rows[-1, 1] == pytest.approx(len(neg) / (negN / posN), rel=1e-5)
+    assert np.all((rows[:, 4] >= 0) & (rows[:, 4] <= 1.0 + 1e-6))
+    pv = np.array([float(x) for x in open(tmp_path / "u.zoops.pvalues").read().split()])
+    assert len(pv) == len(pos) and np.all((pv > 0) & (pv <= 1))

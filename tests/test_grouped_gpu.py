@@ -111,17 +111,17 @@ def test_grouped_kernel_matches_exact_arithmetic(spec, gpu_ctx, orc):
 
 
 @pytest.mark.parametrize("spec", GROUPED_CASES[:5], ids=[d["name"] for d in GROUPED_CASES[:5]])
-def test_grouped_equals_per_column_kernel(spec, gpu_ctx, orc, monkeypatch):
+def test_grouped_equals_per_column_kernel(spec, gpu_ctx, orc):
     """Same handle twice, once with the grouped kernel switched off: counts are sums of the same
     fixed-point addends up to the rounding of r, llh and q chain identically."""
     c = Case(**spec)
     res = []
     for off_switch in (False, True):
-        if off_switch:
-            monkeypatch.setenv("BAMM_NO_GROUPED", "1")
-        else:
-            monkeypatch.delenv("BAMM_NO_GROUPED", raising=False)
-        em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+        gpu_ctx.set_tuning(grouped=not off_switch)
+        try:
+            em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+        finally:
+            gpu_ctx.set_tuning(grouped=1)
         g, o, _ = em.plan()
         assert (g == 0) == off_switch
         em.iterate(4)
@@ -135,19 +135,21 @@ def test_grouped_equals_per_column_kernel(spec, gpu_ctx, orc, monkeypatch):
     np.testing.assert_allclose(a[4], b[4], rtol=5e-6, atol=1e-12)
 
 
-def test_group_sizes_agree(gpu_ctx, orc, monkeypatch):
+def test_group_sizes_agree(gpu_ctx, orc):
     """K = 2 runs with 3 columns per row when the tables fit and with 2 otherwise: the two only differ
     in how the window products are rounded."""
     c = Case(name="g_sizes", N=300, L0=200, W=20, K=2)
     out = []
-    for G in ("3", "2"):
-        monkeypatch.setenv("BAMM_GRP_G", G)
-        em, ss, *_ = make_em(gpu_ctx, c, orc)
+    for G in (3, 2):
+        gpu_ctx.set_tuning(group_size=G)
+        try:
+            em, ss, *_ = make_em(gpu_ctx, c, orc)
+        finally:
+            gpu_ctx.set_tuning(group_size=0)
         assert em.plan()[0] == c.N
         em.iterate(6)
         out.append((em.getCounts(), em.getV(), em.trace()[0]))
         em.close(); ss.close()
-    monkeypatch.delenv("BAMM_GRP_G")
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=2e-6, atol=1e-6)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=2e-6, atol=1e-10)
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-6)
@@ -209,12 +211,15 @@ def test_handles_created_from_several_host_threads(gpu_ctx, orc):
 @pytest.mark.parametrize("layout", [0, 2, 3])
 @pytest.mark.parametrize("spec", [GROUPED_CASES[1], GROUPED_CASES[9], GROUPED_CASES[4]],
                          ids=["k2_ds_N", "k1_ss", "k0_ds_w2"])
-def test_every_table_layout_matches_exact_arithmetic(spec, layout, gpu_ctx, orc, monkeypatch):
+def test_every_table_layout_matches_exact_arithmetic(spec, layout, gpu_ctx, orc):
     """The table layouts the planner chooses between (grp_geometry: partial rows or per-wave virtual rows
     for the groups cut by the LW1 edge, even or odd number of quads per row) compute the same thing."""
-    monkeypatch.setenv("BAMM_GRP_LAYOUT", str(layout))
     c = Case(**spec)
-    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    gpu_ctx.set_tuning(group_layout=layout)
+    try:
+        em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    finally:
+        gpu_ctx.set_tuning(group_layout=-1)
     assert em.plan()[0] > 0
     v64, *_ = orc.em_step_f64(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
     em.iterate(1)

@@ -98,6 +98,51 @@ def test_getR_after_iterate_is_the_last_estep(gpu_ctx, orc):
     em.close(); ss.close()
 
 
+def test_getR_after_mstep_then_optimize_q(gpu_ctx, orc):
+    """The reference's own call order (EM.cpp:93-99): EStep(); MStep(); optimize_q().  getR() afterwards is
+    still the r of that EStep, computed with the q it saw; the new q only enters the next EStep."""
+    c = Case(**SMALL_CASES[0])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+    Kb = min(c.bg_order, c.K)
+    v0, q0 = em.getV(), em.getQ()
+    em.EStep()
+    em.MStep()
+    v1 = em.getV()
+    em.optimize_q()
+    s0 = orc.linear_s(v0, vbg, c.K, c.W, Kb)
+    r0, _ = orc.estep(kmer, off, c.K, c.W, s0, q0)
+    q1 = orc.optimize_q(r0, off, c.W)
+    assert q1 != np.float32(q0)
+    np.testing.assert_allclose(em.getQ(), q1, rtol=1e-5)
+    np.testing.assert_allclose(em.getR(), r0, rtol=R_RTOL, atol=R_ATOL)          # old s, OLD q
+    # ... and the other order, EStep(); optimize_q(); MStep(); getR()
+    em.EStep()
+    s1 = orc.linear_s(v1, vbg, c.K, c.W, Kb)
+    r1, _ = orc.estep(kmer, off, c.K, c.W, s1, q1)
+    em.optimize_q()
+    em.MStep()
+    np.testing.assert_allclose(em.getR(), r1, rtol=R_RTOL, atol=R_ATOL)
+    np.testing.assert_allclose(em.getQ(), orc.optimize_q(r1, off, c.W), rtol=1e-5)
+    em.close(); ss.close()
+
+
+def test_second_optimize_call_reestimates_q(gpu_ctx, orc):
+    """`iteration` is local to EM::optimize (EM.cpp:75-99): every call re-estimates q in its first five
+    passes, whatever the handle ran before."""
+    c = Case(**SMALL_CASES[0])
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True, epsilon=0.0, max_iterations=3)
+    res1 = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=True, epsilon=0.0, max_iter=3)
+    res2 = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, res1["v"], res1["q"], optimizeQ=True, epsilon=0.0,
+                        max_iter=3)
+    assert em.optimize() == 3
+    np.testing.assert_allclose(em.getQ(), res1["q"], rtol=1e-5)
+    assert em.optimize() == 3
+    assert res2["q"] != res1["q"]
+    np.testing.assert_allclose(em.getQ(), res2["q"], rtol=2e-5)
+    np.testing.assert_allclose(em.getV(), res2["v"], rtol=5e-5, atol=1e-8)
+    em.close(); ss.close()
+
+
 SLICED_CASES = [
     dict(name="k4", N=60, L0=300, W=30, K=4, ss=True, ragged=40, n_frac=0.01),
     dict(name="k4_M96_128", N=5, L0=6600, W=30, K=4, ss=True, ragged=1500, n_frac=0.0005),   # longest length classes

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE config 5 through the drop-in CLI: 200k x 200 bp, -k 2, --FDR -n 5 -m 10 (5-fold CV,
 10x sampled negatives).  Writes a FASTA + MEME seed, runs BaMMmotif, prints wall times (per stage
-with BAMM_TIMING=1).  `config5_run.py N OUT em` runs the plain --EM line instead (config 3 at N=1M)."""
+with --timing).  `config5_run.py N OUT em` runs the plain --EM line instead (config 3 at N=1M)."""
 import os, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,8 +29,7 @@ t = time.time()
 em_only = len(sys.argv) > 3 and sys.argv[3] == "em"
 extra = [] if em_only else ["--FDR", "-n", "5", "-m", "10"]
 r = subprocess.run([build.CLI, os.path.join(out, "res"), os.path.join(out, "pos.fasta"), "--PWMFile", os.path.join(out, "seed.meme"),
-                    "--EM", "-k", "2", "--maxEMIterations", "60"] + extra, capture_output=True, text=True,
-                   env=dict(os.environ, BAMM_TIMING="1"))
+                    "--EM", "-k", "2", "--maxEMIterations", "60", "--timing"] + extra, capture_output=True, text=True)
 dt = time.time() - t
 print("BaMMmotif exit", r.returncode, "wall %.1f s" % dt)
 print("\n".join(l for l in r.stdout.splitlines() if "Runtime" in l))
