@@ -35,7 +35,7 @@ class Packed(C.Structure):
 class EmParams(C.Structure):
     _fields_ = [("K", C.c_uint32), ("W", C.c_uint32), ("bg_order", C.c_uint32), ("q", C.c_float),
                 ("optimize_q", C.c_int32), ("epsilon", C.c_float), ("max_iterations", C.c_uint32),
-                ("n_seqs_global", C.c_uint64)]
+                ("n_seqs_global", C.c_uint64), ("n_seqs_bound", C.c_uint64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
@@ -48,7 +48,8 @@ SYMBOLS = [
     "bamm_seqs_destroy", "bamm_seqs_info", "bamm_em_default_params", "bamm_em_create",
     "bamm_em_destroy", "bamm_em_estep", "bamm_em_mstep", "bamm_em_optimize_q", "bamm_em_iterate",
     "bamm_em_optimize", "bamm_em_mask", "bamm_em_accumulate", "bamm_em_reduce_buffer", "bamm_em_update", "bamm_em_set_reduce_buffer",
-    "bamm_em_set_allreduce", "bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s", "bamm_em_get_q",
+    "bamm_em_set_allreduce", "bamm_em_set_comm", "bamm_comm_init_all", "bamm_comm_unique_id", "bamm_comm_init_rank",
+    "bamm_comm_info", "bamm_comm_destroy", "bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s", "bamm_em_get_q",
     "bamm_em_get_llh", "bamm_em_get_vdiff", "bamm_em_get_iteration", "bamm_em_get_r",
     "bamm_em_get_trace", "bamm_em_kernel_time", "bamm_em_set_kernel_timing", "bamm_em_plan", "bamm_seed_from_pwm", "bamm_set_host_threads", "bamm_logodds", "bamm_logodds_subset", "bamm_bg_model", "bamm_calculate_p", "bamm_v_size",
     "bamm_v_offset", "bamm_bg_size",
@@ -102,6 +103,12 @@ def load() -> C.CDLL:
     L.bamm_em_reduce_buffer.argtypes = [vp, P(vp), P(u64)]
     L.bamm_em_set_reduce_buffer.argtypes = [vp, vp, u64]
     L.bamm_em_set_allreduce.argtypes = [vp, ALLREDUCE_FN, vp]
+    L.bamm_em_set_comm.argtypes = [vp, vp]
+    L.bamm_comm_init_all.argtypes = [P(vp), u32, P(vp)]
+    L.bamm_comm_unique_id.argtypes = [vp, C.c_size_t]
+    L.bamm_comm_init_rank.argtypes = [vp, vp, u32, u32, P(vp)]
+    L.bamm_comm_info.argtypes = [vp, P(u32), P(u32), P(i)]
+    L.bamm_comm_destroy.argtypes = [vp]
     for name in ("bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s"):
         getattr(L, name).argtypes = [vp, f32p]
     for name in ("bamm_em_get_q", "bamm_em_get_llh", "bamm_em_get_vdiff"):

@@ -15,7 +15,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbamm_em.so")
-SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "mask.hip", "seed.hip", "abi.cpp", "pack.cpp"]
+SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "mask.hip", "seed.hip", "abi.cpp", "comm.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(CSRC, "grouped_kernel.h"),
            os.path.join(HERE, "..", "include", "bamm_em.h")]
 # -Rpass-analysis=kernel-resource-usage: registers / scratch / spills of every kernel go to the compiler's
@@ -160,7 +160,7 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
             raise subprocess.CalledProcessError(rc, cmd)
         os.replace(_remarks(s) + ".tmp", _remarks(s))
     check_resources([s for s in SOURCES if s.endswith(".hip")])
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-ldl", "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -130,10 +130,12 @@ struct bamm_em {
     const float *s_last = nullptr, *q_last = nullptr;
     uint32_t* d_iteration = nullptr;
     uint8_t* d_mask = nullptr;
-    double* d_red = nullptr;
-    bool red_external = false;                 // caller-owned reduce buffer (bamm_em_set_reduce_buffer)
-    unsigned long long* d_partial_n = nullptr;
-    double* d_partial_stat = nullptr;
+    // the pass's fused accumulator [cells | llh | sum_r | n_seqs]: 64-bit integers the blocks add into,
+    // summed across ranks as int64 (exact, order-free), consumed and zeroed by the update
+    long long* d_acc = nullptr;
+    bool acc_external = false;                 // caller-owned (bamm_em_set_reduce_buffer)
+    bool acc_dirty = false;                    // holds sums nobody consumed (accumulate without update, getR replay)
+    uint32_t fix_shift = 40;                   // counts travel in units of 2^-fix_shift (40 unless the set is huge)
     float* h_status = nullptr;                  // pinned, 8 floats
     uint32_t total_blocks = 0;
     std::vector<EmBucket> ebuckets;             // launches of one pass (length class x kernel flavour)
@@ -152,6 +154,7 @@ struct bamm_em {
     uint32_t host_iteration = 0;
     bamm_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    bamm_comm* comm = nullptr;                  // native RCCL all-reduce (bamm_em_set_comm)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     uint32_t events_used = 0;
     uint32_t timing_every = 8, pass_no = 0;     // bamm_em_set_kernel_timing
@@ -160,7 +163,7 @@ struct bamm_em {
     uint64_t n_active = 0;                      // sequences the handle trains on (mask applied)
     float* d_mask_r = nullptr;                  // responsibilities in the reference layout
     uint32_t* d_mask_bits = nullptr;
-    double* d_mask_hist = nullptr;
+    long long* d_mask_hist = nullptr;
     MaskSelect* d_mask_sel = nullptr;
     float* d_mask_qseq = nullptr;
     unsigned long long* d_mask_partial_n = nullptr;
@@ -351,8 +354,11 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
     hipStream_t st = em->ctx->stream;
     int rc = use_device(em->ctx);
     if (rc) return rc;
+    if (em->acc_dirty) {                                      // sums of a pass that was never consumed
+        BAMM_HIP(hipMemsetAsync(em->d_acc, 0, (em->cells + 3) * sizeof(long long), st));
+        em->acc_dirty = false;
+    }
     if ((rc = record_event(em, true))) return rc;
-    uint32_t block_base = 0;
     for (size_t b = 0; b < em->ebuckets.size(); b++) {
         const EmBucket& bk = em->ebuckets[b];
         EmKernelArgs a{};
@@ -361,8 +367,8 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
         a.logC = bk.logc;
         a.s = replay_last ? em->s_last : em->d_s;
         a.q = replay_last ? em->q_last : em->d_q;
-        a.partial_n = em->d_partial_n + (size_t)block_base * em->cells;
-        a.partial_stat = em->d_partial_stat + (size_t)block_base * 4;
+        a.acc = em->d_acc;
+        a.fix_scale = ldexpf(1.0f, (int)em->fix_shift - 40);
         a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
         const uint32_t threads = bucket_threads(em->ctx, bk);
         if (!em->sliced) {
@@ -396,22 +402,28 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
                                     bk.blocks, mthreads, st);
         }
         if (rc) return rc;
-        block_base += bk.blocks;
     }
     rc = record_event(em, false);
     if (rc) return rc;
     if (!replay_last) { em->s_last = em->d_s; em->q_last = em->d_q; em->mask_done = false; }
-    if (em->total_blocks == 0) {
-        BAMM_HIP(hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), st));
-        return BAMM_OK;
+    em->acc_dirty = true;                                     // until the update (or the E-only read-out) has consumed it
+    return BAMM_OK;
+}
+
+// int64 sum of `n_words` words across the ranks, on the context's stream: RCCL or the caller's callback
+int allreduce_words(bamm_em* em, void* dev_ptr, size_t n_words) {
+    if (em->comm) return comm_allreduce_i64(em->comm, dev_ptr, n_words, em->ctx->stream);
+    if (em->allreduce && em->allreduce(em->allreduce_user, dev_ptr, n_words, (void*)em->ctx->stream) != 0) {
+        set_error("all-reduce callback failed");
+        return BAMM_ERR_COMM;
     }
-    return launch_reduce_partials(accum ? em->d_partial_n : nullptr, em->d_partial_stat, em->total_blocks,
-                                  em->prm.W, em->Y, em->d_red, st);
+    return BAMM_OK;
 }
 
 int run_allreduce(bamm_em* em) {
+    if (em->comm) return comm_allreduce_i64(em->comm, em->d_acc, em->cells + 3, em->ctx->stream);
     if (!em->allreduce) return BAMM_OK;
-    int rc = em->allreduce(em->allreduce_user, em->d_red, em->cells + 3, (void*)em->ctx->stream);
+    int rc = em->allreduce(em->allreduce_user, em->d_acc, em->cells + 3, (void*)em->ctx->stream);
     if (rc != 0) {
         set_error("all-reduce callback failed with %d", rc);
         return BAMM_ERR_COMM;
@@ -434,7 +446,7 @@ float* q_write_slot(bamm_em* em) {
 int run_update(bamm_em* em, bool q_window) {
     UpdateArgs u{};
     u.K = em->prm.K; u.W = em->prm.W; u.Kbg = em->Kbg;
-    u.red = em->d_red; u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s_alt;
+    u.acc = em->d_acc; u.count_unit = ldexp(1.0, -(int)em->fix_shift); u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s_alt;
     float* q_out = q_write_slot(em);
     u.q = em->d_q; u.q_out = q_out; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
     u.iteration = em->d_iteration; u.optimize_q = (em->prm.optimize_q && q_window) ? 1 : 0;
@@ -442,6 +454,7 @@ int run_update(bamm_em* em, bool q_window) {
     int rc = use_device(em->ctx);
     if (!rc) rc = launch_update(u, em->ctx->stream);
     if (rc) return rc;
+    em->acc_dirty = false;                                    // k_update left the accumulator zeroed
     std::swap(em->d_s, em->d_s_alt);
     em->d_q = q_out;
     em->host_iteration++;
@@ -457,6 +470,11 @@ int fetch_status(bamm_em* em) {
 }
 
 }  // namespace
+
+namespace bamm {
+int ctx_device(const bamm_ctx* c) { return c->device; }
+hipStream_t ctx_stream(const bamm_ctx* c) { return c->stream; }
+}  // namespace bamm
 
 extern "C" {
 
@@ -643,8 +661,8 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipSetDevice(em->ctx->device);
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
-                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->red_external ? nullptr : em->d_red),
-                    (void*)em->d_partial_n, (void*)em->d_partial_stat, (void*)em->d_state, (void*)em->d_s_alt,
+                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->acc_external ? nullptr : em->d_acc),
+                    (void*)em->d_state, (void*)em->d_s_alt,
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
                     (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})
@@ -735,11 +753,18 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if ((rc = dev_alloc(&em->d_status, 8))) return fail(rc);
     if ((rc = dev_alloc(&em->d_trace, (size_t)em->prm.max_iterations * 3))) return fail(rc);
     if ((rc = dev_alloc(&em->d_iteration, 1))) return fail(rc);
-    if ((rc = dev_alloc(&em->d_red, em->cells + 3))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_acc, em->cells + 3))) return fail(rc);
+    {   // counts are sums of r * 2^fix_shift over at most n_seqs_global (else this handle's) sequences, each
+        // contributing less than 1 per cell: keep the int64 total below 2^62
+        const uint64_t n_hint = std::max<uint64_t>(prm->n_seqs_bound ? prm->n_seqs_bound : (prm->n_seqs_global ? prm->n_seqs_global : seqs->n), 1);
+        uint32_t bits = 0;
+        while ((uint64_t(1) << bits) < n_hint && bits < 63u) bits++;
+        em->fix_shift = std::min(40u, 62u - std::min(bits, 38u));
+    }
     if (hipMemsetAsync(em->d_n, 0, em->vsz * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(em->d_status, 0, 8 * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(em->d_iteration, 0, sizeof(uint32_t), st) != hipSuccess ||
-        hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), st) != hipSuccess) {
+        hipMemsetAsync(em->d_acc, 0, (em->cells + 3) * sizeof(long long), st) != hipSuccess) {
         set_error("hipMemsetAsync failed");
         return fail(BAMM_ERR_HIP);
     }
@@ -844,8 +869,6 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         b.blocks = nb;
         em->total_blocks += nb;
     }
-    if ((rc = dev_alloc(&em->d_partial_n, (size_t)em->total_blocks * em->cells))) return fail(rc);
-    if ((rc = dev_alloc(&em->d_partial_stat, (size_t)em->total_blocks * 4))) return fail(rc);
     if (sliced && (rc = dev_alloc(&em->d_state, (size_t)seqs->total_len))) return fail(rc);
     if ((rc = launch_make_s(em->d_v, em->d_vbg, prm->K, prm->W, em->Kbg, em->d_s, st))) return fail(rc);
     em->s_last = em->d_s;
@@ -857,8 +880,25 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
 
 int bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (fn && !em->prm.n_seqs_bound && !em->prm.n_seqs_global && em->seqs->n > (uint64_t(1) << 21)) {
+        set_error("a shard of %llu sequences needs bamm_em_params.n_seqs_bound (the unit of the integer accumulator "
+                  "must be the same on every rank)", (unsigned long long)em->seqs->n);
+        return BAMM_ERR_ARG;
+    }
     em->allreduce = fn;
     em->allreduce_user = user;
+    return BAMM_OK;
+}
+
+int bamm_em_set_comm(bamm_em* em, bamm_comm* comm) {
+    if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (comm && comm_ctx(comm) != em->ctx) { set_error("the communicator belongs to another context"); return BAMM_ERR_ARG; }
+    if (comm && !em->prm.n_seqs_bound && !em->prm.n_seqs_global && em->seqs->n > (uint64_t(1) << 21)) {
+        set_error("a shard of %llu sequences needs bamm_em_params.n_seqs_bound (the unit of the integer accumulator "
+                  "must be the same on every rank)", (unsigned long long)em->seqs->n);
+        return BAMM_ERR_ARG;
+    }
+    em->comm = comm;
     return BAMM_OK;
 }
 
@@ -868,7 +908,8 @@ int bamm_em_estep(bamm_em* em) {
     int rc = run_accumulate(em, false);
     if (rc) return rc;
     if ((rc = run_allreduce(em))) return rc;
-    if ((rc = launch_stat_only(em->d_red, (uint32_t)em->cells, em->d_status, em->ctx->stream))) return rc;
+    if ((rc = launch_stat_only(em->d_acc, (uint32_t)em->cells, em->d_status, em->ctx->stream))) return rc;
+    em->acc_dirty = false;
     em->estep_done = true;
     return BAMM_OK;
 }
@@ -908,25 +949,26 @@ int bamm_em_accumulate(bamm_em* em) {
     return run_accumulate(em, true);
 }
 
-int bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_doubles) {
-    if (!em || !dev_ptr || !n_doubles) { set_error("bad argument"); return BAMM_ERR_ARG; }
-    *dev_ptr = em->d_red;
-    *n_doubles = em->cells + 3;
+int bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_words) {
+    if (!em || !dev_ptr || !n_words) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    *dev_ptr = em->d_acc;
+    *n_words = em->cells + 3;
     return BAMM_OK;
 }
 
-int bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_doubles) {
+int bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_words) {
     if (!em || !dev_ptr) { set_error("bad argument"); return BAMM_ERR_ARG; }
-    if (n_doubles < em->cells + 3) {
-        set_error("reduce buffer holds %llu doubles, %llu needed", (unsigned long long)n_doubles, (unsigned long long)(em->cells + 3));
+    if (n_words < em->cells + 3) {
+        set_error("reduce buffer holds %llu 64-bit words, %llu needed", (unsigned long long)n_words, (unsigned long long)(em->cells + 3));
         return BAMM_ERR_ARG;
     }
     BAMM_HIP(hipSetDevice(em->ctx->device));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
-    if (!em->red_external) (void)hipFree(em->d_red);
-    em->d_red = static_cast<double*>(dev_ptr);
-    em->red_external = true;
-    BAMM_HIP(hipMemsetAsync(em->d_red, 0, (em->cells + 3) * sizeof(double), em->ctx->stream));
+    if (!em->acc_external) (void)hipFree(em->d_acc);
+    em->d_acc = static_cast<long long*>(dev_ptr);
+    em->acc_external = true;
+    em->acc_dirty = false;
+    BAMM_HIP(hipMemsetAsync(em->d_acc, 0, (em->cells + 3) * sizeof(long long), em->ctx->stream));
     return BAMM_OK;
 }
 
@@ -978,7 +1020,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     if (!(f > 0.0f && f < 1.0f)) { set_error("bamm_em_mask: fraction %g outside (0,1)", (double)f); return BAMM_ERR_ARG; }
     if (em->n_active == 0) { set_error("bamm_em_mask: no sequences (the reference indexes an empty array, EM.cpp:343)"); return BAMM_ERR_ARG; }
     if (em->prm.W < 2) { set_error("bamm_em_mask: W=1 reads past pos_[n] in the reference (EM.cpp:416)"); return BAMM_ERR_UNSUPPORTED; }
-    if (em->prm.optimize_q && em->allreduce) {
+    if (em->prm.optimize_q && (em->allreduce || em->comm)) {
         set_error("bamm_em_mask: optimize_q re-estimates q after every sequence (EM.cpp:321), a serial chain that cannot be sharded");
         return BAMM_ERR_UNSUPPORTED;
     }
@@ -1024,7 +1066,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     }
     BAMM_HIP(hipMemsetAsync(em->d_mask_r, 0, (size_t)s->total_len * sizeof(float), st));
     BAMM_HIP(hipMemsetAsync(em->d_mask_bits, 0, ((size_t)s->total_len / 32 + 2) * sizeof(uint32_t), st));
-    BAMM_HIP(hipMemsetAsync(em->d_mask_hist, 0, 2049 * sizeof(double), st));
+    BAMM_HIP(hipMemsetAsync(em->d_mask_hist, 0, 2049 * sizeof(long long), st));
     BAMM_HIP(hipMemsetAsync(em->d_mask_sel, 0, sizeof(MaskSelect), st));
 
     Bucket all;                                              // every sequence in natural order
@@ -1038,6 +1080,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     a.q = em->d_q;
     a.q_seq = em->prm.optimize_q ? em->d_mask_qseq : nullptr;
     a.n_total = (float)em->n_active;
+    a.fix_scale = ldexpf(1.0f, (int)em->fix_shift - 40);
     a.r = em->d_mask_r; a.bits = em->d_mask_bits; a.hist = em->d_mask_hist; a.sel = em->d_mask_sel;
     a.partial_n = em->d_mask_partial_n; a.partial_stat = em->d_mask_partial_stat;
 
@@ -1054,10 +1097,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     // cut-off (EM.cpp:329-343)
     for (int pass = 0; pass < 3; pass++) {
         if ((rc = launch_mask_hist(a, pass, blocks_for(4, cus * 8), st))) return rc;
-        if (em->allreduce && em->allreduce(em->allreduce_user, em->d_mask_hist, 2049, (void*)st) != 0) {
-            set_error("all-reduce callback failed in bamm_em_mask");
-            return BAMM_ERR_COMM;
-        }
+        if ((rc = allreduce_words(em, em->d_mask_hist, 2049))) return rc;
         if ((rc = launch_mask_pick(a, pass, f, st))) return rc;
     }
     if ((rc = launch_mask_bits(a, blocks_for(4, cus * 8), st))) return rc;     // EM.cpp:345-356
@@ -1083,7 +1123,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
             rc = launch_mask_m(a, mblocks, m_waves * 64, st);
         }
         if (!rc) rc = record_event(em, false);
-        if (!rc) rc = launch_reduce_partials(em->d_mask_partial_n, em->d_mask_partial_stat, mblocks, W, Y, em->d_red, st);
+        if (!rc) rc = launch_reduce_partials(em->d_mask_partial_n, em->d_mask_partial_stat, mblocks, W, Y, em->d_acc, st);
         if (!rc) rc = run_allreduce(em);
         if (!rc) rc = run_update(em, false);
         if (!rc) rc = fetch_status(em);
@@ -1186,18 +1226,14 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
     float* d_r = nullptr;
     int rc = dev_alloc(&d_r, total);
     if (rc) return rc;
-    double* d_stat = nullptr;
     BAMM_HIP(hipMemsetAsync(d_r, 0, total * sizeof(float), st));
-    uint32_t maxb = 0;
-    for (auto& eb : em->ebuckets) maxb = std::max(maxb, eb.blocks);
-    if ((rc = dev_alloc(&d_stat, (size_t)maxb * 4))) { (void)hipFree(d_r); return rc; }
     for (size_t b = 0; b < em->ebuckets.size() && !rc; b++) {
         const EmBucket& bk = em->ebuckets[b];
         EmKernelArgs a{};
         a.sv = make_view(s, em->exc, bk, nullptr);        // masked-out sequences still have an r in the reference
         a.K = em->prm.K; a.W = em->prm.W; a.Y = em->Y;
         a.s = em->s_last; a.q = em->q_last;                 // the E pass the caller last ran (EM.cpp:521)
-        a.partial_n = nullptr; a.partial_stat = d_stat;
+        a.acc = nullptr;                                    // responsibilities only
         a.r_out = d_r; a.r_base = base; a.seq_begin = (uint32_t)begin; a.seq_end = (uint32_t)end;
         rc = launch_fused(em, bk, false, true, a, bucket_threads(em->ctx, bk), st);
     }
@@ -1207,7 +1243,6 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         if (e != hipSuccess) { set_error("copy of r failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
     }
     (void)hipFree(d_r);
-    (void)hipFree(d_stat);
     return rc;
 }
 

@@ -1,0 +1,176 @@
+// RCCL inside the drop-in: the one collective of the EM path -- an int64 sum of the fused accumulator
+// [n_K | llh | sum_r | n_seqs] per pass -- issued on the context's HIP stream.
+//
+// Reference: the cross-sequence reductions this stands for are the OpenMP `reduction(+:llikelihood)`
+// (/root/reference/src/refinement/EM.cpp:148), the CAS float adds into n_[K] (EM.cpp:203-215,240) and
+// the serial sum over r_ of optimize_q (EM.cpp:509-513); sequences shard over the GPUs.
+//
+// librccl is opened at the first bamm_comm_* call (dlopen + dlsym), not linked: a process that never
+// shards loads nothing, and a process that already carries an RCCL (torch ships its own) keeps using that
+// copy -- the loader hands back the library that is already mapped under the same SONAME.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <mutex>
+
+#include "common.h"
+
+using namespace bamm;
+
+struct bamm_comm {
+    ncclComm_t comm = nullptr;
+    bamm_ctx* ctx = nullptr;
+    uint32_t rank = 0, world = 1;
+};
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+};
+
+Rccl g_rccl;
+std::once_flag g_once;
+std::string g_load_error;
+
+void load_rccl() {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) {
+        const char* e = dlerror();
+        g_load_error = std::string("librccl could not be opened: ") + (e ? e : "not found");
+        return;
+    }
+    Rccl r;
+    r.handle = h;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(h, name); if (!p) { ok = false; g_load_error = std::string("librccl lacks ") + name; } return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
+    if (ok) g_rccl = r;
+}
+
+const Rccl* rccl() {
+    std::call_once(g_once, load_rccl);
+    if (!g_rccl.handle) {
+        set_error("%s", g_load_error.c_str());
+        return nullptr;
+    }
+    return &g_rccl;
+}
+
+int fail(const Rccl* r, const char* what, ncclResult_t rc) {
+    set_error("%s failed: %s", what, r->GetErrorString(rc));
+    return BAMM_ERR_COMM;
+}
+
+}  // namespace
+
+namespace bamm {
+
+int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st) {
+    const Rccl* r = rccl();
+    if (!r) return BAMM_ERR_COMM;
+    const ncclResult_t rc = r->AllReduce(dev_ptr, dev_ptr, n_words, ncclInt64, ncclSum, c->comm, st);
+    return rc == ncclSuccess ? BAMM_OK : fail(r, "ncclAllReduce", rc);
+}
+
+bamm_ctx* comm_ctx(const bamm_comm* c) { return c->ctx; }
+
+}  // namespace bamm
+
+extern "C" {
+
+int bamm_comm_init_all(bamm_ctx* const* ctxs, uint32_t n, bamm_comm** out) {
+    if (!ctxs || !out || n == 0) { set_error("bamm_comm_init_all: bad argument"); return BAMM_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) out[i] = nullptr;
+    const Rccl* r = rccl();
+    if (!r) return BAMM_ERR_COMM;
+    std::vector<int> devs(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!ctxs[i]) { set_error("bamm_comm_init_all: null context %u", i); return BAMM_ERR_ARG; }
+        devs[i] = ctx_device(ctxs[i]);
+        for (uint32_t j = 0; j < i; j++)
+            if (devs[j] == devs[i]) {
+                set_error("bamm_comm_init_all: device %d appears twice (one rank per GPU)", devs[i]);
+                return BAMM_ERR_ARG;
+            }
+    }
+    std::vector<ncclComm_t> comms(n, nullptr);
+    const ncclResult_t rc = r->CommInitAll(comms.data(), (int)n, devs.data());
+    if (rc != ncclSuccess) return fail(r, "ncclCommInitAll", rc);
+    for (uint32_t i = 0; i < n; i++) {
+        bamm_comm* c = new bamm_comm();
+        c->comm = comms[i]; c->ctx = ctxs[i]; c->rank = i; c->world = n;
+        out[i] = c;
+    }
+    return BAMM_OK;
+}
+
+int bamm_comm_unique_id(void* id_out, size_t cap) {
+    if (!id_out || cap < BAMM_COMM_ID_BYTES) { set_error("bamm_comm_unique_id: buffer of %d bytes needed", BAMM_COMM_ID_BYTES); return BAMM_ERR_ARG; }
+    static_assert(sizeof(ncclUniqueId) == BAMM_COMM_ID_BYTES, "ncclUniqueId size");
+    const Rccl* r = rccl();
+    if (!r) return BAMM_ERR_COMM;
+    ncclUniqueId id;
+    const ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess) return fail(r, "ncclGetUniqueId", rc);
+    memcpy(id_out, &id, sizeof id);
+    return BAMM_OK;
+}
+
+int bamm_comm_init_rank(bamm_ctx* ctx, const void* id, uint32_t rank, uint32_t world, bamm_comm** out) {
+    if (!ctx || !id || !out || world == 0 || rank >= world) { set_error("bamm_comm_init_rank: bad argument"); return BAMM_ERR_ARG; }
+    *out = nullptr;
+    const Rccl* r = rccl();
+    if (!r) return BAMM_ERR_COMM;
+    BAMM_HIP(hipSetDevice(ctx_device(ctx)));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t rc = r->CommInitRank(&comm, (int)world, uid, (int)rank);
+    if (rc != ncclSuccess) return fail(r, "ncclCommInitRank", rc);
+    bamm_comm* c = new bamm_comm();
+    c->comm = comm; c->ctx = ctx; c->rank = rank; c->world = world;
+    *out = c;
+    return BAMM_OK;
+}
+
+int bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rccl_version) {
+    if (!c) { set_error("null communicator"); return BAMM_ERR_ARG; }
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    if (rccl_version) {
+        const Rccl* r = rccl();
+        *rccl_version = 0;
+        if (r) (void)r->GetVersion(rccl_version);
+    }
+    return BAMM_OK;
+}
+
+int bamm_comm_destroy(bamm_comm* c) {
+    if (!c) return BAMM_OK;
+    const Rccl* r = rccl();
+    if (r && c->comm) {
+        (void)hipSetDevice(ctx_device(c->ctx));
+        (void)r->CommDestroy(c->comm);
+    }
+    delete c;
+    return BAMM_OK;
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <string>
@@ -43,6 +44,12 @@ inline size_t v_size(size_t K, size_t W) { return v_offset(K + 1, W); }
 inline size_t bg_offset(size_t k) { return (ipow4(k + 1) - 4) / 3; }
 inline size_t bg_size(size_t K) { return bg_offset(K + 1); }
 
+// internals shared between abi.cpp and comm.cpp
+int ctx_device(const bamm_ctx* c);
+hipStream_t ctx_stream(const bamm_ctx* c);
+int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st);   // ncclAllReduce(ncclInt64, ncclSum)
+bamm_ctx* comm_ctx(const bamm_comm* c);
+
 // positions-per-lane classes the sequence kernels are instantiated for (L <= 64*M)
 constexpr int kNumMClasses = 23;
 extern const int kMClasses[kNumMClasses];
@@ -69,8 +76,10 @@ struct EmKernelArgs {
     uint32_t sparse_wave_bytes;  // per-wave LDS scratch of the sparse M-step
     const float* s;              // device, [W][Y+1], last row entry = neutral element
     const float* q;              // device scalar
-    unsigned long long* partial_n;  // [blocks][W*Y] in [j][y] order, 2^-40 fixed point
-    double*  partial_stat;       // [blocks][4]: llh, sum_r, n_seqs, unused
+    long long* acc;              // nullable.  The pass's ONE fused accumulator [Y*W | llh | sum_r | n_seqs] of 64-bit
+                                 // integers (counts in [y][j] order, fixed point): every block adds its table with
+                                 // no-return device-scope atomics.  Integer sums are exact and order-free.
+    float    fix_scale;          // r is multiplied by this power of two before the 2^40 conversion (1 = 2^-40 units)
     float*   r_out;              // WRITE_R: reference layout, r_base subtracted; sliced path: slot-indexed state / r
     uint64_t r_base;             // pos_off of the first requested sequence
     uint32_t seq_begin, seq_end; // WRITE_R range filter (sequence ids)
@@ -138,7 +147,9 @@ struct ScoreKernelArgs {
 
 struct UpdateArgs {
     uint32_t K, W, Kbg;          // Kbg = min(bg_order, K)
-    const double* red;           // [Y*W + 3]: n_K in [y][j], llh, sum_r, n_seqs
+    long long* acc;              // [Y*W + 3]: n_K in [y][j] (units of count_unit), llh, sum_r (fixed point), n_seqs;
+                                 // consumed AND zeroed for the next pass
+    double   count_unit;         // value of one unit of the counts (2^-40 unless the set is huge)
     const float* vbg;            // flat bg conditionals (orders 0..bg_order)
     const float* A;              // [K+1][W]
     float* n;                    // flat counts (all orders)
@@ -174,9 +185,11 @@ struct MaskKernelArgs {          // EM::mask kernels (mask.hip)
     float*   q;                  // device scalar
     float*   q_seq;              // nullable: q each sequence saw in the order-0 pass (optimizeQ)
     float    n_total;            // number of training sequences (optimize_q's N)
+    float    fix_scale;          // as EmKernelArgs::fix_scale
     float*   r;                  // responsibilities, reference layout (pos_off[n] + r-index)
     uint32_t* bits;              // 1 bit per r slot: window belongs to the top-f set
-    double*  hist;               // [2049]
+    long long* hist;             // [2049] window counts per bin + the number of windows: integers, so that the
+                                 // all-reduce across ranks is the same int64 sum as the EM pass's
     MaskSelect* sel;
     unsigned long long* partial_n;
     double*  partial_stat;
@@ -208,12 +221,13 @@ int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
                    uint32_t threads, hipStream_t st);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
                  hipStream_t st);
+// EM::mask only: its kernels still leave one partial table per block; summed into the fused accumulator
 int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks,
-                           uint32_t W, uint32_t Y, double* red, hipStream_t st);
+                           uint32_t W, uint32_t Y, long long* acc, hipStream_t st);
 int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint32_t Kbg, float* s,
                   hipStream_t st);
 int launch_update(const UpdateArgs& a, hipStream_t st);
-int launch_stat_only(const double* red, uint32_t cells, float* status, hipStream_t st);
+int launch_stat_only(long long* acc, uint32_t cells, float* status, hipStream_t st);
 uint32_t max_threads_for_mclass(int mclass);
 
 }  // namespace bamm

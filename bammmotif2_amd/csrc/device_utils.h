@@ -28,6 +28,18 @@ __device__ __forceinline__ unsigned long long to_fixed40(float r) {
     return ((unsigned long long)hi << 32) | lo;
 }
 constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
+// the pass statistics travel in the same integer accumulator as the counts: log-likelihood in units of
+// 2^-24 (|log Z| < 89 per sequence: 2^32 sequences fit), sum of r in units of 2^-30, the sequence count as is
+constexpr double kLlhScale = 16777216.0, kSumrScale = 1073741824.0;
+// no-return device-scope add (global_atomic_add_x2): the blocks of a pass fold their tables into one
+__device__ __forceinline__ void acc_add(long long* cell, long long v) {
+    (void)__hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// a block's three statistics (threads 0..2 call this with their own k)
+__device__ __forceinline__ void acc_add_stat(long long* acc, uint32_t cells, uint32_t k, double v) {
+    const double scaled = k == 0u ? v * kLlhScale : (k == 1u ? v * kSumrScale : v);
+    acc_add(acc + cells + k, __double2ll_rn(scaled));
+}
 // 128-bit LDS gather.  hipcc splits a float4 LDS load whose components are consumed under
 // different (even wave-uniform) conditions into b32/b64 pieces, which costs 2-4x the LDS cycles
 // (tools/lds_bench2.hip), so the read is issued by hand; lds_wait() retires all of them and

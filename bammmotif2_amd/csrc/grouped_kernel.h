@@ -411,8 +411,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         // 1.5 ulp of the reference's U / Z, EM.cpp:185-187)
         float invZ = __builtin_amdgcn_rcpf(Z);
         invZ = fmaf(fmaf(-Z, invZ, 1.0f), invZ, invZ);
+        // the M-step wants r in units of the count accumulator: the power-of-two scale rides on 1/Z (exact)
+        const float invZs = ACCUM ? invZ * a.fix_scale : invZ;
 #pragma unroll
-        for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187
+        for (int m = 0; m < M; m++) U[m] = U[m] * invZs; // EM.cpp:185-187
         // EM.cpp:195.  v_log_f32 (log2, 1 ulp of its result) times ln 2: as close to logf(Z) as Z itself is
         // known (Z carries half an ulp of its own); the sum runs in fp64
         llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);
@@ -507,11 +509,11 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         stat_lds[wave * 3 + 2] = (double)seq_cnt;
     }
     __syncthreads();
+    if (a.acc == nullptr) return;                        // getR(): responsibilities only
     if (ACCUM) {
-        unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
         const uint32_t C = 1u << logC;
-        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) {
-            const uint32_t j = i / Y, yy = i - j * Y;
+        for (uint32_t o = threadIdx.x; o < W * Y; o += blockDim.x) {       // o = y*W + j: consecutive global cells
+            const uint32_t yy = o / W, j = o - yy * W, i = j * Y + yy;
             const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
             unsigned long long acc = n1[i];
             const unsigned long long* tab = ng + (T - 1u - t);          // + ((row << logC) + copy) * T
@@ -538,13 +540,13 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         }
                 }
             }
-            out[i] = acc;
+            if (acc) acc_add(a.acc + o, (long long)acc);
         }
     }
     if (threadIdx.x < 3) {
         double acc = 0.0;
         for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
-        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+        acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
     }
 }
 

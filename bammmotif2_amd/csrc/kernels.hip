@@ -208,8 +208,10 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         }
         const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
         const float invZ = 1.0f / Z;                     // one IEEE division per sequence
+        // the M-step wants r in units of the count accumulator: the power-of-two scale rides on 1/Z (exact)
+        const float invZs = ACCUM ? invZ * a.fix_scale : invZ;
 #pragma unroll
-        for (int m = 0; m < M; m++) U[m] = U[m] * invZ;  // EM.cpp:185-187 (r/Z within 1 ulp)
+        for (int m = 0; m < M; m++) U[m] = U[m] * invZs; // EM.cpp:185-187 (r/Z within 1 ulp)
         llh_acc += (double)logf(Z);                      // EM.cpp:195
         sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
         seq_cnt++;
@@ -314,7 +316,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         }
     }
 
-    // ---- block epilogue: partial table + statistics
+    // ---- block epilogue: this block's table and statistics into the pass's accumulator
     lds_drain();
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
@@ -322,19 +324,19 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         stat_lds[wave * 3 + 2] = (double)seq_cnt;
     }
     __syncthreads();
+    if (a.acc == nullptr) return;                        // getR(): responsibilities only
     if (ACCUM) {
-        unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y);
-        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) {
-            const uint32_t j = i / Y, yy = i - j * Y;
+        for (uint32_t o = threadIdx.x; o < W * Y; o += blockDim.x) {       // o = y*W + j: consecutive global cells
+            const uint32_t yy = o / W, j = o - yy * W;
             unsigned long long acc = 0ull;
             for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[(((size_t)j * Ys + yy) << logC) + c];
-            out[i] = acc;
+            if (acc) acc_add(a.acc + o, (long long)acc);
         }
     }
     if (threadIdx.x < 3) {
         double acc = 0.0;
         for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
-        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+        acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
     }
 }
 
@@ -415,10 +417,10 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
         stat_lds[wave * 3 + 2] = (double)seq_cnt;
     }
     __syncthreads();
-    if (last && threadIdx.x < 3) {
+    if (last && threadIdx.x < 3 && a.acc) {
         double acc = 0.0;
         for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
-        a.partial_stat[(size_t)blockIdx.x * 4 + threadIdx.x] = acc;
+        acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
     }
 }
 
@@ -455,7 +457,8 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
 #pragma unroll
                 for (int m = 0; m < M; m += 4) {
                     const f32x4u v = *reinterpret_cast<const f32x4u*>(rs + (L - 1u - (p0 + (uint32_t)m + 3u + shift)));
-                    F[m] = to_fixed40(v.w); F[m + 1] = to_fixed40(v.z); F[m + 2] = to_fixed40(v.y); F[m + 3] = to_fixed40(v.x);
+                    F[m] = to_fixed40(v.w * a.fix_scale); F[m + 1] = to_fixed40(v.z * a.fix_scale);
+                    F[m + 2] = to_fixed40(v.y * a.fix_scale); F[m + 3] = to_fixed40(v.x * a.fix_scale);
                 }
                 loaded = true;
             }
@@ -464,7 +467,7 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
 #pragma unroll
             for (int m = 0; m < M; m++) {
                 const uint32_t slot = p0 + m + shift;
-                F[m] = to_fixed40(slot < L ? rs[r_reversed ? L - 1u - slot : slot] : 0.0f);
+                F[m] = to_fixed40(slot < L ? rs[r_reversed ? L - 1u - slot : slot] * a.fix_scale : 0.0f);
             }
         }
         bool dense = true;
@@ -528,12 +531,11 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
     }
     lds_drain();
     __syncthreads();
-    unsigned long long* out = a.partial_n + (size_t)blockIdx.x * (W * Y) + (size_t)j0 * Y;
-    for (uint32_t i = threadIdx.x; i < nc * Y; i += blockDim.x) {
-        const uint32_t j = i / Y, yy = i - j * Y;
+    for (uint32_t i = threadIdx.x; i < nc * Y; i += blockDim.x) {          // i = y*nc + j: runs of nc consecutive cells
+        const uint32_t yy = i / nc, j = i - yy * nc;
         unsigned long long acc = 0ull;
         for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[(((size_t)j * Ys + yy) << logC) + c];
-        out[i] = acc;
+        if (acc) acc_add(a.acc + (size_t)yy * W + j0 + j, (long long)acc);
     }
 }
 
@@ -594,11 +596,12 @@ __global__ void __launch_bounds__(THREADS) k_score(ScoreKernelArgs a) {
     }
 }
 
-// ---- reduce the per-block partial tables (deterministic, fp64) ------------------------------
+// ---- EM::mask: sum the per-block partial tables of the masked kernels into the fused accumulator ------
 // grid.x = ceil(W*Y/64) blocks of 64 cells x 16 groups, + one block for the three statistics
 __global__ void __launch_bounds__(1024) k_reduce_partials(const unsigned long long* partial_n, const double* partial_stat,
-                                                          uint32_t blocks, uint32_t W, uint32_t Y, double* red) {
-    __shared__ double sh[16][64];
+                                                          uint32_t blocks, uint32_t W, uint32_t Y, long long* acc_out) {
+    __shared__ unsigned long long sh[16][64];
+    __shared__ double shd[16][4];
     const uint32_t C = partial_n ? W * Y : 0u;
     if (blockIdx.x + 1u == gridDim.x) {
         // statistics: llh, sum_r, n_seqs -- 256 groups of 4 lanes, summed over the lanes of a wave by
@@ -609,51 +612,29 @@ __global__ void __launch_bounds__(1024) k_reduce_partials(const unsigned long lo
             for (uint32_t b = grp; b < blocks; b += 256u) t += partial_stat[(size_t)b * 4 + k];
 #pragma unroll
         for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
-        if ((threadIdx.x & 63u) < 4u) sh[threadIdx.x >> 6][threadIdx.x & 3u] = t;
+        if ((threadIdx.x & 63u) < 4u) shd[threadIdx.x >> 6][threadIdx.x & 3u] = t;
         __syncthreads();
         if (threadIdx.x < 3u) {
             double acc = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; w++) acc += sh[w][threadIdx.x];
-            red[(size_t)W * Y + threadIdx.x] = acc;
+            for (int w = 0; w < 16; w++) acc += shd[w][threadIdx.x];
+            acc_add_stat(acc_out, W * Y, threadIdx.x, acc);
         }
         return;
     }
     const uint32_t c = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t g = threadIdx.x >> 6;
-    double acc = 0.0;
-    if (c < C) {
-        // sixteen loads in flight per thread: with 256 partial tables the whole sum is one round trip
-        // (a chain of dependent loads was most of this kernel's 8.6 us).  The partials are integers:
-        // the sums are exact below 2^53 whatever the order
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        uint32_t b = g;
-        for (; b + 240u < blocks; b += 256u) {
-            unsigned long long x[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) x[u] = partial_n[(size_t)(b + 16u * (uint32_t)u) * C + c];
-#pragma unroll
-            for (int u = 0; u < 16; u += 4) {
-                a0 += (double)x[u]; a1 += (double)x[u + 1]; a2 += (double)x[u + 2]; a3 += (double)x[u + 3];
-            }
-        }
-        for (; b + 48u < blocks; b += 64u) {
-            a0 += (double)partial_n[(size_t)b * C + c];
-            a1 += (double)partial_n[(size_t)(b + 16u) * C + c];
-            a2 += (double)partial_n[(size_t)(b + 32u) * C + c];
-            a3 += (double)partial_n[(size_t)(b + 48u) * C + c];
-        }
-        for (; b < blocks; b += 16u) a0 += (double)partial_n[(size_t)b * C + c];
-        acc = (a0 + a1) + (a2 + a3);
-    }
+    unsigned long long acc = 0ull;
+    if (c < C)
+        for (uint32_t b = g; b < blocks; b += 16u) acc += partial_n[(size_t)b * C + c];
     sh[g][threadIdx.x & 63u] = acc;
     __syncthreads();
     if (g == 0 && c < C) {
-        double t = 0.0;
+        unsigned long long t = 0ull;
 #pragma unroll
         for (int i = 0; i < 16; i++) t += sh[i][threadIdx.x];
         const uint32_t j = c / Y, y = c % Y;               // LDS layout [j][y] -> ABI layout [y][j]
-        red[(size_t)y * W + j] = t * kFixedScaleInv;
+        if (t) acc_add(acc_out + (size_t)y * W + j, (long long)t);
     }
 }
 
@@ -676,9 +657,18 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     auto voff = [W](uint32_t k) { return (size_t)W * (((size_t(1) << (2 * (k + 1))) - 4) / 3); };
 
-    // order-K counts from the (all-reduced) fp64 buffer
+    // order-K counts from the (all-reduced) integer accumulator, which is left zeroed for the next pass
     float* nK = a.n + voff(K);
-    for (uint32_t i = tid; i < YK * W; i += nt) nK[i] = (float)a.red[i];
+    for (uint32_t i = tid; i < YK * W; i += nt) {
+        nK[i] = (float)((double)a.acc[i] * a.count_unit);
+        a.acc[i] = 0ll;
+    }
+    __shared__ double stat3[3];
+    if (tid < 3) {
+        const long long x = a.acc[(size_t)YK * W + tid];
+        a.acc[(size_t)YK * W + tid] = 0ll;
+        stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : (double)x);
+    }
     __syncthreads();
     // EM.cpp:247-254: n[k-1][y mod 4^k][j] += n[k][y][j], y ascending (same float order)
     for (uint32_t k = K; k > 0; k--) {
@@ -751,9 +741,8 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         }
     }
     if (tid == 0) {
-        const size_t C = (size_t)YK * W;
-        const double llh = a.red[C + 0], sum_r = a.red[C + 1];
-        const double nseq = a.n_seqs_override > 0.0 ? a.n_seqs_override : a.red[C + 2];
+        const double llh = stat3[0], sum_r = stat3[1];
+        const double nseq = a.n_seqs_override > 0.0 ? a.n_seqs_override : stat3[2];
         const uint32_t it = *a.iteration + 1u;
         *a.iteration = it;
         float q = *a.q;
@@ -774,11 +763,13 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
     }
 }
 
-__global__ void k_stat_only(const double* red, uint32_t cells, float* status) {
+// EStep() alone: publish the statistics and clear them (the counts part was not touched)
+__global__ void k_stat_only(long long* acc, uint32_t cells, float* status) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        status[0] = (float)red[cells + 0];
-        status[4] = (float)red[cells + 1];
-        status[5] = (float)red[cells + 2];
+        status[0] = (float)((double)acc[cells + 0] / kLlhScale);
+        status[4] = (float)((double)acc[cells + 1] / kSumrScale);
+        status[5] = (float)acc[cells + 2];
+        acc[cells + 0] = 0ll; acc[cells + 1] = 0ll; acc[cells + 2] = 0ll;
     }
 }
 
@@ -926,10 +917,10 @@ int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t
 }
 
 int launch_reduce_partials(const unsigned long long* partial_n, const double* partial_stat, uint32_t blocks, uint32_t W,
-                           uint32_t Y, double* red, hipStream_t st) {
+                           uint32_t Y, long long* acc, hipStream_t st) {
     const uint32_t C = partial_n ? W * Y : 0u;
     const uint32_t grid = (C + 63u) / 64u + 1u;             // + the statistics block
-    hipLaunchKernelGGL(k_reduce_partials, dim3(grid), dim3(1024), 0, st, partial_n, partial_stat, blocks, W, Y, red);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(grid), dim3(1024), 0, st, partial_n, partial_stat, blocks, W, Y, acc);
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;
 }
@@ -947,8 +938,8 @@ int launch_update(const UpdateArgs& a, hipStream_t st) {
     return BAMM_OK;
 }
 
-int launch_stat_only(const double* red, uint32_t cells, float* status, hipStream_t st) {
-    hipLaunchKernelGGL(k_stat_only, dim3(1), dim3(64), 0, st, red, cells, status);
+int launch_stat_only(long long* acc, uint32_t cells, float* status, hipStream_t st) {
+    hipLaunchKernelGGL(k_stat_only, dim3(1), dim3(64), 0, st, acc, cells, status);
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;
 }

@@ -33,6 +33,10 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+__device__ __forceinline__ void acc_add(long long* cell, long long v) {      // as device_utils.h:acc_add
+    (void)__hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ float mask_wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -192,15 +196,15 @@ __global__ void __launch_bounds__(256) k_mask_hist(MaskKernelArgs a, int pass) {
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 2048u; i += blockDim.x)
-        if (h[i]) atomicAdd(&a.hist[i], (double)h[i]);
-    if (pass == 0 && threadIdx.x == 0 && npos) atomicAdd(&a.hist[2048], (double)npos);
+        if (h[i]) acc_add(&a.hist[i], (long long)h[i]);
+    if (pass == 0 && threadIdx.x == 0 && npos) acc_add(&a.hist[2048], (long long)npos);
 }
 
 __global__ void k_mask_pick(MaskKernelArgs a, int pass, float f) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     MaskSelect* s = a.sel;
     if (pass == 0) {
-        s->pos_count = a.hist[2048];
+        s->pos_count = (double)a.hist[2048];
         const float scaled = (float)(unsigned long long)s->pos_count * f;   // EM.cpp:343
         double rank = (double)(unsigned long long)scaled;
         if (rank >= s->pos_count) rank = s->pos_count - 1.0;                // reference: out-of-bounds read
@@ -210,14 +214,14 @@ __global__ void k_mask_pick(MaskKernelArgs a, int pass, float f) {
     double cum = 0.0;
     int pick = 0;
     for (int b = bins - 1; b >= 0; b--) {
-        const double hb = a.hist[b];
+        const double hb = (double)a.hist[b];
         if (cum + hb > s->rank) { pick = b; break; }
         cum += hb;
     }
     s->rank -= cum;
     s->prefix = pass == 0 ? (uint32_t)pick : (pass == 1 ? ((s->prefix << 11) | (uint32_t)pick) : ((s->prefix << 10) | (uint32_t)pick));
     if (pass == 2) s->cutoff = __uint_as_float(s->prefix);
-    for (int b = 0; b <= 2048; b++) a.hist[b] = 0.0;
+    for (int b = 0; b <= 2048; b++) a.hist[b] = 0ll;
 }
 
 // ---- EM.cpp:345-356 ---------------------------------------------------------------------------
@@ -314,7 +318,7 @@ __global__ void __launch_bounds__(256) k_mask_m(MaskKernelArgs a) {
         const uint32_t cnt = load_list(a, base, L, LW1, lane, w);
         for (uint32_t e = (uint32_t)lane; e < cnt; e += 64u) {
             const uint32_t ri = w.lst[e];
-            const unsigned long long fx = mask_to_fixed40(a.r[base + ri]);
+            const unsigned long long fx = mask_to_fixed40(a.r[base + ri] * a.fix_scale);
             if (fx == 0ull) continue;
             const uint32_t start = L - W - ri;
             for (uint32_t j = j0; j < j1; j++) atomicAdd(&tab[(j - j0) * Y + w.y[start + j]], fx);

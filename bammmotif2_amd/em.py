@@ -161,6 +161,49 @@ class Context:
             self.h = None
 
 
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """One rank of an RCCL communicator bound to a Context (include/bamm_em.h: bamm_comm_*)."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.lib, self.h = ctx, ctx.lib, handle
+
+    @classmethod
+    def init_all(cls, ctxs):
+        """One process driving len(ctxs) distinct devices: ncclCommInitAll."""
+        lib = ctxs[0].lib
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        out = (C.c_void_p * len(ctxs))()
+        check(lib.bamm_comm_init_all(arr, len(ctxs), out))
+        return [cls(c, C.c_void_p(h)) for c, h in zip(ctxs, out)]
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(abi.load().bamm_comm_unique_id(buf, COMM_ID_BYTES))
+        return buf.raw
+
+    @classmethod
+    def init_rank(cls, ctx: Context, uid: bytes, rank: int, world: int):
+        """One process per device: `uid` from rank 0's unique_id(), carried by the launcher."""
+        assert len(uid) == COMM_ID_BYTES
+        h = C.c_void_p()
+        check(ctx.lib.bamm_comm_init_rank(ctx.h, C.c_char_p(uid), rank, world, C.byref(h)))
+        return cls(ctx, h)
+
+    def info(self):
+        r, w, v = C.c_uint32(), C.c_uint32(), C.c_int()
+        check(self.lib.bamm_comm_info(self.h, C.byref(r), C.byref(w), C.byref(v)))
+        return dict(rank=r.value, world=w.value, rccl_version=v.value)
+
+    def close(self):
+        if self.h:
+            self.lib.bamm_comm_destroy(self.h)
+            self.h = None
+
+
 class SeqSet:
     """Sequences resident in HBM (a shard [begin, end) of a PackedSeqs)."""
 
@@ -190,7 +233,7 @@ class EM:
 
     def __init__(self, ctx: Context, seqs: SeqSet, K: int, W: int, vbg, A, v_init, q: float,
                  bg_order: int = 2, optimizeQ: bool = False, mask=None, epsilon: float = 0.01,
-                 max_iterations: int = 1000, n_seqs_global: int = 0):
+                 max_iterations: int = 1000, n_seqs_global: int = 0, n_seqs_bound: int = 0):
         self.ctx, self.lib, self.seqs = ctx, ctx.lib, seqs
         self.K, self.W = K, W
         prm = abi.EmParams()
@@ -198,6 +241,7 @@ class EM:
         prm.K, prm.W, prm.bg_order, prm.q = K, W, bg_order, q
         prm.optimize_q = int(optimizeQ)
         prm.epsilon, prm.max_iterations, prm.n_seqs_global = epsilon, max_iterations, n_seqs_global
+        prm.n_seqs_bound = n_seqs_bound
         self.max_iterations = max_iterations
         vbg, A, v_init = _f32(vbg), _f32(A), _f32(v_init)
         assert len(vbg) >= bg_size(bg_order) and len(A) == (K + 1) * W and len(v_init) == v_size(K, W)
@@ -260,13 +304,13 @@ class EM:
         check(self.lib.bamm_em_reduce_buffer(self.h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
 
-    def set_reduce_buffer(self, dev_ptr: int, n_doubles: int):
-        """Use caller-owned device memory (e.g. a torch float64 tensor) as the fused reduce buffer."""
-        check(self.lib.bamm_em_set_reduce_buffer(self.h, C.c_void_p(dev_ptr), n_doubles))
+    def set_reduce_buffer(self, dev_ptr: int, n_words: int):
+        """Use caller-owned device memory (e.g. a torch int64 tensor) as the fused accumulator."""
+        check(self.lib.bamm_em_set_reduce_buffer(self.h, C.c_void_p(dev_ptr), n_words))
 
     def set_allreduce(self, fn: Optional[Callable[[int, int, int], int]]):
-        """fn(dev_ptr, n_doubles, hip_stream) -> 0 on success; called between the local
-        accumulation and the model update of every pass."""
+        """fn(dev_ptr, n_words, hip_stream) -> 0 on success: sum n_words int64 words across ranks;
+        called between the local accumulation and the model update of every pass."""
         if fn is None:
             self._cb = abi.ALLREDUCE_FN(0)
         else:
@@ -279,6 +323,11 @@ class EM:
                     return 1
             self._cb = abi.ALLREDUCE_FN(tramp)
         check(self.lib.bamm_em_set_allreduce(self.h, self._cb, None))
+
+    def set_comm(self, comm: Optional["Comm"]):
+        """Native path: one ncclAllReduce(int64, sum) of the accumulator per pass, on the context's stream."""
+        check(self.lib.bamm_em_set_comm(self.h, comm.h if comm is not None else None))
+        self._comm = comm
 
     def getV(self) -> np.ndarray:
         out = np.zeros(v_size(self.K, self.W), np.float32)

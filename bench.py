@@ -29,7 +29,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-ALG_BYTES_PER_POSITION = 0.25  # the 2-bit base is the only per-position HBM read
+
+
+def algorithmic_bytes(positions: int, windows: int, sliced: bool) -> float:
+    """SURVEY.md 8(d).  Fused path (tables fit one CU's LDS, k <= 3): the 2-bit base is the only
+    per-position HBM read, 0.25 B/position.  Split path (k >= 4): the sequence is read by the E pass and
+    by the M pass (2 x 0.25 B/position) and the responsibilities make one round trip as f32 (8 B/window)."""
+    return (0.5 * positions + 8.0 * windows) if sliced else 0.25 * positions
 
 
 def parse():
@@ -49,6 +55,10 @@ def parse():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the RCCL all-reduce path even with one rank (self-test)")
+    ap.add_argument("--torch-allreduce", action="store_true",
+                    help="all-reduce through torch.distributed.all_reduce from a Python callback instead of the "
+                         "library's own RCCL call (bamm_em_set_comm), which is the default with the nccl backend")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold-start / optimize()-mode figures")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the fused buffer through the host: lets 2 ranks share ONE GPU (self-test of "
                          "the N>1 logic on a 1-GPU box; never used for reported numbers)")
@@ -122,8 +132,33 @@ def cpu_baseline(codes, in_off, W, K, v0, alpha, q, sample, iters, ss):
                       f"(EStep+MStep), OpenMP on {cores} host threads, -O2"}
 
 
+def lds_roofline(tj, avg_kernel_s):
+    """the sequence kernel's LDS wave-instructions per second against the rate an
+    LDS-only loop of the same instruction mix reaches (tools/lds_mix_bench.hip, run on the same box by
+    tools/pmc_run.sh; its result travels in the PMC summary).  None without a matching profile."""
+    d = tj.get("derived") or {}
+    insts = d.get("lds_wave_instr_per_launch")
+    if not insts or not avg_kernel_s:
+        return None
+    out = {"wave_instr_per_s": insts / avg_kernel_s,
+           "wave_instr_per_launch": insts,
+           "lds_busy_frac": d.get("lds_busy_frac"),
+           "bank_conflict_frac": d.get("lds_bank_conflict_frac"),
+           "valu_busy_frac": d.get("valu_busy_frac")}
+    peak = (tj.get("lds_mix_bench") or {}).get("wave_instr_per_s")
+    if peak:
+        out.update({"peak_from_lds_bench": peak, "frac": out["wave_instr_per_s"] / peak,
+                    "peak_is": (tj.get("lds_mix_bench") or {}).get("what")})
+    return out
+
+
 def main():
     args = parse()
+    # stdout carries ONE JSON line (rank 0).  RCCL prints a version banner on stdout when a communicator
+    # is created: everything written to fd 1 before the result goes to stderr instead.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,14 +201,29 @@ def main():
         ctx.set_launch(args.blocks, args.threads)
     begin, end = packed.shard_range(W, rank, world)
     seqs = bm.SeqSet(ctx, packed, begin, end)
-    em = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=args.steps + args.warmup + 8)
+    em = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=args.steps + args.warmup + 8,
+               n_seqs_bound=args.nseq)      # same unit of the integer count accumulator whatever the number of ranks
 
     keep = []
-    if use_dist:
+    allreduce_kind = "none"
+    if use_dist and args.dist_backend == "nccl" and not args.torch_allreduce:
+        # the library's own collective: ncclAllReduce(int64, sum) on the context's stream, no Python in the
+        # loop.  Rank 0's unique id travels over the torch process group that also serves the barriers.
+        try:
+            uid = [bm.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = bm.Comm.init_rank(ctx, uid[0], rank, world)
+            em.set_comm(comm)
+            keep.append(comm)
+            allreduce_kind = "rccl (libbamm_em, ncclAllReduce int64 on the kernels' stream)"
+        except Exception as e:   # report it, then fall back to the torch path below
+            print(f"[bench] native RCCL path unavailable ({e}); using torch.distributed.all_reduce", file=sys.stderr)
+    if use_dist and allreduce_kind == "none":
+        allreduce_kind = "torch.distributed.all_reduce (%s) from a callback" % args.dist_backend
         _, n = em.reduce_buffer()
-        # the fused [n_K | llh | sum_r | N] buffer lives in a torch tensor, so RCCL sees ordinary
-        # torch memory of this rank's device
-        red = torch.zeros(n, dtype=torch.float64, device=torch.device("cuda", local_rank))
+        # the fused [n_K | llh | sum_r | N] accumulator (64-bit integers, fixed point) lives in a torch
+        # tensor, so RCCL sees ordinary torch memory of this rank's device; int64 sums are exact
+        red = torch.zeros(n, dtype=torch.int64, device=torch.device("cuda", local_rank))
         torch.cuda.synchronize()
         em.set_reduce_buffer(red.data_ptr(), n)
         keep.append(red)
@@ -212,7 +262,26 @@ def main():
         dt = float(t.item())
 
     kernel_ms, launches = em.kernel_time()
+    # beside the steady-state figure: what a run from the seed pays (the first passes are slower: few
+    # responsibilities are exactly zero yet), as iterate() and as optimize() (EM.cpp:81-128: one host
+    # read-back of (llh, v_diff) per pass for the stopping rule); single rank only, outside the timed region
+    extras = {}
+    if world == 1 and not use_dist and not args.no_extras:
+        n_cold = 20
+        with torch.cuda.stream(tstream):
+            e2 = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=n_cold, n_seqs_bound=args.nseq)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter(); e2.iterate(n_cold); torch.cuda.synchronize()
+            extras["ms_per_step_cold"] = (time.perf_counter() - t1) / n_cold * 1e3
+            e2.close()
+            e3 = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=n_cold, epsilon=0.0, n_seqs_bound=args.nseq)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter(); it3 = e3.optimize(); torch.cuda.synchronize()
+            extras["ms_per_step_optimize_mode"] = (time.perf_counter() - t1) / max(it3, 1) * 1e3
+            extras["cold_passes"] = n_cold
+            e3.close()
     local_positions = int(seqs.off[-1])
+    local_windows = int((seqs.lengths.astype(np.int64) - W + 1).sum())
     total_positions = packed.total_len
     total_windows = int((packed.lengths.astype(np.int64) - W + 1).sum())
     llh, vdiff, _ = em.trace()
@@ -224,18 +293,21 @@ def main():
     if rank == 0:
         its = args.steps / dt
         avg_kernel_s = kernel_ms / launches * 1e-3 if launches else float('nan')
-        alg_bytes = ALG_BYTES_PER_POSITION * local_positions
+        sliced = K >= 4
+        alg_bytes = algorithmic_bytes(local_positions, local_windows, sliced)
         achieved = alg_bytes / avg_kernel_s / 1e9
-        traffic, lds_busy = None, None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        # PMC summaries of the same command (tools/pmc_run.sh -> tools/summarize_pmc.py), matched by workload
+        traffic, lds = None, None
+        import glob
+        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):   # newest round first
             try:
                 tj = json.load(open(tpath))
-                if tj.get("positions_per_launch") == local_positions:
+                if tj.get("positions_per_launch") == local_positions and tj.get("order", 2) == K:
                     traffic = tj.get("hbm_bytes_per_launch")
-                    lds_busy = (tj.get("derived") or {}).get("lds_busy_frac")
+                    lds = lds_roofline(tj, avg_kernel_s)
+                    break
             except Exception:
-                traffic = None
+                pass
         out = {
             "metric": "EM seq-positions/sec (and iterations/sec), 1Mx200bp k=2 W=20",
             "value": total_positions * its,
@@ -255,14 +327,21 @@ def main():
                                    f"(L={int(packed.lengths[0])}), W={W}, k={K}, K_bg=2, --EM, fixed iteration budget",
                        "n_seqs": args.nseq, "seq_len": L0, "W": W, "k": K,
                        "parallelism": f"sequences sharded over {world} GPU(s), 1 all-reduce of "
-                                      f"{4 ** (K + 1) * W + 3} doubles per iteration" if world > 1 else "1 GPU"},
+                                      f"{4 ** (K + 1) * W + 3} int64 words per iteration" if world > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "lds_busy_frac": lds_busy,   # PMC: SQ_LDS_IDX_ACTIVE per CU / kernel cycles (profiles/hbm_traffic.json)
-                         "note": "2-bit stream only; the kernel is LDS / VALU issue bound (DESIGN.md section 4)"},
+                         "algorithmic_bytes_rule": ("0.5 B/position + 8 B/window (sequence read by the E and the M pass, "
+                                                    "r written and read once as f32)" if sliced else
+                                                    "0.25 B/position (2-bit base, read once)"),
+                         "lds": lds,
+                         "note": ("E pass + M slices of one iteration, timed together" if sliced else
+                                  "the fused kernel is LDS / VALU issue bound (DESIGN.md section 4): "
+                                  "`lds` prices it against a measured LDS ceiling")},
+            "allreduce": allreduce_kind,
             "llh_last": float(llh[-1]) if len(llh) else None,
+            **extras,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -272,8 +351,8 @@ def main():
             except Exception as e:  # the baseline is a reported number, never a reason to lose the line
                 out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": usable_cpus(),
                                        "kind": "unavailable", "sample": repr(e)}
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     em.close(); seqs.close(); ctx.close()
     if use_dist:

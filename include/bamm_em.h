@@ -47,6 +47,7 @@ extern "C" {
 typedef struct bamm_ctx  bamm_ctx;   /* one device + one stream                                   */
 typedef struct bamm_seqs bamm_seqs;  /* a sequence set resident in HBM (2-bit packed)             */
 typedef struct bamm_em   bamm_em;    /* one EM run; replaces `class EM` (EM.h:11-69)              */
+typedef struct bamm_comm bamm_comm;  /* one rank of an RCCL communicator, bound to a context       */
 
 const char* bamm_last_error(void);
 const char* bamm_version(void);
@@ -142,6 +143,11 @@ typedef struct bamm_em_params {
     float    epsilon;        /* EM.h:62  (0.01)                                              */
     uint32_t max_iterations; /* EM.h:63  (1000)                                              */
     uint64_t n_seqs_global;  /* N used by optimize_q (EM.cpp:515); 0 = this handle's own N   */
+    uint64_t n_seqs_bound;   /* upper bound on the sequences summed into this model over ALL
+                              * ranks; sizes the unit of the integer count accumulator (2^-40
+                              * up to 4M sequences, coarser beyond: the int64 sums never
+                              * overflow).  0 = n_seqs_global, else this handle's own count.
+                              * Ranks that all-reduce together must agree on it.               */
 } bamm_em_params;
 
 void bamm_em_default_params(bamm_em_params* p);
@@ -176,18 +182,43 @@ int  bamm_em_optimize(bamm_em* em, uint32_t* iterations);
  * reads one float past its allocation there (EM.cpp:416).  *cutoff / *listed are optional.     */
 int  bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint64_t* listed);
 
-/* multi-GPU: between the local accumulation and the model update the fused buffer
- * [n_K (4^(K+1)*W) | llh | sum_r | n_seqs] (doubles, on the device, on the context's stream)
- * is summed across ranks by the caller.  Either drive the three phases by hand ...           */
+/* multi-GPU: between the local accumulation and the model update the fused accumulator
+ * [n_K (4^(K+1)*W, [y][j]) | llh | sum_r | n_seqs] is summed across ranks.  It holds SIGNED 64-BIT
+ * INTEGERS (fixed point: counts in units of 2^-40, llh 2^-24, sum_r 2^-30, n_seqs 1), on the device,
+ * written on the context's stream: sum it as int64 (ncclInt64 / torch.int64) -- integer sums are
+ * exact and order-free, so the model does not depend on the number of ranks.  The blocks of the
+ * sequence kernels add into it directly; bamm_em_update consumes it and leaves it zeroed.
+ * Either drive the three phases by hand ...                                                    */
 int  bamm_em_accumulate(bamm_em* em);
-int  bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_doubles);
+int  bamm_em_reduce_buffer(bamm_em* em, void** dev_ptr, uint64_t* n_words);
 int  bamm_em_update(bamm_em* em);
-/* let the fused buffer live in memory the caller allocated (e.g. a torch tensor that is handed
- * to torch.distributed.all_reduce): n_doubles >= 4^(K+1)*W + 3; the caller keeps ownership.   */
-int  bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_doubles);
-/* ... or install a callback that bamm_em_iterate/optimize/mstep invoke at that point.        */
-typedef int (*bamm_allreduce_fn)(void* user, void* dev_ptr, uint64_t n_doubles, void* hip_stream);
+/* let the accumulator live in memory the caller allocated (e.g. a torch.int64 tensor that is handed
+ * to torch.distributed.all_reduce): n_words >= 4^(K+1)*W + 3; the caller keeps ownership.        */
+int  bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_words);
+/* ... or install a callback that bamm_em_iterate/optimize/mstep invoke at that point (int64 sum
+ * of n_words words at dev_ptr, enqueued on hip_stream; EM::mask's window histogram goes through
+ * the same callback) ...                                                                        */
+typedef int (*bamm_allreduce_fn)(void* user, void* dev_ptr, uint64_t n_words, void* hip_stream);
 int  bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user);
+
+/* ... or hand the handle a communicator: every pass then ends its accumulation with one
+ * ncclAllReduce(ncclInt64, ncclSum) of the accumulator over RCCL / xGMI on the context's stream (the
+ * reduction the reference gets from its OpenMP reduction clause and float atomics, EM.cpp:148,240,
+ * 509-513).  The communicator must belong to the handle's context; it outlives the handle.       */
+int  bamm_em_set_comm(bamm_em* em, bamm_comm* comm);
+
+/* ------------------------------------------------------------------ communicators (RCCL) -- */
+/* librccl is opened at the first of these calls; BAMM_ERR_COMM carries RCCL's message.         */
+#define BAMM_COMM_ID_BYTES 128
+/* one process, n devices: a communicator per context (distinct devices), ncclCommInitAll.  Drive
+ * each context from a host thread of its own (as FDR.cpp:37 does with its folds).              */
+int  bamm_comm_init_all(bamm_ctx* const* ctxs, uint32_t n, bamm_comm** out /* [n] */);
+/* one process per device: rank 0 makes an id (BAMM_COMM_ID_BYTES bytes), the launcher carries it
+ * to the other ranks (MPI, a file, torch.distributed ...), every rank calls init_rank.        */
+int  bamm_comm_unique_id(void* id_out, size_t cap);
+int  bamm_comm_init_rank(bamm_ctx* ctx, const void* id, uint32_t rank, uint32_t world, bamm_comm** out);
+int  bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rccl_version);
+int  bamm_comm_destroy(bamm_comm* c);
 
 /* results (each synchronises the stream)                                                     */
 int  bamm_em_get_v(bamm_em* em, float* v_flat);        /* Motif::getV()                       */

@@ -171,6 +171,39 @@ def run_travis_case(R):
     print("wrote travis_jund", neg.N, len(occ), len(files["zoops.stats"]))
 
 
+def run_config5_case(R):
+    """BASELINE config 5's command line on a reduced set: `--EM -k 2 --FDR -n 5 -m 10`, 600 x 200 bp, both
+    strands, W = 20.  The model is seeded through --BaMMFile (Motif::initFromBaMM is reference code here, the
+    PWM seeder is not buildable without Boost); mainBaMM.cpp:100-106 raises mFold to 5000/600+1 = 9 for a
+    set this small, exactly as the drop-in CLI does.  Everything below the FASTA reader is reference code."""
+    import tempfile
+    c = Case("config5", N=600, L0=200, W=20, K=2, seed=1234)
+    S = R.session(c.codes, c.in_off, c.ss, 42)
+    bg, vbg = S.bg(c.bg_order, c.alpha_bg)
+    m0 = S.motif(c.W, c.K, c.alpha, bg, c.q, c.v0)
+    seed_ihbcp, _ = S.write_motif(m0, base="seed")             # Motif::write: %.3e text
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "seed.ihbcp")
+        open(path, "wb").write(seed_ihbcp)
+        m = S.R.ref_motif_from_bamm_file(c.W, c.K, np.ascontiguousarray(c.alpha, np.float32), bg, c.q, path.encode())
+    minSeqN, posN = 5000, c.N
+    mfold = minSeqN // posN + (1 if minSeqN % posN else 0)     # mainBaMM.cpp:100-106 overrides -m 10
+    neg = S.negset(2, mfold, False)
+    files, scores, q = S.fdr(neg, m, bg, 5, False, True, em=True, optimizeQ=False, threads=1, save_pvalues=True)
+    out = dict(codes=c.codes, in_off=c.in_off, W=c.W, K=c.K, seed_ihbcp=np.frombuffer(seed_ihbcp, np.uint8), vbg=vbg,
+               v_seed=S.motif_v(m), neg_n=neg.N, mfold=mfold, fdr_q=np.float32(q),
+               zoops_stats=np.frombuffer(files["zoops.stats"], np.uint8),
+               zoops_pvalues=np.frombuffer(files["zoops.pvalues"], np.uint8),
+               pos_max=scores[0], neg_max=scores[1])
+    # the full-set model of the same command line (mainBaMM.cpp:131-147 runs it before the folds)
+    m_full = S.motif(c.W, c.K, c.alpha, bg, c.q, S.motif_v(m))
+    e = S.em(m_full, bg, False, False)
+    S.R.ref_em_optimize(e)
+    out["v_full"] = S.motif_v(m_full)
+    np.savez_compressed(os.path.join(HERE, "config5_small.npz"), **out)
+    print("wrote config5_small", neg.N, len(files["zoops.stats"]))
+
+
 def run_mask_cases(R):
     """EM::mask (--advanceEM, EM.cpp:261-503) run by the reference itself on the small cases; W=1 is
     left out (the reference reads pos_[n][L], one float past its allocation, EM.cpp:416)."""
@@ -223,7 +256,11 @@ def main():
     if sys.argv[1:] == ["mask"]:
         run_mask_cases(R)
         return
+    if sys.argv[1:] == ["config5"]:
+        run_config5_case(R)
+        return
     run_mask_cases(R)
+    run_config5_case(R)
     run_eval_case(R)
     run_travis_case(R)
     for spec in SMALL_CASES:

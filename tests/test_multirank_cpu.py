@@ -48,21 +48,23 @@ def _worker(rank, world, port, out_dir):
         s = O.linear_s(v, vbg, c.K, c.W, 2)
         r, llh = O.estep(sub_kmer, sub_off, c.K, c.W, s, q)
         n = O.mstep_counts(sub_kmer, sub_off, c.K, c.W, r)
-        buf = np.zeros(cells + 3, np.float64)               # the layout bamm_em_reduce_buffer exposes
-        buf[:cells] = n[bm.v_offset(c.K, c.W):]
-        buf[cells + 0] = llh
-        buf[cells + 1] = sum(float(r[int(sub_off[i]):int(sub_off[i + 1])].sum()) for i in range(e - b))
+        # the layout and number format bamm_em_reduce_buffer exposes: 64-bit integers, counts in units of
+        # 2^-40, llh 2^-24, sum_r 2^-30, the sequence count as is -- summed across ranks as int64
+        buf = np.zeros(cells + 3, np.int64)
+        buf[:cells] = np.rint(n[bm.v_offset(c.K, c.W):].astype(np.float64) * 2.0 ** 40)
+        buf[cells + 0] = np.rint(llh * 2.0 ** 24)
+        buf[cells + 1] = np.rint(sum(float(r[int(sub_off[i]):int(sub_off[i + 1])].sum()) for i in range(e - b)) * 2.0 ** 30)
         buf[cells + 2] = e - b
         t = torch.from_numpy(buf)
         dist.all_reduce(t)                                   # one small collective per iteration
-        nK = t.numpy()[:cells].astype(np.float32)
+        nK = (t.numpy()[:cells] * 2.0 ** -40).astype(np.float32)
         n_all = np.zeros(bm.v_size(c.K, c.W), np.float32)
         n_all[bm.v_offset(c.K, c.W):] = nK
         for k in range(c.K, 0, -1):                          # EM.cpp:247-254
             hi = n_all[bm.v_offset(k, c.W):bm.v_offset(k + 1, c.W)].reshape(4, 4 ** k, c.W)
             n_all[bm.v_offset(k - 1, c.W):bm.v_offset(k, c.W)] = hi.sum(axis=0).ravel()
         v = O.update_v(n_all, c.A, vbg, c.K, c.W)
-        N_glob, sum_r = t.numpy()[cells + 2], t.numpy()[cells + 1]
+        N_glob, sum_r = float(t.numpy()[cells + 2]), t.numpy()[cells + 1] * 2.0 ** -30
         q = float(np.float32((N_glob - sum_r + 1.0) / (N_glob + 2.0)))
     np.save(os.path.join(out_dir, f"v_{rank}.npy"), v)
     np.save(os.path.join(out_dir, f"range_{rank}.npy"), np.array([b, e, q]))

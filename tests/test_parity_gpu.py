@@ -261,7 +261,7 @@ def test_two_shards_with_allreduce_callback_equal_one(gpu_ctx, orc):
     eall = bm.EM(gpu_ctx, sall, c.K, c.W, vbg, c.A, c.v0, c.q, optimizeQ=True)
     pa, n = ea.reduce_buffer()
     pb, _ = eb.reduce_buffer()
-    ha, hb = np.zeros(n), np.zeros(n)
+    ha, hb = np.zeros(n, np.int64), np.zeros(n, np.int64)          # the accumulator holds 64-bit integers
     for _ in range(3):
         ea.accumulate(); eb.accumulate()
         gpu_ctx.sync()
@@ -273,7 +273,8 @@ def test_two_shards_with_allreduce_callback_equal_one(gpu_ctx, orc):
         ea.update(); eb.update()
     eall.iterate(3)
     assert np.array_equal(ea.getV(), eb.getV())                  # redundant, identical updates
-    np.testing.assert_allclose(ea.getV(), eall.getV(), rtol=2e-6, atol=1e-10)
+    assert np.array_equal(ea.getV(), eall.getV())                # integer sums: the split does not show
+    assert np.array_equal(ea.getCounts(), eall.getCounts())
     np.testing.assert_allclose(ea.getQ(), eall.getQ(), rtol=1e-6)
     for x in (ea, eb, eall, sa, sb, sall):
         x.close()
@@ -401,17 +402,23 @@ def test_external_reduce_buffer(gpu_ctx, orc):
     c = Case(**SMALL_CASES[0])
     em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
     _, n = em.reduce_buffer()
-    red = torch.zeros(n + 5, dtype=torch.float64, device="cuda:0")
+    red = torch.zeros(n + 5, dtype=torch.int64, device="cuda:0")
     torch.cuda.synchronize()
     em.set_reduce_buffer(red.data_ptr(), n + 5)
-    em.iterate(2)
+    em.iterate(1)
+    em.accumulate()                                          # second pass, stopped before its update
     gpu_ctx.sync()
     res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, epsilon=0.0, max_iter=2)
-    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
     host = red.cpu().numpy()
     cells = 4 ** (c.K + 1) * c.W
-    np.testing.assert_allclose(host[cells], res["llh"], rtol=1e-5)          # llh of the last pass
+    np.testing.assert_allclose(host[cells] * 2.0 ** -24, res["llh"], rtol=1e-5)          # llh of the second pass
+    np.testing.assert_allclose(host[:cells].reshape(-1, c.W) * 2.0 ** -40,
+                               res["n"][bm.v_offset(c.K, c.W):].reshape(-1, c.W), rtol=2e-5, atol=1e-6)
     assert host[cells + 2] == c.N and np.all(host[n:] == 0)
+    em.update()
+    gpu_ctx.sync()
+    assert np.all(red.cpu().numpy() == 0)                     # consumed and cleared for the next pass
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=2e-5, atol=1e-9)
     with pytest.raises(bm.abi.BammError):
         em.set_reduce_buffer(red.data_ptr(), 3)
     em.close(); ss.close()

@@ -17,7 +17,7 @@ ctx = bm.Context(0, ts.cuda_stream)
 seqs = bm.SeqSet(ctx, packed)
 em = bm.EM(ctx, seqs, K, W, vbg, A, v0, 0.3, bg_order=2, max_iterations=1000)
 _, n = em.reduce_buffer()
-red = torch.zeros(n, dtype=torch.float64, device="cuda:0"); torch.cuda.synchronize()
+red = torch.zeros(n, dtype=torch.int64, device="cuda:0"); torch.cuda.synchronize()
 em.set_reduce_buffer(red.data_ptr(), n)
 def cb(_p, _n, _s):
     dist.all_reduce(red); return 0

@@ -1,0 +1,113 @@
+// LDS ceiling for the fused EM kernel's own instruction mix (figure iii).
+//
+// k_em_grp on the bench workload (K=2, W=20: 3 columns per table row, T=7 groups, 7 positions per lane)
+// issues per sequence 14 `ds_read_b128` (7 positions x 2 quads of a random 48-byte table row) and 49
+// predicated `ds_add_u64` (7 positions x 7 groups, ~15 of 64 lanes active, random rows of a [row][group]
+// table).  This loop issues exactly that mix -- same table geometry, same 16 waves per CU, random rows,
+// no decode, no chain arithmetic, no normalisation -- so its rate is what the LDS pipe alone allows for
+// THIS access pattern (bank conflicts of random rows included).  Reads-only and adds-only rates are
+// printed beside it.  One JSON line at the end for tools/summarize_pmc.py.
+//   hipcc --offload-arch=gfx950 -O3 tools/lds_mix_bench.hip -o tools/lds_mix_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int M = 7, T = 7, ROWS = 1100, ROWSTRIDE_B = 48;      // bytes per odds-table row (3 quads)
+
+template <int OFF>
+__device__ __forceinline__ f32x4 rd128(uint32_t a) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void add64(uint32_t a, unsigned long long v, unsigned long long mask) {
+    unsigned long long saved;
+    asm volatile("s_and_saveexec_b64 %0, %3\n\tds_add_u64 %1, %2 offset:%4\n\ts_mov_b64 exec, %0"
+                 : "=&s"(saved) : "v"(a), "v"(v), "s"(mask), "n"(OFF) : "memory", "scc");
+}
+
+template <bool READS, bool ADDS>
+__global__ void __launch_bounds__(1024) k_mix(int iters, int active_per_64, float* sink) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t sg_bytes = ROWS * ROWSTRIDE_B, ng_off = (sg_bytes + 15u) & ~15u;
+    for (uint32_t i = threadIdx.x; i < (ng_off + ROWS * T * 8u) / 4u; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1.0f;
+    __syncthreads();
+    const uint32_t sg_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    const uint32_t ng_base = sg_base + ng_off;
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    float acc = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        uint32_t row[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) { x = x * 1664525u + 1013904223u; row[m] = (x >> 8) % ROWS; }
+        if (READS) {
+            f32x4 v[2 * M];
+#pragma unroll
+            for (int m = 0; m < M; m++) v[m] = rd128<0>(sg_base + row[m] * ROWSTRIDE_B);
+#pragma unroll
+            for (int m = 0; m < M; m++) v[M + m] = rd128<16>(sg_base + row[m] * ROWSTRIDE_B);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+#pragma unroll
+            for (int m = 1; m < 2 * M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
+#pragma unroll
+            for (int m = 0; m < 2 * M; m++) acc += v[m].x;
+        }
+        if (ADDS) {
+            unsigned long long mask[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                x = x * 1664525u + 1013904223u;
+                mask[m] = __ballot((int)((x >> 10) & 63u) < active_per_64);
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t a = ng_base + row[m] * (T * 8u);
+                add64<0>(a, 3ull, mask[m]);  add64<8>(a, 3ull, mask[(m + 1) % M]);  add64<16>(a, 3ull, mask[(m + 2) % M]);
+                add64<24>(a, 3ull, mask[(m + 3) % M]); add64<32>(a, 3ull, mask[(m + 4) % M]); add64<40>(a, 3ull, mask[(m + 5) % M]);
+                add64<48>(a, 3ull, mask[(m + 6) % M]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+template <bool R, bool A>
+int run(const char* name, int per_iter, int iters, int active, float* sink, double* rate_out) {
+    const size_t lds = ((ROWS * ROWSTRIDE_B + 15) & ~15) + ROWS * T * 8;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mix<R, A>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_mix<R, A>), dim3(256), dim3(1024), lds, 0, iters / 10, active, sink);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_mix<R, A>), dim3(256), dim3(1024), lds, 0, iters, active, sink);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double wave_instr = 256.0 * 16.0 * (double)iters * per_iter;
+    const double rate = wave_instr / (ms * 1e-3);
+    printf("%-28s %8.3f ms  %6.2f ns per sequence-equivalent per CU  %.3e LDS wave-instr/s  (%.2f cycles per wave-instr per CU @2.4 GHz)\n",
+           name, ms, ms * 1e6 / (16.0 * iters), rate, 2.4e9 * 256.0 / rate);
+    if (rate_out) *rate_out = rate;
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const int iters = 4000, active = argc > 1 ? atoi(argv[1]) : 15;
+    float* sink;
+    CK(hipMalloc(&sink, 4));
+    double mix = 0, r = 0, a = 0;
+    if (run<true, false>("14 ds_read_b128", 14, iters, active, sink, &r)) return 1;
+    if (run<false, true>("49 ds_add_u64", 49, iters, active, sink, &a)) return 1;
+    if (run<true, true>("14 reads + 49 adds", 63, iters, active, sink, &mix)) return 1;
+    printf("{\"wave_instr_per_s\": %.6e, \"reads_only_wave_instr_per_s\": %.6e, \"adds_only_wave_instr_per_s\": %.6e, "
+           "\"active_lanes_per_add\": %d, \"what\": \"LDS-only loop of k_em_grp's mix on the bench workload: 14 ds_read_b128 + 49 "
+           "predicated ds_add_u64 per sequence, random rows of the same tables, 16 waves per CU (tools/lds_mix_bench.hip)\"}\n",
+           mix, r, a, active);
+    return 0;
+}
