@@ -94,6 +94,15 @@ void fdr_statistics(std::vector<float> pos_max, std::vector<float> neg_max, std:
 int fdr_write(const std::string& dir, const std::string& basename, const FdrResult& r, size_t posN, size_t negN,
               bool mops, bool zoops, bool save_prs, bool save_pvalues, std::string& err);   // FDR.cpp:338-410
 
+// --saveLogOdds: FDR::write's .zoops.logOdds / .mops.logOdds (FDR.cpp:416-450) and
+// ScoreSeqSet::writeLogOdds' .logOddsZoops (ScoreSeqSet.cpp:293-331)
+int fdr_logodds_write(const std::string& dir, const std::string& basename, std::vector<float> pos_max, std::vector<float> neg_max,
+                      std::vector<float> pos_all, std::vector<float> neg_all, size_t posN, size_t negN, bool mops, bool zoops,
+                      bool ascending, std::string& err);
+int logodds_zoops_write(const std::string& dir, const std::string& basename, const std::vector<std::string>& headers,
+                        const uint8_t* codes, const uint64_t* off, size_t n_seqs, bool revcomp, bool ss, uint32_t W,
+                        const float* zoops, const uint64_t* z, std::string& err);
+
 // ScoreSeqSet::calcPvalues (seq_scoring/ScoreSeqSet.cpp:70-126): p-/e-values of every window
 void mops_pvalues(const float* pos_scores, size_t n_pos_scores, std::vector<float> neg_all, size_t posN,
                   std::vector<float>& p_out, std::vector<float>& e_out);

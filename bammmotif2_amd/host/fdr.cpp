@@ -456,6 +456,65 @@ int fdr_write(const std::string& dir, const std::string& basename, const FdrResu
     return 0;
 }
 
+// FDR::write, saveLogOdds_ branch (FDR.cpp:416-450): score i of the positives beside score
+// i * negN / posN of the negatives.  The reference writes its vectors in whatever order the statistics left
+// them: descending after calculatePR (FDR.cpp:158-159,203-204), ascending when calculatePvalues ran as well
+// (FDR.cpp:288-289,310-311).  A negative index beyond the list (negN not a multiple of cvFold) ends the file:
+// the reference reads past the end there.
+int fdr_logodds_write(const std::string& dir, const std::string& basename, std::vector<float> posMax, std::vector<float> negMax,
+                      std::vector<float> posAll, std::vector<float> negAll, size_t posN, size_t negN, bool mops, bool zoops,
+                      bool ascending, std::string& err) {
+    auto order = [&](std::vector<float>& v) {
+        if (ascending) std::sort(v.begin(), v.end(), std::less<float>());
+        else std::sort(v.begin(), v.end(), std::greater<float>());
+    };
+    auto emit = [&](const std::string& path, std::vector<float>& pos, std::vector<float>& neg) {
+        order(pos); order(neg);
+        std::ofstream f(path);
+        if (!f.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+        f << "positive" << '\t' << "negative" << std::endl;
+        RowWriter w(6);
+        for (size_t i = 0; i < pos.size(); i++) {
+            const size_t j = i * negN / posN;
+            if (j >= neg.size()) break;
+            w.num(pos[i]); w.tab(); w.num(neg[j]); w.nl();
+            w.maybe_flush(f);
+        }
+        w.flush_to(f);
+        return 0;
+    };
+    if (zoops && emit(dir + '/' + basename + ".zoops.logOdds", posMax, negMax)) return 1;
+    if (mops && emit(dir + '/' + basename + ".mops.logOdds", posAll, negAll)) return 1;
+    return 0;
+}
+
+// ScoreSeqSet::writeLogOdds (seq_scoring/ScoreSeqSet.cpp:293-331): the best window of every sequence.
+// `revcomp`: the stored sequences carry the reverse strand behind an N (positives unless --ss); the sampled
+// negatives never do, although the reference halves their length column too when --ss is absent.
+int logodds_zoops_write(const std::string& dir, const std::string& basename, const std::vector<std::string>& headers,
+                        const uint8_t* codes, const uint64_t* off, size_t n_seqs, bool revcomp, bool ss, uint32_t W,
+                        const float* zoops, const uint64_t* z, std::string& err) {
+    std::ofstream f(dir + '/' + basename + ".logOddsZoops");
+    if (!f.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
+    f << "seq\tlength\tstrand\tstart..end\tpattern\tzoops_score" << std::endl;
+    static const char B[] = "NACGT";
+    for (size_t n = 0; n < n_seqs; n++) {
+        const size_t L0 = off[n + 1] - off[n], L = revcomp ? 2 * L0 + 1 : L0;
+        size_t seqlen = L;
+        if (!ss) seqlen = (seqlen - 1) / 2;
+        const uint8_t* c = codes + off[n];
+        f << headers[n] << '\t' << seqlen << '\t' << ((z[n] < seqlen) ? '+' : '-') << '\t' << z[n] + 1 << ".." << z[n] + W << '\t';
+        for (size_t m = z[n]; m < z[n] + W; m++) {
+            char b = 'N';                                      // Sequence::getSequence(): forward, N, reverse complement
+            if (m < L0) b = B[c[m] <= 4 ? c[m] : 0];
+            else if (revcomp && m > L0 && m < L) { const uint8_t x = c[2 * L0 - m]; b = (x >= 1 && x <= 4) ? B[5 - x] : 'N'; }
+            f << b;
+        }
+        f << '\t' << std::setprecision(3) << zoops[n] << std::endl;
+    }
+    return 0;
+}
+
 void mops_pvalues(const float* pos_scores, size_t n_pos_scores, std::vector<float> neg, size_t posN,
                   std::vector<float>& p_out, std::vector<float>& e_out) {
     const size_t negN = neg.size();                    // ScoreSeqSet.cpp:75-93

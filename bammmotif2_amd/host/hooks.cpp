@@ -144,6 +144,22 @@ int bh_fdr_stats(const float* pos_max, uint64_t n_pos_max, const float* neg_max,
     return fdr_write(dir, base, r, posN, negN, mops != 0, zoops != 0, true, save_pvalues != 0, g_err);
 }
 
+// --saveLogOdds writers on caller-provided scores
+int bh_fdr_logodds(const float* pos_max, uint64_t n_pos_max, const float* neg_max, uint64_t n_neg_max, const float* pos_all,
+                   uint64_t n_pos_all, const float* neg_all, uint64_t n_neg_all, uint64_t posN, uint64_t negN, int mops, int zoops,
+                   int ascending, const char* dir, const char* base) {
+    return fdr_logodds_write(dir, base, std::vector<float>(pos_max, pos_max + n_pos_max), std::vector<float>(neg_max, neg_max + n_neg_max),
+                             std::vector<float>(pos_all, pos_all + n_pos_all), std::vector<float>(neg_all, neg_all + n_neg_all), posN, negN,
+                             mops != 0, zoops != 0, ascending != 0, g_err);
+}
+
+int bh_logodds_zoops(const char* dir, const char* base, const char* header_prefix, int number_headers, const uint8_t* codes,
+                     const uint64_t* off, uint64_t n_seqs, int revcomp, int ss, uint32_t W, const float* zoops, const uint64_t* z) {
+    std::vector<std::string> headers;
+    for (uint64_t n = 0; n < n_seqs; n++) headers.push_back(number_headers ? header_prefix + std::to_string(n) : std::string(header_prefix));
+    return logodds_zoops_write(dir, base, headers, codes, off, n_seqs, revcomp != 0, ss != 0, W, zoops, z, g_err);
+}
+
 int bh_mops_pvalues(const float* pos_scores, uint64_t n_pos, const float* neg_all, uint64_t n_neg, uint64_t posN, float* p_out,
                     float* e_out) {
     std::vector<float> p, e;

@@ -1,9 +1,10 @@
 // BaMMmotif OUTDIR FASTA [options] -- MI355X drop-in for the reference driver
 // (/root/reference/src/refinement/mainBaMM.cpp, Global.cpp).  The EM itself runs on the GPU
 // through the C ABI (include/bamm_em.h); everything here is host plumbing with the reference's
-// flags, defaults, messages and output files, including --scoreSeqset (.occurrence) and --FDR
-// (cross-validated .zoops.stats) and --advanceEM (EM::mask).  Not ported (exit with a clear
-// message): --CGS, --saveLogOdds, non-STANDARD alphabets.
+// flags, defaults, messages and output files, including --scoreSeqset (.occurrence), --FDR
+// (cross-validated .zoops.stats), --saveLogOdds and --advanceEM (EM::mask); --gpus N shards the
+// sequences (--EM) and spreads the cross-validation folds (--FDR) over N GPUs.  Not ported (exit
+// with a clear message): --CGS, non-STANDARD alphabets.
 #include <omp.h>
 #include <sys/stat.h>
 
@@ -48,6 +49,10 @@ void print_help() {
     printf("\t EXTENSIONS of this build:\n");
     printf("\t\t --maxEMIterations <INT> (1000)   -e, --epsilon <FLOAT> (0.01)   --device <INT> (0)\n");
     printf("\t\t --timing (wall time per stage on stderr)   --hostSeeding (initFromPWM's pass on the host)\n");
+    printf("\t\t --gpus <INT> (1)   --deviceList <INT,INT,..>\n");
+    printf("\t\t\t --EM: the sequences are sharded over the GPUs, one RCCL all-reduce of the count table per iteration;\n");
+    printf("\t\t\t --FDR: cross-validation fold f runs on GPU f mod N (FDR.cpp:37 runs the folds on host threads).\n");
+    printf("\t\t\t Output files do not depend on the number of GPUs.\n");
     printf("\n==================================================================\n");
 }
 
@@ -135,7 +140,9 @@ struct Options {                       // Global.cpp:6-96 defaults
     size_t cvFold = 4, mFold = 1, sOrder = 2, threads = 4;
     uint32_t max_iter = 1000;
     int device = 0;
-    bool timing = false, hostSeeding = false;
+    bool timing = false, hostSeeding = false, forceComm = false;
+    size_t gpus = 1;                   // --gpus N: devices device .. device+N-1 (or --deviceList)
+    std::vector<int> device_list;
 };
 
 template <class T>
@@ -238,6 +245,21 @@ Options parse(int nargs, char** args) {
     a.get(0, "device", o.device);
     o.timing = a.present(0, "timing");
     o.hostSeeding = a.present(0, "hostSeeding");
+    a.get(0, "gpus", o.gpus);
+    {   // --deviceList 0,1,2: explicit devices (a device may appear twice for the fold replicas of --FDR; the
+        // sharded --EM wants distinct ones, RCCL has one rank per GPU)
+        std::string list;
+        if (a.get_str(0, "deviceList", list)) {
+            std::stringstream ss(list);
+            std::string tok;
+            while (std::getline(ss, tok, ',')) if (!tok.empty()) o.device_list.push_back(atoi(tok.c_str()));
+            if (o.device_list.empty()) { fprintf(stderr, "--deviceList format error.\n"); exit(1); }
+            o.gpus = o.device_list.size();
+        }
+    }
+    if (o.gpus < 1) o.gpus = 1;
+    if (o.device_list.empty()) for (size_t d = 0; d < o.gpus; d++) o.device_list.push_back(o.device + (int)d);
+    o.forceComm = a.present(0, "forceComm");
     if (a.remain()) {
         print_help();
         std::cerr << "Oops! Unknown option(s) remaining... \n\n";
@@ -270,7 +292,6 @@ int main(int nargs, char* args[]) {
     timing = o.timing;
     if (o.alphabet != "STANDARD") die("Error: this build supports --alphabet STANDARD only.");
     if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
-    if (o.saveLogOdds) die("Error: --saveLogOdds is not ported.");
     if (o.K > BAMM_MAX_ORDER) die("Error: model order above 10 is not supported (kmer_ spans 11 bases).");
 
     std::string err;
@@ -309,15 +330,30 @@ int main(int nargs, char* args[]) {
     std::vector<uint64_t> off(pos.size() + 1, 0);
     for (size_t n = 0; n < pos.size(); n++) off[n + 1] = off[n] + packed->len[n];
     const bool need_gpu = o.EM || o.score || o.FDR;
-    bamm_ctx* ctx = nullptr;
+    // one slot per GPU (a single one unless --gpus / --deviceList): context, resident sets, RCCL rank
+    struct Dev {
+        int device = 0;
+        bamm_ctx* ctx = nullptr;
+        bamm_seqs* full = nullptr;         // every kept positive (scoring, fold replicas, single-GPU EM)
+        bamm_seqs* shard = nullptr;        // this GPU's range of the kept positives (the full set with one GPU)
+        bamm_seqs* neg = nullptr;          // the sampled negatives
+        bamm_comm* comm = nullptr;
+        uint64_t begin = 0, end = 0;
+    };
+    const size_t ndev = need_gpu ? o.device_list.size() : 1;
+    std::vector<Dev> devs(ndev);
+    for (size_t d = 0; d < ndev; d++) devs[d].device = o.device_list[d];
+    auto make_ctx = [&](Dev& dv) {
+        if (!dv.ctx && bamm_ctx_create(dv.device, nullptr, &dv.ctx)) die_abi("no usable MI355X");
+    };
     bamm_seqs* dseqs_all = nullptr;                          // every positive record, resident (seeding, then EM)
     SeedDevice seed_dev;
     std::vector<uint32_t> yK;
     if (need_gpu && o.seed_tag == "PWM" && !o.hostSeeding) {
         // Motif::initFromPWM's pass over the sequences runs on the device: upload first
-        if (bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
-        if (bamm_seqs_upload(ctx, packed, 0, packed->n_seqs, &dseqs_all)) die_abi("upload");
-        seed_dev.ctx = ctx; seed_dev.seqs = dseqs_all;
+        make_ctx(devs[0]);
+        if (bamm_seqs_upload(devs[0].ctx, packed, 0, packed->n_seqs, &dseqs_all)) die_abi("upload");
+        seed_dev.ctx = devs[0].ctx; seed_dev.seqs = dseqs_all;
         stage("device context + upload of the positives");
     } else if (o.seed_tag == "PWM") {
         yK.resize(packed->total_len ? packed->total_len : 1);
@@ -336,13 +372,15 @@ int main(int nargs, char* args[]) {
     if (posN < o.cvFold) { std::cerr << "There are " << posN << " sequences longer than input motif. Exit!\n"; exit(1); }
 
     if (o.verbose) std::cout << std::endl << "*********************" << std::endl << "*   BaMM Training   *" << std::endl << "*********************" << std::endl;
-    bamm_seqs* dseqs = nullptr;
-    bamm_seqs* dneg = nullptr;
     std::vector<uint8_t> neg_codes;
     std::vector<uint64_t> neg_off{0};
     std::vector<uint32_t> kept_len;
+    // sequences sharded over the GPUs for the main EM run: one RCCL rank per GPU, so only over distinct devices
+    // (a device listed twice still hosts fold replicas of --FDR, each with a context and a stream of its own)
+    const bool distinct = std::set<int>(o.device_list.begin(), o.device_list.end()).size() == ndev;
+    const bool sharded = ndev > 1 && o.EM && distinct;
     if (need_gpu) {
-        if (!ctx && bamm_ctx_create(o.device, nullptr, &ctx)) die_abi("no usable MI355X");
+        for (auto& dv : devs) make_ctx(dv);
         bamm_packed* use = packed;
         bamm_packed* filtered = nullptr;
         if (posN != pos.size()) {                            // re-pack only the kept records; kmers are position-local
@@ -355,15 +393,36 @@ int main(int nargs, char* args[]) {
             if (bamm_pack_kmers(km.data(), kept_off.data(), kept_off.size() - 1, &filtered)) die_abi("re-pack");
             use = filtered;
         }
-        if (dseqs_all && use == packed) {
-            dseqs = dseqs_all;                               // nothing was dropped: the seeding copy is the training set
-        } else {
-            if (dseqs_all) bamm_seqs_destroy(dseqs_all);
-            if (bamm_seqs_upload(ctx, use, 0, use->n_seqs, &dseqs)) die_abi("upload");
+        if (dseqs_all && use != packed) { bamm_seqs_destroy(dseqs_all); dseqs_all = nullptr; }
+        // which GPU needs what: the full set where sequences are scored (GPU 0) or folds are trained (every GPU
+        // with --FDR), a shard where the main EM run is sharded
+        for (size_t d = 0; d < ndev; d++) {
+            Dev& dv = devs[d];
+            const bool want_full = !sharded || (d == 0 && o.score) || o.FDR;
+            if (want_full) {
+                if (d == 0 && dseqs_all) dv.full = dseqs_all;   // nothing was dropped: the seeding copy is the training set
+                else if (bamm_seqs_upload(dv.ctx, use, 0, use->n_seqs, &dv.full)) die_abi("upload");
+            } else if (d == 0 && dseqs_all) {
+                bamm_seqs_destroy(dseqs_all);
+            }
+            if (sharded) {
+                if (bamm_shard_range(use->len, use->n_seqs, seeds.max_w, (uint32_t)d, (uint32_t)ndev, &dv.begin, &dv.end)) die_abi("shard range");
+                if (bamm_seqs_upload(dv.ctx, use, dv.begin, dv.end, &dv.shard)) die_abi("upload of a shard");
+            } else {
+                dv.shard = dv.full; dv.begin = 0; dv.end = use->n_seqs;
+            }
         }
         dseqs_all = nullptr;
         kept_len.assign(use->len, use->len + use->n_seqs);
-        stage("device context + upload of the positives");
+        stage("device contexts + upload of the positives");
+        if (sharded || o.forceComm) {
+            std::vector<bamm_ctx*> ctxs;
+            std::vector<bamm_comm*> comms(ndev, nullptr);
+            for (auto& dv : devs) ctxs.push_back(dv.ctx);
+            if (bamm_comm_init_all(ctxs.data(), (uint32_t)ndev, comms.data())) die_abi("RCCL communicator");
+            for (size_t d = 0; d < ndev; d++) devs[d].comm = comms[d];
+            stage("RCCL communicator over the GPUs");
+        }
         if (o.score || o.FDR) {
             // negative set sampled from the s-mer statistics of the (kept) positives, mainBaMM.cpp:97-116
             size_t mFold = o.mFold;
@@ -374,27 +433,34 @@ int main(int nargs, char* args[]) {
             std::vector<uint64_t> uoff(use->n_seqs + 1, 0);
             for (uint64_t n = 0; n < use->n_seqs; n++) uoff[n + 1] = uoff[n] + use->len[n];
             if (sample_negatives(ys.data(), uoff.data(), use->n_seqs, (uint32_t)o.sOrder, mFold, o.genericNeg, neg_codes, neg_off, err)) die(err);
+            stage("negative set: sample (host, rand() stream of the reference)");
             bamm_packed* npk = nullptr;
             if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) die_abi("packing negatives");
-            if (bamm_seqs_upload(ctx, npk, 0, npk->n_seqs, &dneg)) die_abi("upload negatives");
+            for (size_t d = 0; d < ndev; d++)
+                if (d == 0 || o.FDR)
+                    if (bamm_seqs_upload(devs[d].ctx, npk, 0, npk->n_seqs, &devs[d].neg)) die_abi("upload negatives");
             bamm_packed_free(npk);
-            stage("negative set: sample + pack + upload");
+            stage("negative set: pack + upload");
         }
         if (filtered) bamm_packed_free(filtered);
     }
     const size_t negN = neg_off.size() - 1;
     // scorer over a resident set: MOPS scores (concatenated), ZOOPS maxima
-    auto score_set = [&](bamm_seqs* set, const std::vector<uint32_t>& lens, const Motif& m, std::vector<float>& mops,
-                         std::vector<float>& zoops, const uint8_t* subset = nullptr, bool want_mops = true) {
+    auto score_set = [&](bamm_ctx* ctx, bamm_seqs* set, const std::vector<uint32_t>& lens, const Motif& m, std::vector<float>& mops,
+                         std::vector<float>& zoops, const uint8_t* subset = nullptr, bool want_mops = true,
+                         std::vector<uint64_t>* z_out = nullptr) {
         size_t total = 0;
         if (want_mops) for (uint32_t L : lens) total += L - m.W + 1;
         mops.assign(total ? total : 1, 0.f);
         zoops.assign(lens.size() ? lens.size() : 1, 0.f);
-        std::vector<uint64_t> z(lens.size() ? lens.size() : 1);
+        std::vector<uint64_t> z_local;
+        std::vector<uint64_t>& z = z_out ? *z_out : z_local;
+        z.assign(lens.size() ? lens.size() : 1, 0);
         if (bamm_logodds_subset(ctx, set, subset, m.K, m.W, bg.K, m.v.data(), bg.v.data(), want_mops ? mops.data() : nullptr, total,
-                                zoops.data(), z.data())) die_abi("calcLogOdds");
+                                zoops.data(), z.data())) return 1;
         mops.resize(total);
         zoops.resize(lens.size());
+        return 0;
     };
     std::vector<uint32_t> neg_len;
     for (size_t n = 0; n < negN; n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
@@ -408,6 +474,14 @@ int main(int nargs, char* args[]) {
             kept_codes.insert(kept_codes.end(), pos.codes.begin() + pos.off[n], pos.codes.begin() + pos.off[n + 1]);
             kept_off.push_back(kept_codes.size());
         }
+    auto em_params = [&](const Motif& m) {
+        bamm_em_params p;
+        bamm_em_default_params(&p);
+        p.K = m.K; p.W = m.W; p.bg_order = bg.K; p.q = m.q; p.optimize_q = o.optimizeQ;
+        p.epsilon = o.epsilon; p.max_iterations = o.max_iter;
+        p.n_seqs_bound = posN;                               // one unit for the count accumulator on every GPU
+        return p;
+    };
 
     for (size_t n = 0; n < seeds.motifs.size(); n++) {
         Motif motif = seeds.motifs[n];                       // deep copy (mainBaMM.cpp:121)
@@ -415,15 +489,34 @@ int main(int nargs, char* args[]) {
         if (o.saveInitial && motif_write(o.out_dir, o.basename + "_init_motif_" + std::to_string(n + 1), motif, err)) die(err);
         if (o.EM) {
             auto t0 = std::chrono::high_resolution_clock::now();
-            bamm_em_params p;
-            bamm_em_default_params(&p);
-            p.K = motif.K; p.W = motif.W; p.bg_order = bg.K; p.q = motif.q; p.optimize_q = o.optimizeQ;
-            p.epsilon = o.epsilon; p.max_iterations = o.max_iter;
-            bamm_em* em = nullptr;
-            if (bamm_em_create(ctx, dseqs, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &em)) die_abi("EM");
-            uint32_t it = 0;
-            if (!o.advanceEM) { if (bamm_em_optimize(em, &it)) die_abi("EM::optimize"); }      // mainBaMM.cpp:133-137
-            else if (bamm_em_mask(em, o.f, &it, nullptr, nullptr)) die_abi("EM::mask");
+            if (o.advanceEM && o.optimizeQ && devs[0].comm)
+                die("Error: --advanceEM --optimizeQ re-estimates q after every sequence (EM.cpp:321); that chain cannot be sharded over GPUs.");
+            const bamm_em_params p = em_params(motif);
+            // one handle per GPU over its shard; with several GPUs each is driven by a host thread of its own and
+            // every pass ends in one RCCL all-reduce, after which all of them hold the same model
+            std::vector<bamm_em*> ems(ndev, nullptr);
+            std::vector<std::string> thread_err(ndev);
+            std::vector<uint32_t> its(ndev, 0);
+            for (size_t d = 0; d < ndev; d++) {
+                if (d > 0 && !sharded) break;
+                if (bamm_em_create(devs[d].ctx, devs[d].shard, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &ems[d])) die_abi("EM");
+                if (devs[d].comm && bamm_em_set_comm(ems[d], devs[d].comm)) die_abi("EM communicator");
+            }
+            const int nthreads = sharded ? (int)ndev : 1;
+#pragma omp parallel num_threads(nthreads)
+            {
+                const size_t d = (size_t)omp_get_thread_num();
+                if (d < ndev && ems[d]) {
+                    int rc;
+                    if (!o.advanceEM) rc = bamm_em_optimize(ems[d], &its[d]);                    // mainBaMM.cpp:133-137
+                    else rc = bamm_em_mask(ems[d], o.f, &its[d], nullptr, nullptr);
+                    if (rc) thread_err[d] = bamm_last_error();                                    // thread-local message
+                }
+            }
+            for (size_t d = 0; d < ndev; d++)
+                if (!thread_err[d].empty()) die("Error: EM on GPU " + std::to_string(devs[d].device) + ": " + thread_err[d]);
+            bamm_em* em = ems[0];
+            const uint32_t it = its[0];
             if (bamm_em_get_v(em, motif.v.data())) die_abi("get_v");
             float q = 0;
             bamm_em_get_q(em, &q);
@@ -458,10 +551,18 @@ int main(int nargs, char* args[]) {
                     }
                     fn << std::endl;
                 }
-                uint64_t ns = 0, total = 0;
-                bamm_seqs_info(dseqs, &ns, &total, nullptr, nullptr);
+                // r of every kept sequence, shard after shard (the shards are consecutive ranges)
+                uint64_t total = 0;
+                for (uint32_t L : kept_len) total += L;
                 std::vector<float> r(total ? total : 1);
-                if (bamm_em_get_r(em, 0, ns, r.data(), total)) die_abi("getR");
+                uint64_t ro_base = 0;
+                for (size_t d = 0; d < ndev; d++) {
+                    if (!ems[d]) continue;
+                    uint64_t ns = 0, tl = 0;
+                    bamm_seqs_info(devs[d].shard, &ns, &tl, nullptr, nullptr);
+                    if (tl && bamm_em_get_r(ems[d], 0, ns, r.data() + ro_base, tl)) die_abi("getR");
+                    ro_base += tl;
+                }
                 std::ofstream fp(o.out_dir + '/' + mbase + ".positions");
                 fp << "seq\tlength\tstrand\tstart..end\tpattern" << std::endl;
                 static const char B[] = "NACGT";
@@ -487,7 +588,7 @@ int main(int nargs, char* args[]) {
                 }
             }
             std::cout << "optimized q = " << q << std::endl;   // mainBaMM.cpp:147
-            bamm_em_destroy(em);
+            for (bamm_em* e : ems) bamm_em_destroy(e);
         } else {
             std::cout << "Note: the model is not optimized!\n";
         }
@@ -498,8 +599,16 @@ int main(int nargs, char* args[]) {
             Motif sm = motif;
             if (!o.EM && o.seed_tag == "BaMM" && o.bg_file.empty()) die("No background Model file provided for initial search motif!");
             std::vector<float> neg_mops, neg_zoops, pos_mops, pos_zoops, pv, ev;
-            score_set(dneg, neg_len, sm, neg_mops, neg_zoops);
-            score_set(dseqs, kept_len, sm, pos_mops, pos_zoops);
+            std::vector<uint64_t> neg_z, pos_z;
+            if (score_set(devs[0].ctx, devs[0].neg, neg_len, sm, neg_mops, neg_zoops, nullptr, true, &neg_z)) die_abi("calcLogOdds");
+            if (score_set(devs[0].ctx, devs[0].full, kept_len, sm, pos_mops, pos_zoops, nullptr, true, &pos_z)) die_abi("calcLogOdds");
+            if (o.saveLogOdds) {                             // mainBaMM.cpp:204-208, :223-227
+                const std::vector<std::string> neg_headers(negN, "> bg_seq");                     // SeqGenerator.cpp:228
+                if (logodds_zoops_write(o.out_dir, o.basename + ".negSet", neg_headers, neg_codes.data(), neg_off.data(), negN, false,
+                                        o.ss, sm.W, neg_zoops.data(), neg_z.data(), err)) die(err);
+                if (logodds_zoops_write(o.out_dir, mbase, kept_headers, kept_codes.data(), kept_off.data(), kept_len.size(), !o.ss,
+                                        o.ss, sm.W, pos_zoops.data(), pos_z.data(), err)) die(err);
+            }
             mops_pvalues(pos_mops.data(), pos_mops.size(), neg_mops, kept_len.size(), pv, ev);
             if (occurrence_write(o.out_dir, mbase, kept_headers, kept_codes.data(), kept_off.data(), kept_len.size(), o.ss, sm.W,
                                  pv.data(), ev.data(), o.pvalCutoff, err)) die(err);
@@ -512,59 +621,82 @@ int main(int nargs, char* args[]) {
         const size_t cv = o.cvFold, P = kept_len.size();
         for (size_t n = 0; n < seeds.motifs.size(); n++) {
             const Motif& seed = seeds.motifs[n];
-            std::vector<float> posMax, negMax, posAll, negAll;
-            float updatedQ = seed.q;
-            for (size_t fold = 0; fold < cv; fold++) {
+            // Fold f trains and scores on GPU f mod N, on a host thread per GPU (the reference runs its folds on
+            // OpenMP threads, FDR.cpp:37); every fold keeps its scores to itself and they are merged in fold
+            // order afterwards, so the files do not depend on N or on which fold finishes first.
+            struct FoldOut { std::vector<float> posMax, negMax, posAll, negAll; float q = 0.f; std::string log, err; };
+            std::vector<FoldOut> folds(cv);
+            for (auto& f : folds) f.q = seed.q;
+#pragma omp parallel for num_threads((int)ndev) schedule(static, 1)
+            for (long fold_l = 0; fold_l < (long)cv; fold_l++) {
+                const size_t fold = (size_t)fold_l;
+                Dev& dv = devs[fold % ndev];                 // schedule(static, 1): thread t owns the folds t, t+N, ...
+                FoldOut& fo = folds[fold];
                 Motif m = seed;
                 std::vector<uint8_t> train(P, 0), test(P, 0);
                 for (size_t i = 0; i + cv <= P; i += cv)     // strided split; the last P mod cv records are unused
                     for (size_t f = 0; f < cv; f++) (f != fold ? train : test)[i + f] = 1;
                 if (o.EM) {
-                    bamm_em_params p;
-                    bamm_em_default_params(&p);
-                    p.K = m.K; p.W = m.W; p.bg_order = bg.K; p.q = m.q; p.optimize_q = o.optimizeQ;
-                    p.epsilon = o.epsilon; p.max_iterations = o.max_iter;
+                    bamm_em_params p = em_params(m);
                     bamm_em* em = nullptr;
-                    if (bamm_em_create(ctx, dseqs, &p, bg.v.data(), m.A.data(), m.v.data(), train.data(), &em)) die_abi("EM (fold)");
+                    if (bamm_em_create(dv.ctx, dv.full, &p, bg.v.data(), m.A.data(), m.v.data(), train.data(), &em)) { fo.err = bamm_last_error(); continue; }
                     uint32_t it = 0;
                     auto t0 = std::chrono::high_resolution_clock::now();
-                    if (!o.advanceEM) { if (bamm_em_optimize(em, &it)) die_abi("EM::optimize (fold)"); }   // FDR.cpp:67-72
-                    else if (bamm_em_mask(em, o.f, &it, nullptr, nullptr)) die_abi("EM::mask (fold)");
+                    int rc;
+                    if (!o.advanceEM) rc = bamm_em_optimize(em, &it);                              // FDR.cpp:67-72
+                    else rc = bamm_em_mask(em, o.f, &it, nullptr, nullptr);
+                    if (rc) { fo.err = bamm_last_error(); bamm_em_destroy(em); continue; }
                     bamm_em_get_v(em, m.v.data());
-                    bamm_em_get_q(em, &updatedQ);
+                    bamm_em_get_q(em, &fo.q);
                     bamm_em_destroy(em);
-                    std::cout << "\n--- Runtime for EM: " << std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() << " seconds ---\n";
+                    std::ostringstream os;
+                    os << "\n--- Runtime for EM: " << std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() << " seconds ---\n";
+                    fo.log = os.str();
                 }
                 std::vector<float> mops, zoops;
-                score_set(dseqs, kept_len, m, mops, zoops, test.data(), o.mops);
+                if (score_set(dv.ctx, dv.full, kept_len, m, mops, zoops, test.data(), o.mops)) { fo.err = bamm_last_error(); continue; }
                 size_t o_m = 0;
                 for (size_t i = 0; i < P; i++) {
                     const size_t nw = kept_len[i] - m.W + 1;
                     if (test[i]) {
-                        if (o.mops) posAll.insert(posAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
-                        if (o.zoops) posMax.push_back(zoops[i]);
+                        if (o.mops) fo.posAll.insert(fo.posAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
+                        if (o.zoops) fo.posMax.push_back(zoops[i]);
                     }
                     o_m += nw;
                 }
                 std::vector<uint8_t> neg_sel(negN ? negN : 1, 0);
                 for (size_t i = 0; i + cv <= negN; i += cv) neg_sel[i] = 1;
-                score_set(dneg, neg_len, m, mops, zoops, neg_sel.data(), o.mops);
+                if (score_set(dv.ctx, dv.neg, neg_len, m, mops, zoops, neg_sel.data(), o.mops)) { fo.err = bamm_last_error(); continue; }
                 o_m = 0;
                 for (size_t i = 0; i < negN; i++) {
                     const size_t nw = neg_len[i] - m.W + 1;
                     if (i % cv == 0 && i + cv <= negN) {       // negSet = every cv-th negative (FDR.cpp:58-60)
-                        if (o.mops) negAll.insert(negAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
-                        if (o.zoops) negMax.push_back(zoops[i]);
+                        if (o.mops) fo.negAll.insert(fo.negAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
+                        if (o.zoops) fo.negMax.push_back(zoops[i]);
                     }
                     o_m += nw;
                 }
             }
-            stage("--FDR: fold EMs + scoring");
+            std::vector<float> posMax, negMax, posAll, negAll;
+            float updatedQ = seed.q;
+            for (size_t fold = 0; fold < cv; fold++) {        // merge in fold order
+                FoldOut& fo = folds[fold];
+                if (!fo.err.empty()) die("Error: fold " + std::to_string(fold) + ": " + fo.err);
+                std::cout << fo.log;
+                posMax.insert(posMax.end(), fo.posMax.begin(), fo.posMax.end());
+                negMax.insert(negMax.end(), fo.negMax.begin(), fo.negMax.end());
+                posAll.insert(posAll.end(), fo.posAll.begin(), fo.posAll.end());
+                negAll.insert(negAll.end(), fo.negAll.begin(), fo.negAll.end());
+                if (o.EM) updatedQ = fo.q;                    // the reference keeps whichever fold wrote last (FDR.cpp:73): the last one here
+            }
+            stage("--FDR: fold EMs + scoring (GPU)");
+            const std::string fbase = o.basename + "_motif_" + std::to_string(n + 1);
+            if (o.saveLogOdds && fdr_logodds_write(o.out_dir, fbase, posMax, negMax, posAll, negAll, P, negN, o.mops, o.zoops,
+                                                   o.savePvalues, err)) die(err);
             FdrResult res;
             fdr_statistics(posMax, negMax, posAll, negAll, P, negN, updatedQ, o.mops, o.zoops, o.savePvalues, res);
-            if (fdr_write(o.out_dir, o.basename + "_motif_" + std::to_string(n + 1), res, P, negN, o.mops, o.zoops, o.savePRs,
-                          o.savePvalues, err)) die(err);
-            stage("--FDR: PR / p-value statistics + writers");
+            if (fdr_write(o.out_dir, fbase, res, P, negN, o.mops, o.zoops, o.savePRs, o.savePvalues, err)) die(err);
+            stage("--FDR: PR / p-value statistics + writers (host)");
         }
     }
 
@@ -581,9 +713,13 @@ int main(int nargs, char* args[]) {
     auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0_wall);
     std::cout << std::endl << "------ Runtime: " << dt.count() << " seconds -------" << std::endl;
 
-    if (dneg) bamm_seqs_destroy(dneg);
-    if (dseqs) bamm_seqs_destroy(dseqs);
-    if (ctx) bamm_ctx_destroy(ctx);
+    for (auto& dv : devs) {
+        if (dv.comm) bamm_comm_destroy(dv.comm);
+        if (dv.neg) bamm_seqs_destroy(dv.neg);
+        if (dv.shard && dv.shard != dv.full) bamm_seqs_destroy(dv.shard);
+        if (dv.full) bamm_seqs_destroy(dv.full);
+        if (dv.ctx) bamm_ctx_destroy(dv.ctx);
+    }
     bamm_packed_free(packed);
     return 0;
 }

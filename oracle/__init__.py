@@ -266,6 +266,7 @@ class Reference:
         R.ref_em_get_n.argtypes = [vp, _f32p]
         R.ref_em_write.argtypes = [vp, C.c_char_p, C.c_char_p, i]
         R.ref_logodds.argtypes = [vp, vp, vp, _f32p, _f32p, _u64p]
+        R.ref_write_logodds.argtypes = [vp, vp, vp, C.c_char_p, C.c_char_p, i]
         R.ref_negset_create.argtypes = [vp, u64, u64, i]
         R.ref_negset_create.restype = vp
         R.ref_session_size.argtypes = [vp]
@@ -370,9 +371,15 @@ class RefSession:
         h = self.R.ref_negset_create(self.h, s_order, m_fold, int(generic))
         return RefSession(self.ref, None, None, True, 0, False, handle=h)
 
+    def write_logodds(self, m, bg, ss, base="x"):
+        """ScoreSeqSet::writeLogOdds -> bytes of <base>.logOddsZoops"""
+        with tempfile.TemporaryDirectory() as d:
+            self.R.ref_write_logodds(m, bg, self.h, d.encode(), base.encode(), int(ss))
+            return open(os.path.join(d, base + ".logOddsZoops"), "rb").read()
+
     def fdr(self, neg, m, bg, cv_fold, mops, zoops, em=True, optimizeQ=False, frac=0.05, threads=1,
-            save_pvalues=True, base="x"):
-        f = self.R.ref_fdr_create(self.h, neg.h, m, bg, cv_fold, int(mops), int(zoops), 1, int(save_pvalues), 0)
+            save_pvalues=True, base="x", save_logodds=False):
+        f = self.R.ref_fdr_create(self.h, neg.h, m, bg, cv_fold, int(mops), int(zoops), 1, int(save_pvalues), int(save_logodds))
         self.R.ref_fdr_evaluate(f, int(em), int(optimizeQ), frac, threads)
         files = {}
         with tempfile.TemporaryDirectory() as d:

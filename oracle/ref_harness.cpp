@@ -225,6 +225,15 @@ void ref_logodds(void* m, void* bg, void* h, float* mops_out, float* zoops_out, 
     }
 }
 
+// ScoreSeqSet::writeLogOdds (ScoreSeqSet.cpp:293-331): <dir>/<base>.logOddsZoops
+void ref_write_logodds(void* m, void* bg, void* h, const char* dir, const char* base, int ss) {
+    Session* s = static_cast<Session*>(h);
+    ScoreSeqSet sc(static_cast<Motif*>(m), static_cast<BackgroundModel*>(bg), s->seqs);
+    sc.calcLogOdds();
+    std::string d(dir);
+    sc.writeLogOdds(&d[0], base, ss != 0);
+}
+
 // ---- negative set (SeqGenerator.cpp:3-42 ctor incl. srand(42), :188-204 sample_bgseqset_by_fold) ----
 void* ref_negset_create(void* h, uint64_t sOrder, uint64_t mFold, int genericNeg) {
     Session* s = static_cast<Session*>(h);

@@ -189,17 +189,33 @@ def run_config5_case(R):
     minSeqN, posN = 5000, c.N
     mfold = minSeqN // posN + (1 if minSeqN % posN else 0)     # mainBaMM.cpp:100-106 overrides -m 10
     neg = S.negset(2, mfold, False)
-    files, scores, q = S.fdr(neg, m, bg, 5, False, True, em=True, optimizeQ=False, threads=1, save_pvalues=True)
+    files, scores, q = S.fdr(neg, m, bg, 5, False, True, em=True, optimizeQ=False, threads=1, save_pvalues=True,
+                             save_logodds=True)
     out = dict(codes=c.codes, in_off=c.in_off, W=c.W, K=c.K, seed_ihbcp=np.frombuffer(seed_ihbcp, np.uint8), vbg=vbg,
                v_seed=S.motif_v(m), neg_n=neg.N, mfold=mfold, fdr_q=np.float32(q),
                zoops_stats=np.frombuffer(files["zoops.stats"], np.uint8),
                zoops_pvalues=np.frombuffer(files["zoops.pvalues"], np.uint8),
-               pos_max=scores[0], neg_max=scores[1])
+               pos_max=scores[0], neg_max=scores[1],
+               zoops_logodds=np.frombuffer(files["zoops.logOdds"], np.uint8))      # --saveLogOdds, FDR.cpp:416-433
+    # the same statistics with MOPS scores and without p-values (vectors left in descending order) on a subset
+    m2 = S.motif(c.W, c.K, c.alpha, bg, c.q, S.motif_v(m))
+    files2, scores2, _ = S.fdr(neg, m2, bg, 5, True, True, em=False, threads=1, save_pvalues=False, save_logodds=True)
+    out["noem_zoops_logodds"] = np.frombuffer(files2["zoops.logOdds"], np.uint8)
+    out["noem_mops_logodds_sha256"] = digest(np.frombuffer(files2["mops.logOdds"], np.uint8))
+    out["noem_mops_logodds_head"] = np.frombuffer(files2["mops.logOdds"][:4000], np.uint8)
+    out["noem_pos_max"], out["noem_neg_max"] = scores2[0], scores2[1]
+    out["noem_pos_all_sha256"], out["noem_neg_all_sha256"] = digest(scores2[2]), digest(scores2[3])
     # the full-set model of the same command line (mainBaMM.cpp:131-147 runs it before the folds)
     m_full = S.motif(c.W, c.K, c.alpha, bg, c.q, S.motif_v(m))
     e = S.em(m_full, bg, False, False)
     S.R.ref_em_optimize(e)
     out["v_full"] = S.motif_v(m_full)
+    # --saveLogOdds with --scoreSeqset (mainBaMM.cpp:204-227): ScoreSeqSet::writeLogOdds for both sets
+    out["pos_logoddszoops"] = np.frombuffer(S.write_logodds(m_full, bg, c.ss, base="p"), np.uint8)
+    out["neg_logoddszoops"] = np.frombuffer(neg.write_logodds(m_full, bg, c.ss, base="n"), np.uint8)
+    _, out["pos_zoops_full"], out["pos_z_full"] = S.logodds(m_full, bg, c.W)
+    _, out["neg_zoops_full"], out["neg_z_full"] = neg.logodds(m_full, bg, c.W)
+    out["neg_codes_sha256"] = digest(neg.seq_codes())        # the sampler itself is pinned by eval_small
     np.savez_compressed(os.path.join(HERE, "config5_small.npz"), **out)
     print("wrote config5_small", neg.N, len(files["zoops.stats"]))
 

@@ -156,3 +156,85 @@ def test_cli_advance_em_on_jund(oq, tmp_path, orc, gpu_ctx):
             L = int(o[n + 1] - o[n])
             n_hits += int((res["r"][int(o[n]):int(o[n]) + L - W + 1] >= 0.3).sum())
         assert abs((len(pos) - 1) - n_hits) <= 3
+
+
+def _write_config5_inputs(tmp_path, g):
+    codes, off = g["codes"], g["in_off"]
+    lut = np.frombuffer(b"NACGT", np.uint8)
+    with open(tmp_path / "pos.fasta", "wb") as f:
+        for n in range(len(off) - 1):
+            f.write(b">seq%d\n" % n)
+            f.write(lut[codes[int(off[n]):int(off[n + 1])]].tobytes() + b"\n")
+    open(tmp_path / "seed.ihbcp", "wb").write(g["seed_ihbcp"].tobytes())
+    return str(tmp_path / "pos.fasta"), str(tmp_path / "seed.ihbcp")
+
+
+CONFIG5_FLAGS = ["--EM", "-k", "2", "--FDR", "-n", "5", "-m", "10", "--savePvalues", "--saveLogOdds"]
+
+
+def test_cli_config5_fdr_line(tmp_path, gpu_ctx):
+    """BASELINE config 5's command line, `--EM -k 2 --FDR -n 5 -m 10`, on the reduced set of
+    tests/golden/config5_small.npz (600 x 200 bp, both strands, W = 20): 1 full EM + 5 fold EMs + scoring of
+    the test folds and of the sampled negatives, against what the reference's EM / FDR / ScoreSeqSet /
+    SeqGenerator produced for the same inputs (FDR.cpp:28-145, mainBaMM.cpp:97-116,243-265)."""
+    from tests import golden_util as gu
+    build.build_host()
+    g = dict(np.load(os.path.join(gu.GOLDEN_DIR, "config5_small.npz")))
+    fasta, seed = _write_config5_inputs(tmp_path, g)
+    out = tmp_path / "o"
+    r = subprocess.run([build.CLI, str(out), fasta, "--BaMMFile", seed] + CONFIG5_FLAGS, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    assert r.stdout.count("--- Runtime for EM:") == 6                    # 1 full run + 5 folds
+    assert "Folds for cross-validation (FDR estimation): 5" in r.stdout
+    K, W = 2, 20
+    np.testing.assert_allclose(parse_ihbcp(out / "pos_motif_1.ihbcp", K, W), g["v_full"], rtol=2e-3, atol=1e-6)   # %.3e files
+
+    def rows(b):
+        lines = b.decode().strip().split("\n")
+        return lines[0], [l.rstrip("\t").split("\t") for l in lines[1:]]
+
+    h_ref, ref = rows(g["zoops_stats"].tobytes())
+    h_mine, mine = rows(open(out / "pos_motif_1.zoops.stats", "rb").read())
+    assert h_mine.split("\t")[:6] == h_ref.split("\t")[:6]               # TP FP FDR Recall p-value mFold (= 9, mainBaMM.cpp:100-106)
+    assert float(h_mine.split("\t")[5]) == int(g["mfold"]) == 9
+    assert float(h_mine.split("\t")[6]) == pytest.approx(float(h_ref.split("\t")[6]), abs=5e-3)   # occ_frac
+    assert len(mine) == len(ref) == 600 + int(g["neg_n"])
+    a, b = np.array(mine, float), np.array(ref, float)
+    assert np.mean(np.all(a[:, :2] == b[:, :2], axis=1)) > 0.98          # TP/FP along the ranking: near-ties may swap
+    np.testing.assert_allclose(a[:, 4], b[:, 4], rtol=0.05, atol=2e-4)   # p-values along the ranking
+    pv_ref = np.array(g["zoops_pvalues"].tobytes().decode().split(), float)
+    pv = np.array(open(out / "pos_motif_1.zoops.pvalues").read().split(), float)
+    assert len(pv) == len(pv_ref) == 600
+    np.testing.assert_allclose(pv, pv_ref, rtol=0.02, atol=2e-4)
+    lo_ref = np.array([l.split("\t") for l in g["zoops_logodds"].tobytes().decode().strip().split("\n")[1:]], float)
+    lo = np.array([l.split("\t") for l in open(out / "pos_motif_1.zoops.logOdds").read().strip().split("\n")[1:]], float)
+    assert lo.shape == lo_ref.shape == (600, 2)
+    np.testing.assert_allclose(lo, lo_ref, rtol=2e-4, atol=2e-4)         # scores of models that agree to ~1e-5
+
+
+def test_cli_fold_replicas_and_native_comm_do_not_change_the_files(tmp_path, gpu_ctx):
+    """--gpus N: fold f trains on GPU f mod N on a host thread of its own, scores are merged in fold order
+    (FDR.cpp:37-127).  A 1-GPU box runs the thread-per-fold path with two (three) contexts on device 0; every
+    output file must equal the single-context run byte for byte.  --forceComm runs the sharded-EM code path
+    (handle per GPU + RCCL all-reduce inside libbamm_em) with a 1-rank communicator: same bytes again."""
+    from tests import golden_util as gu
+    build.build_host()
+    g = dict(np.load(os.path.join(gu.GOLDEN_DIR, "config5_small.npz")))
+    fasta, seed = _write_config5_inputs(tmp_path, g)
+    flags = CONFIG5_FLAGS + ["--scoreSeqset", "--saveBaMMs"]
+    outs = {}
+    for tag, extra in (("one", []), ("gpus1", ["--gpus", "1"]), ("two", ["--deviceList", "0,0"]),
+                       ("three", ["--deviceList", "0,0,0"]), ("comm", ["--forceComm"])):
+        out = tmp_path / tag
+        r = subprocess.run([build.CLI, str(out), fasta, "--BaMMFile", seed] + flags + extra, capture_output=True, text=True)
+        assert r.returncode == 0, tag + ": " + r.stderr + r.stdout[-2000:]
+        assert r.stdout.count("--- Runtime for EM:") == 6
+        outs[tag] = {f: open(out / f, "rb").read() for f in sorted(os.listdir(out))}
+    names = sorted(outs["one"])
+    assert {"pos_motif_1.zoops.stats", "pos_motif_1.zoops.pvalues", "pos_motif_1.zoops.logOdds", "pos_motif_1.ihbcp",
+            "pos_motif_1.occurrence", "pos_motif_1.logOddsZoops", "pos.negSet.logOddsZoops", "pos_motif_1.positions",
+            "pos_motif_1.counts"} <= set(names)
+    for tag in ("gpus1", "two", "three", "comm"):
+        assert sorted(outs[tag]) == names, tag
+        for f in names:
+            assert outs[tag][f] == outs["one"][f], f"{tag}: {f} differs"

@@ -120,3 +120,52 @@ def test_fdr_statistics_with_uneven_fold_split(host, tmp_path):
     assert np.all((rows[:, 4] >= 0) & (rows[:, 4] <= 1.0 + 1e-6))
     pv = np.array([float(x) for x in open(tmp_path / "u.zoops.pvalues").read().split()])
     assert len(pv) == len(pos) and np.all((pv > 0) & (pv <= 1))
+
+
+@pytest.fixture(scope="module")
+def g5():
+    return dict(np.load(os.path.join(gu.GOLDEN_DIR, "config5_small.npz")))
+
+
+def test_save_logodds_fdr_files_match_reference(host, g5, tmp_path):
+    """--saveLogOdds, FDR::write (FDR.cpp:416-450): score i of the positives beside score i*negN/posN of the
+    negatives, in the order the statistics left the vectors (ascending once calculatePvalues has run,
+    descending after calculatePR alone)."""
+    posN, negN = 600, int(g5["neg_n"])
+    rc = host.bh_fdr_logodds(fp(g5["pos_max"]), C.c_uint64(len(g5["pos_max"])), fp(g5["neg_max"]), C.c_uint64(len(g5["neg_max"])),
+                             fp(g5["pos_max"]), C.c_uint64(0), fp(g5["neg_max"]), C.c_uint64(0), C.c_uint64(posN), C.c_uint64(negN),
+                             0, 1, 1, str(tmp_path).encode(), b"a")
+    assert rc == 0, host.bh_last_error()
+    assert open(tmp_path / "a.zoops.logOdds", "rb").read() == g5["zoops_logodds"].tobytes()
+    rc = host.bh_fdr_logodds(fp(g5["noem_pos_max"]), C.c_uint64(len(g5["noem_pos_max"])), fp(g5["noem_neg_max"]),
+                             C.c_uint64(len(g5["noem_neg_max"])), fp(g5["noem_pos_max"]), C.c_uint64(0), fp(g5["noem_neg_max"]),
+                             C.c_uint64(0), C.c_uint64(posN), C.c_uint64(negN), 0, 1, 0, str(tmp_path).encode(), b"d")
+    assert rc == 0, host.bh_last_error()
+    assert open(tmp_path / "d.zoops.logOdds", "rb").read() == g5["noem_zoops_logodds"].tobytes()
+
+
+def test_save_logodds_zoops_listing_matches_reference(host, g5, tmp_path):
+    """--saveLogOdds with --scoreSeqset, ScoreSeqSet::writeLogOdds (ScoreSeqSet.cpp:293-331): the best window of
+    every positive (both strands stored) and of every sampled negative (single strand, header '> bg_seq')."""
+    codes = np.ascontiguousarray(g5["codes"], np.uint8)
+    off = np.ascontiguousarray(g5["in_off"], np.uint64)
+    W = int(g5["W"])
+    z = np.ascontiguousarray(g5["pos_z_full"], np.uint64)
+    assert host.bh_logodds_zoops(str(tmp_path).encode(), b"p", b"seq", 1, codes.ctypes.data_as(C.c_void_p),
+                                 off.ctypes.data_as(C.c_void_p), C.c_uint64(600), 1, 0, W, fp(g5["pos_zoops_full"]),
+                                 z.ctypes.data_as(C.c_void_p)) == 0, host.bh_last_error()
+    assert open(tmp_path / "p.logOddsZoops", "rb").read() == g5["pos_logoddszoops"].tobytes()
+    # the negatives: sampled by the product's own sampler (pinned against the reference above)
+    packed = bm.PackedSeqs.from_codes(codes, off, False, seed=42)
+    n, m = C.c_uint64(), C.c_uint64()
+    mfold = int(g5["mfold"])
+    assert host.bh_sample_negatives(packed._p, 2, C.c_uint64(mfold), 0, C.byref(n), C.byref(m), None, None) == 0
+    ncodes, noff = np.zeros(m.value, np.uint8), np.zeros(n.value + 1, np.uint64)
+    assert host.bh_sample_negatives(packed._p, 2, C.c_uint64(mfold), 0, C.byref(n), C.byref(m), ncodes.ctypes.data_as(C.c_void_p),
+                                    noff.ctypes.data_as(C.c_void_p)) == 0
+    assert gu.digest(ncodes) == str(g5["neg_codes_sha256"])
+    nz = np.ascontiguousarray(g5["neg_z_full"], np.uint64)
+    assert host.bh_logodds_zoops(str(tmp_path).encode(), b"n", b"> bg_seq", 0, ncodes.ctypes.data_as(C.c_void_p),
+                                 noff.ctypes.data_as(C.c_void_p), C.c_uint64(n.value), 0, 0, W, fp(g5["neg_zoops_full"]),
+                                 nz.ctypes.data_as(C.c_void_p)) == 0, host.bh_last_error()
+    assert open(tmp_path / "n.logOddsZoops", "rb").read() == g5["neg_logoddszoops"].tobytes()

@@ -1,13 +1,24 @@
 #!/usr/bin/env python3
-"""BASELINE config 5 through the drop-in CLI: 200k x 200 bp, -k 2, --FDR -n 5 -m 10 (5-fold CV,
-10x sampled negatives).  Writes a FASTA + MEME seed, runs BaMMmotif, prints wall times (per stage
-with --timing).  `config5_run.py N OUT em` runs the plain --EM line instead (config 3 at N=1M)."""
-import os, subprocess, sys, time
+"""BASELINE config 5 through the drop-in CLI: 200k x 200 bp, -k 2, --FDR -n 5 -m 10 (5-fold CV, 10x
+sampled negatives).  Writes a FASTA + MEME seed, runs BaMMmotif with --timing and prints the wall time per
+stage: the GPU part (full EM, fold EMs + scoring) apart from the host work the reference also does (FASTA,
+rand()-driven negative sampler, sorting / statistics / writers).
+
+    config5_run.py [N] [OUT] [em] [--gpus G | --deviceList a,b,..]
+
+`em` runs the plain --EM line instead (config 3 at N = 1M)."""
+import os, re, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bammmotif2_amd import synth, build
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-out = sys.argv[2] if len(sys.argv) > 2 else "/tmp/c5"
+argv = sys.argv[1:]
+extra_dev = []
+for flag in ("--gpus", "--deviceList"):
+    if flag in argv:
+        i = argv.index(flag); extra_dev += argv[i:i + 2]; del argv[i:i + 2]
+N = int(argv[0]) if len(argv) > 0 else 200000
+out = argv[1] if len(argv) > 1 else "/tmp/c5"
+em_only = len(argv) > 2 and argv[2] == "em"
 os.makedirs(out, exist_ok=True)
 W = 20
 pwm = synth.make_pwm(W, 1234)
@@ -26,14 +37,20 @@ with open(os.path.join(out, "seed.meme"), "w") as f:
 print("inputs written in %.1f s" % (time.time() - t))
 build.build_host()
 t = time.time()
-em_only = len(sys.argv) > 3 and sys.argv[3] == "em"
 extra = [] if em_only else ["--FDR", "-n", "5", "-m", "10"]
 r = subprocess.run([build.CLI, os.path.join(out, "res"), os.path.join(out, "pos.fasta"), "--PWMFile", os.path.join(out, "seed.meme"),
-                    "--EM", "-k", "2", "--maxEMIterations", "60", "--timing"] + extra, capture_output=True, text=True)
+                    "--EM", "-k", "2", "--maxEMIterations", "60", "--timing"] + extra + extra_dev, capture_output=True, text=True)
 dt = time.time() - t
-print("BaMMmotif exit", r.returncode, "wall %.1f s" % dt)
+print("BaMMmotif", " ".join(extra + extra_dev), "exit", r.returncode, "wall %.2f s" % dt)
+stages = re.findall(r"\[timing\] (.*): ([\d.e+-]+) s", r.stderr)
+gpu = sum(float(s) for n, s in stages if "EM" in n or "GPU" in n)
+print("  stage                                                          seconds")
+for n, s in stages:
+    print("  %-62s %8.3f" % (n, float(s)))
+print("  GPU stages (EM runs, fold EMs + scoring) %.3f s of %.3f s in all; the rest is host work" % (gpu, sum(float(s) for _, s in stages)))
 print("\n".join(l for l in r.stdout.splitlines() if "Runtime" in l))
-print(r.stderr[-2500:])
+if r.returncode:
+    print(r.stderr[-2500:])
 print(sorted(os.listdir(os.path.join(out, "res"))))
 if not em_only:
     print(open(os.path.join(out, "res", "pos_motif_1.zoops.stats")).read()[:300])
