@@ -32,6 +32,9 @@ def build(ref: bool = True) -> None:
     subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
     if ref and os.path.isdir("/root/reference/src"):
         subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+        pkg_lib = os.path.join(os.path.dirname(HERE), "bammmotif2_amd", "libbamm_em.so")
+        if os.path.exists(pkg_lib):                       # the reference's classes over libbamm_em (integration/)
+            subprocess.check_call(["make", "-s", "-C", HERE, "ref_hip"])
 
 
 def have_reference() -> bool:

@@ -157,3 +157,25 @@ def test_argument_errors_do_not_crash(lib):
     lib.bamm_em_default_params(C.byref(prm))
     assert (prm.K, prm.bg_order, prm.max_iterations) == (2, 2, 1000) and abs(prm.q - 0.3) < 1e-7 and abs(prm.epsilon - 0.01) < 1e-9
     assert lib.bamm_v_size(2, 20) == 1680 and lib.bamm_v_offset(2, 20) == 400 and lib.bamm_bg_size(2) == 84
+
+
+def test_integration_sources_compile_against_the_headers(tmp_path):
+    """integration/ is code, not prose: the multi-GPU caller (sharded_em.cpp) compiles against include/bamm_em.h
+    and links with libbamm_em.so; EM_hip.cpp / ScoreSeqSet_hip.cpp compile against the reference's UNCHANGED
+    EM.h / ScoreSeqSet.h where that tree is present (development container; `make -C oracle ref_hip` builds the
+    library tests/test_integration_gpu.py runs on the GPU box)."""
+    import shutil, subprocess
+    from bammmotif2_amd import build
+    build.build_library()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = shutil.which("g++") or "g++"
+    obj = tmp_path / "sharded_em.o"
+    subprocess.check_call([cxx, "-std=c++17", "-fopenmp", "-Wall", "-Werror", "-fPIC", "-I", os.path.join(root, "include"), "-c",
+                           os.path.join(root, "integration", "sharded_em.cpp"), "-o", str(obj)])
+    subprocess.check_call([cxx, "-shared", "-fopenmp", str(obj), "-L", os.path.dirname(build.LIB), "-lbamm_em",
+                           "-Wl,--no-undefined", "-o", str(tmp_path / "libsharded.so")])
+    ref = "/root/reference/src"
+    if os.path.isdir(ref):
+        for f in ("EM_hip.cpp", "ScoreSeqSet_hip.cpp"):
+            subprocess.check_call([cxx, "-std=c++11", "-fopenmp", "-w", "-fPIC", "-I", ref, "-I", os.path.join(root, "include"),
+                                   "-c", os.path.join(root, "integration", f), "-o", str(tmp_path / (f + ".o"))])
