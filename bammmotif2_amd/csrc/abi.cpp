@@ -73,7 +73,7 @@ struct bamm_ctx {
     bool own_stream = false;
     uint32_t blocks = 0, threads = 0;   // 0 = default
     // bamm_ctx_set_tuning: kernel-selection switches for benchmarks and the cross-kernel parity tests
-    bool use_grouped = true, use_sparse = true, use_e_fused = true;
+    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true;
     uint32_t group_size = 0;            // 0 = planner's choice
     int group_layout = -1;              // -1 = planner's choice
     int num_cus = 0;
@@ -147,7 +147,11 @@ struct bamm_em {
     uint32_t m_slice_logc = 0;
     bool e_fused = false;                       // the E pass of the sliced path is k_em_seq (whole odds table in LDS)
     uint32_t m_slice_cap = 0;                   // sparse list capacity per wave in the M-slices (0 = dense)
-    float* d_state = nullptr;                   // one float per position slot: E-chain state, then r
+    float* d_state = nullptr;                   // one float per position slot: E-chain state, then r (allocated on first use)
+    // e_fused: the E pass hands the M slices compacted lists of the non-zero windows instead of dense r
+    float* d_list_r = nullptr;
+    uint16_t* d_list_p = nullptr;
+    uint32_t* d_list_n = nullptr;
     ExcK* exc = nullptr;
     bool estep_done = false;
     float llh_prev = 0.0f;                      // EM.h:61
@@ -349,7 +353,7 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
 }
 
 // local E(+M) pass over every length bucket, then the deterministic partial reduction
-int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
+int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense_r = false) {
     bamm_seqs* s = em->seqs;
     hipStream_t st = em->ctx->stream;
     int rc = use_device(em->ctx);
@@ -374,13 +378,30 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
         if (!em->sliced) {
             rc = launch_fused(em, bk, accum, false, a, threads, st);
         } else {
+            uint32_t widest = 0;
+            for (auto& sl : em->m_slices) widest = std::max(widest, sl.second - sl.first);
+            // compacted lists instead of dense r between the E pass and the M slices: when the whole odds table is
+            // in LDS (the E pass is k_em_seq) and a wave's copy of the decoded sequence fits beside the count slice
+            const bool lists = em->e_fused && em->d_list_r && !dense_r &&
+                               m_list_lds_bytes(widest, em->Y, em->m_slice_logc, kMClasses[bk.mclass], threads / 64u) <= 160u * 1024u;
+            if (!lists && !em->d_state) {
+                if ((rc = dev_alloc(&em->d_state, (size_t)s->total_len))) return rc;
+            }
             a.r_out = em->d_state;
             if (em->e_fused) {
                 // the whole odds table fits LDS (only the count table does not): the fused kernel's E
-                // pass, leaving r in the reference's layout (k_em_seq WRITE_R)
+                // pass, leaving r in the reference's layout (k_em_seq WRITE_R) or the lists
                 a.seq_end = (uint32_t)s->n;
                 a.logC = 0; a.sparse_cap = 0; a.sparse_wave_bytes = 0;
+                if (lists) { a.list_r = em->d_list_r; a.list_p = em->d_list_p; a.list_n = em->d_list_n; }
                 rc = launch_em_seq(bk.mclass, false, true, a, bk.blocks, threads, st);
+                if (lists) {
+                    a.logC = em->m_slice_logc;
+                    for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
+                        rc = launch_m_list(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second, bk.blocks, threads, st);
+                    if (rc) return rc;
+                    continue;
+                }
             } else {
                 for (size_t i = 0; i < em->e_slices.size() && !rc; i++)
                     rc = launch_e_slice(bk.mclass, a, em->e_slices[i].first, em->e_slices[i].second,
@@ -389,8 +410,6 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false) {
             a.logC = em->m_slice_logc;
             const uint32_t mthreads = threads;
             {   // this bucket's list capacity: what fits next to the widest slice's count table
-                uint32_t widest = 0;
-                for (auto& sl : em->m_slices) widest = std::max(widest, sl.second - sl.first);
                 const size_t table = m_slice_lds_bytes(widest, em->Y, em->m_slice_logc);
                 uint32_t cap = em->m_slice_cap;
                 while (cap && table + (mthreads / 64u) * m_slice_wave_bytes(kMClasses[bk.mclass], cap) > 160u * 1024u) cap -= 64u;
@@ -549,6 +568,7 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
     if (k == "grouped") c->use_grouped = value != 0;
     else if (k == "sparse") c->use_sparse = value != 0;
     else if (k == "e_fused") c->use_e_fused = value != 0;
+    else if (k == "e_list") c->use_e_list = value != 0;
     else if (k == "group_size") {
         if (value != 0 && (value < 2 || value > 4)) { set_error("group_size must be 0 (auto) or 2..4"); return BAMM_ERR_ARG; }
         c->group_size = (uint32_t)value;
@@ -662,7 +682,7 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->acc_external ? nullptr : em->d_acc),
-                    (void*)em->d_state, (void*)em->d_s_alt,
+                    (void*)em->d_state, (void*)em->d_list_r, (void*)em->d_list_p, (void*)em->d_list_n, (void*)em->d_s_alt,
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
                     (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})
@@ -869,7 +889,11 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         b.blocks = nb;
         em->total_blocks += nb;
     }
-    if (sliced && (rc = dev_alloc(&em->d_state, (size_t)seqs->total_len))) return fail(rc);
+    if (sliced && em->e_fused && c->use_e_list) {
+        if ((rc = dev_alloc(&em->d_list_r, (size_t)seqs->total_len)) || (rc = dev_alloc(&em->d_list_p, (size_t)seqs->total_len)) ||
+            (rc = dev_alloc(&em->d_list_n, (size_t)seqs->n))) return fail(rc);
+        if (hipMemsetAsync(em->d_list_n, 0, (seqs->n ? seqs->n : 1) * sizeof(uint32_t), st) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(BAMM_ERR_HIP); }
+    }
     if ((rc = launch_make_s(em->d_v, em->d_vbg, prm->K, prm->W, em->Kbg, em->d_s, st))) return fail(rc);
     em->s_last = em->d_s;
     em->q_last = em->d_q;
@@ -1210,7 +1234,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         uint8_t* saved_mask = em->d_mask;
         em->d_mask = nullptr;                              // masked-out sequences still have an r
         const uint32_t used = em->events_used, pass_no = em->pass_no;
-        int rc2 = run_accumulate(em, false, true);
+        int rc2 = run_accumulate(em, false, true, true);       // dense r, in the reference's layout
         em->events_used = used; em->pass_no = pass_no;
         em->d_mask = saved_mask;
         if (rc2) return rc2;

@@ -83,6 +83,11 @@ struct EmKernelArgs {
     float*   r_out;              // WRITE_R: reference layout, r_base subtracted; sliced path: slot-indexed state / r
     uint64_t r_base;             // pos_off of the first requested sequence
     uint32_t seq_begin, seq_end; // WRITE_R range filter (sequence ids)
+    // column-sliced path with the whole odds table in LDS: the E pass leaves, per sequence, the compacted list of
+    // its windows with a non-zero fixed-point addend instead of all L responsibilities (list_r != nullptr)
+    float*    list_r;            // [pos_off[seq] + k] responsibility of the k-th listed window
+    uint16_t* list_p;            // [pos_off[seq] + k] its slot: the position of the window's last column
+    uint32_t* list_n;            // [seq] listed windows
 };
 
 // ---- grouped-column kernel (grouped.hip): G motif columns (K+G = 4 or 5) share one table row ------
@@ -219,6 +224,8 @@ int launch_e_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
 size_t m_slice_wave_bytes(int M, uint32_t cap);
 int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, bool r_reversed, uint32_t blocks,
                    uint32_t threads, hipStream_t st);
+int launch_m_list(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads, hipStream_t st);
+size_t m_list_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC, int M, uint32_t waves);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
                  hipStream_t st);
 // EM::mask only: its kernels still leave one partial table per block; summed into the fused accumulator

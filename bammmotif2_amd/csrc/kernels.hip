@@ -216,7 +216,25 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
         seq_cnt++;
 
-        if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
+        if (WRITE_R && a.list_r != nullptr) {
+            // sliced path: only the windows whose fixed-point addend is non-zero (r * scale >= 2^-40, the very
+            // test the M-step applies) are worth a trip through HBM: once the model is informative that is
+            // a quarter of them.  Per sequence: responsibilities and slots, compacted in lane order.
+            const uint64_t base = a.sv.pos_off[seq];
+            uint32_t nnz = 0;
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const bool nzm = U[m] * a.fix_scale >= 0x1p-40f;
+                const unsigned long long mask = __ballot(nzm);
+                const uint32_t at = nnz + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (nzm) {
+                    a.list_r[base + at] = U[m];
+                    a.list_p[base + at] = (uint16_t)(p0 + (uint32_t)m);
+                }
+                nnz += (uint32_t)__popcll(mask);
+            }
+            if (lane == 0) a.list_n[seq] = nnz;
+        } else if (WRITE_R) {                            // EM::getR layout: r[L-W-i], i = p-W+1
             float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
             bool done = false;
             if constexpr (M % 4 == 0) {
@@ -528,6 +546,73 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
             const uint32_t stride = (Ys << logC) * 8u;
             dense_count_walk<M>(nc, lds_offset(n_lds) + (nc - 1u) * stride, stride, ya, F, nz, padm, y, Y);
         }
+    }
+    lds_drain();
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nc * Y; i += blockDim.x) {          // i = y*nc + j: runs of nc consecutive cells
+        const uint32_t yy = i / nc, j = i - yy * nc;
+        unsigned long long acc = 0ull;
+        for (uint32_t c = 0; c < (1u << logC); c++) acc += n_lds[(((size_t)j * Ys + yy) << logC) + c];
+        if (acc) acc_add(a.acc + (size_t)yy * W + j0 + j, (long long)acc);
+    }
+}
+
+// ---- M-slice over the E pass's compacted lists (sliced path, whole odds table in LDS) -----------------
+// Every lane takes listed windows of the wave's sequence and walks the slice's columns: y from a per-wave
+// copy of the decoded sequence, one ds_add_u64 per (window, column).  The same integer addends as the dense
+// walk of k_m_slice, so the counts are bit-identical; nothing is compacted or converted here any more.
+template <int M, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0, uint32_t j1) {
+    extern __shared__ float lds[];
+    const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;
+    unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y+1][C], row Y = dump
+    for (uint32_t i = threadIdx.x; i < (nc * Ys) << logC; i += blockDim.x) n_lds[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
+    unsigned short* ybuf = reinterpret_cast<unsigned short*>(n_lds + ((size_t)(nc * Ys) << logC)) + (size_t)wave * (64u * M + 8u);
+    const uint32_t cstride = Ys << logC;
+    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
+        const uint32_t seq = pick_sequence(a.sv, t);
+        if (a.sv.mask && !a.sv.mask[seq]) continue;
+        const uint32_t nnz = a.list_n[seq];
+        if (nnz == 0u) continue;
+        const uint32_t L = a.sv.len[seq];
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+        const uint64_t base = a.sv.pos_off[seq];
+        // the first entries are on their way while the sequence is decoded
+        const uint32_t e0 = (uint32_t)lane;
+        float r_nxt = e0 < nnz ? a.list_r[base + e0] : 0.0f;
+        uint32_t p_nxt = e0 < nnz ? (uint32_t)a.list_p[base + e0] : 0u;
+        uint32_t y[M];
+        decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);          // EM.cpp:236: positions >= LW1 take no part (row Y)
+#pragma unroll
+        for (int m = 0; m < M; m++) ybuf[p0 + m] = (unsigned short)y[m];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t e = e0; e < nnz; e += 64u) {
+            const float r = r_nxt;
+            const uint32_t p = p_nxt;
+            if (e + 64u < nnz) { r_nxt = a.list_r[base + e + 64u]; p_nxt = (uint32_t)a.list_p[base + e + 64u]; }
+            const unsigned long long Fe = to_fixed40(r * a.fix_scale);
+            uint32_t q = p + 1u - W + j0;                             // position of the window's column j0
+            unsigned long long* ncol = n_lds + copy;
+            // eight columns' y first, then their adds: one LDS round trip per batch (row Y is a dump: no check)
+            for (uint32_t jb = j0; jb < j1; jb += 8u, q += 8u, ncol += 8u * cstride) {
+                uint32_t yy[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) yy[u] = (jb + u < j1) ? (uint32_t)ybuf[q + u] : Y;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (jb + u < j1) atomicAdd(&ncol[(size_t)u * cstride + (yy[u] << logC)], Fe);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                              // ybuf is rewritten for the next sequence
     }
     lds_drain();
     __syncthreads();
@@ -881,6 +966,27 @@ int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
     case idx:                                                                                          \
         if (int rc = allow_lds(reinterpret_cast<const void*>(&k_m_slice<M, T>), lds)) return rc;                 \
         hipLaunchKernelGGL((k_m_slice<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1, r_reversed ? 1 : 0); \
+        break;
+        BAMM_FOR_EACH_MCLASS(X)
+#undef X
+        default: set_error("no kernel for M class %d", mclass); return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipGetLastError());
+    return BAMM_OK;
+}
+
+size_t m_list_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC, int M, uint32_t waves) {
+    return m_slice_lds_bytes(cols, Y, logC) + (size_t)waves * (64u * (size_t)M + 8u) * 2u;
+}
+
+int launch_m_list(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads, hipStream_t st) {
+    const size_t lds = m_list_lds_bytes(j1 - j0, a.Y, a.logC, kMClasses[mclass], threads / 64u);
+    if (lds > 160 * 1024 || j1 <= j0) { set_error("bad list M slice [%u,%u)", j0, j1); return BAMM_ERR_UNSUPPORTED; }
+    switch (mclass) {
+#define X(idx, M, T)                                                                                   \
+    case idx:                                                                                          \
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_m_list<M, T>), lds)) return rc;        \
+        hipLaunchKernelGGL((k_m_list<M, T>), dim3(blocks), dim3(threads), lds, st, a, j0, j1);         \
         break;
         BAMM_FOR_EACH_MCLASS(X)
 #undef X

@@ -50,8 +50,10 @@ struct SeedDevice {
 // Motif::initFromPWM (Motif.cpp:192-333): pwm[y][j] (4 x W); yK = kmer_ mod 4^(K+1) per position (host
 // path; may be null with `dev`).  With `dev` the posteriors, the sampling and the counts run through
 // bamm_seed_from_pwm; the std::mt19937 draws stay here, in sequence order.  Returns 0, or 1 + err.
+// z_out (optional): the sampled site per sequence, 0 = no motif, i = window i-1
 int motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
-                        const uint64_t* off, size_t n_seqs, float q, const SeedDevice* dev, std::string& err);
+                        const uint64_t* off, size_t n_seqs, float q, const SeedDevice* dev, std::string& err,
+                        std::vector<uint32_t>* z_out = nullptr);
 int motif_init_from_bamm(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,
                          std::string& err);                                                     // Motif.cpp:336-397
 int motif_init_from_sites(Motif& m, const std::string& path, uint32_t l_flank, uint32_t r_flank, const BgModel& bg,

@@ -83,6 +83,28 @@ static int load_seed_impl(const char* path, const char* tag, uint32_t l_flank, u
     return 0;
 }
 
+// Motif::initFromPWM on a caller-provided PWM ([4][W]): the model and the sampled site of every sequence, through
+// the host path (std::mt19937 + std::discrete_distribution) or, with ctx/seqs, the device path
+int bh_pwm_sites(const float* pwm, uint32_t W, uint32_t K, const float* alpha, uint32_t bg_order, const float* vbg,
+                 const bamm_packed* packed, float q, float* v_out, uint32_t* z_out, bamm_ctx* ctx, bamm_seqs* seqs) {
+    BgModel bg;
+    bg.K = bg_order;
+    bg.v.assign(vbg, vbg + bamm_bg_size(bg_order));
+    Motif m;
+    motif_alloc(m, W, K, std::vector<float>(alpha, alpha + K + 1), q);
+    std::vector<uint64_t> off(packed->n_seqs + 1, 0);
+    for (uint64_t n = 0; n < packed->n_seqs; n++) off[n + 1] = off[n] + packed->len[n];
+    std::vector<uint32_t> yK(packed->total_len ? packed->total_len : 1), z;
+    if (bamm_unpack_y(packed, K, yK.data())) { g_err = bamm_last_error(); return 1; }
+    SeedDevice dev;
+    dev.ctx = ctx; dev.seqs = seqs;
+    if (motif_init_from_pwm(m, std::vector<float>(pwm, pwm + 4 * (size_t)W), bg, yK.data(), off.data(), packed->n_seqs, q,
+                            ctx ? &dev : nullptr, g_err, &z)) return 1;
+    memcpy(v_out, m.v.data(), m.v.size() * sizeof(float));
+    memcpy(z_out, z.data(), z.size() * sizeof(uint32_t));
+    return 0;
+}
+
 int bh_load_seed(const char* path, const char* tag, uint32_t l_flank, uint32_t r_flank, uint32_t K, const float* alpha,
                  uint64_t max_pwm, float glob_q, uint32_t bg_order, const float* vbg, const bamm_packed* packed,
                  uint32_t index, uint32_t* n_motifs, uint32_t* w_out, float* q_out, float* v_out, uint64_t v_cap) {

@@ -235,7 +235,9 @@ static void orders_from_counts(Motif& m, const std::vector<int>& n, bool order0_
 }
 
 int motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& bg, const uint32_t* yK,
-                        const uint64_t* off, size_t n_seqs, float q, const SeedDevice* dev, std::string& err) {
+                        const uint64_t* off, size_t n_seqs, float q, const SeedDevice* dev, std::string& err,
+                        std::vector<uint32_t>* z_out) {
+    if (z_out) z_out->assign(n_seqs, 0);
     const uint32_t W = m.W, K = m.K;
     m.q = q;
     std::vector<int> n(bamm_v_size(K, W), 0);
@@ -259,7 +261,7 @@ int motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& 
         std::vector<double> u(n_seqs ? n_seqs : 1, 0.0);
         for (size_t s = 0; s < n_seqs; s++)
             if (off[s + 1] - off[s] >= W) u[s] = std::generate_canonical<double, 53>(rngx);
-        if (bamm_seed_from_pwm(dev->ctx, dev->seqs, K, W, score.data(), q, u.data(), n.data(), nullptr)) {
+        if (bamm_seed_from_pwm(dev->ctx, dev->seqs, K, W, score.data(), q, u.data(), n.data(), z_out ? z_out->data() : nullptr)) {
             err = std::string("PWM seeding on the device failed: ") + bamm_last_error();
             return 1;
         }
@@ -300,6 +302,7 @@ int motif_init_from_pwm(Motif& m, const std::vector<float>& pwm, const BgModel& 
             const uint32_t* km = yK + off[s];
             std::discrete_distribution<size_t> dist(r.begin(), r.end());
             const size_t z = dist(rngx);
+            if (z_out) (*z_out)[s] = (uint32_t)z;
             if (z > 0)
                 for (uint32_t k = 0; k <= K; k++)
                     for (uint32_t j = 0; j < W; j++) n[voff(k, W) + (km[z - 1 + j] % ipow4(k + 1)) * W + j]++;

@@ -116,6 +116,8 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
  *   "group_layout" -1 = planner's choice, 0..3 = table layout (csrc/grouped.hip: grp_geometry)
  *   "sparse"       1/0  compacted lists of the non-zero windows in the M-step (default 1)
  *   "e_fused"      1/0  sliced path: whole-table E pass when the odds table fits LDS (default 1)
+ *   "e_list"       1/0  sliced path: the E pass hands the M slices compacted lists of the non-zero
+ *                       windows instead of all responsibilities (default 1)
  * There are no environment variables that change what the library computes or launches.          */
 int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
 

@@ -93,6 +93,7 @@ class Oracle:
         L.orc_mask.restype = sz
         L.orc_logodds.argtypes = [_u64p, _u64p, sz, sz, sz, _f32p, _f32p, _f32p, _u64p]
         L.orc_init_from_pwm.argtypes = [_f32p, sz, sz, _f32p, _f32p, _u64p, _u64p, sz, f, _f32p]
+        L.orc_init_from_pwm_sites.argtypes = [_f32p, sz, sz, _f32p, _f32p, _u64p, _u64p, sz, f, _f32p, C.c_void_p, C.c_void_p]
         L.orc_em_step_f64.argtypes = [_u64p, _u64p, sz, sz, sz, sz, _f32p, _f32p, _f32p, f,
                                       _f32p, _f32p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
@@ -197,6 +198,16 @@ class Oracle:
         v = np.zeros(v_size(K, W), np.float32)
         self.L.orc_init_from_pwm(_f32(pwm), W, K, _f32(A), _f32(vbg), _u64(kmer), _u64(off), len(off) - 1, q, v)
         return v
+
+    def init_from_pwm_sites(self, pwm, W, K, A, vbg, kmer, off, q):
+        """(v, z, counts): the seed model, the sampled site per sequence (0 = none, i = window i-1) and the
+        integer site counts of all orders."""
+        v = np.zeros(v_size(K, W), np.float32)
+        z = np.zeros(max(len(off) - 1, 1), np.uint32)
+        cnt = np.zeros(v_size(K, W), np.int32)
+        self.L.orc_init_from_pwm_sites(_f32(pwm), W, K, _f32(A), _f32(vbg), _u64(kmer), _u64(off), len(off) - 1, q, v,
+                                       z.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p))
+        return v, z[: len(off) - 1], cnt
 
     def em_step_f64(self, kmer, off, K, W, bg_order, vbg, A, v, q):
         v_out = np.zeros(v_size(K, W), np.float32)

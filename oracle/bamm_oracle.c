@@ -509,6 +509,14 @@ static double mt_canonical(mt19937_t* g) {
 
 void orc_init_from_pwm(const float* pwm, size_t W, size_t K, const float* A, const float* vbg,
                        const uint64_t* kmer, const uint64_t* off, size_t N, float q, float* v) {
+    orc_init_from_pwm_sites(pwm, W, K, A, vbg, kmer, off, N, q, v, NULL, NULL);
+}
+
+/* the same, also reporting the sampled site of every sequence (z_out[n]: 0 = no motif, i = window i-1; may be
+ * NULL) and the integer site counts of all orders (counts_out[orc_v_size(K,W)], flat [k][y][j]; may be NULL) */
+void orc_init_from_pwm_sites(const float* pwm, size_t W, size_t K, const float* A, const float* vbg,
+                             const uint64_t* kmer, const uint64_t* off, size_t N, float q, float* v,
+                             uint32_t* z_out, int* counts_out) {
     size_t total = orc_v_size(K, W);
     int* cnt = (int*)calloc(total, sizeof(int));
     /* Motif.cpp:205-220: floor at 1e-8 (double literal compare, float store), renormalise */
@@ -533,6 +541,7 @@ void orc_init_from_pwm(const float* pwm, size_t W, size_t K, const float* A, con
     double* cp = (double*)malloc((maxL + 2) * sizeof(double));
     for (size_t n = 0; n < N; n++) {                            /* Motif.cpp:255-311, serial */
         size_t L = (size_t)(off[n + 1] - off[n]);
+        if (z_out) z_out[n] = 0;
         if (L < W) continue;                                    /* Motif.cpp:240-248 */
         size_t LW1 = L - W + 1;
         const uint64_t* km = kmer + off[n];
@@ -565,6 +574,7 @@ void orc_init_from_pwm(const float* pwm, size_t W, size_t K, const float* A, con
             while (lo < hi) { size_t mid = lo + (hi - lo) / 2; if (cp[mid] < u) lo = mid + 1; else hi = mid; }
             z = lo;
         }
+        if (z_out) z_out[n] = (uint32_t)z;
         if (z > 0)                                              /* Motif.cpp:302-309 */
             for (size_t k = 0; k <= K; k++)
                 for (size_t j = 0; j < W; j++)
@@ -583,6 +593,7 @@ void orc_init_from_pwm(const float* pwm, size_t W, size_t K, const float* A, con
                 vk[y * W + j] = ((float)nk[y * W + j] + Ak[j] * vk1[y2 * W + j]) / ((float)nk1[yk * W + j - 1] + Ak[j]);
         }
     }
+    if (counts_out) memcpy(counts_out, cnt, total * sizeof(int));
     free(cnt); free(score); free(r); free(cp);
 }
 

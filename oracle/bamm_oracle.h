@@ -108,6 +108,11 @@ void   orc_logodds(const uint64_t* kmer, const uint64_t* off, size_t N, size_t K
  * std::discrete_distribution restated).  pwm: [y][j] 4 x W.  v_out: flat v. */
 void   orc_init_from_pwm(const float* pwm, size_t W, size_t K, const float* A, const float* vbg,
                          const uint64_t* kmer, const uint64_t* off, size_t N, float q, float* v_out);
+/* the same, also reporting the sampled site per sequence (z_out[n]: 0 = no motif, i = window i-1) and the
+ * integer site counts of all orders, flat [k][y][j]; either may be NULL */
+void   orc_init_from_pwm_sites(const float* pwm, size_t W, size_t K, const float* A, const float* vbg,
+                               const uint64_t* kmer, const uint64_t* off, size_t N, float q, float* v,
+                               uint32_t* z_out, int* counts_out);
 
 /* fp64 restatement of one E+M step (precision oracle): same formulas,
  * every product / sum in double; outputs rounded to float at the end. */

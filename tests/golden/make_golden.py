@@ -26,6 +26,7 @@ LARGE = [
     dict(name="g4_1k", N=1000, L0=200, W=20, K=2, seed=1234),
     dict(name="g4_10k", N=10000, L0=200, W=20, K=2, seed=1234),
     dict(name="g5_k4", N=300, L0=500, W=30, K=4, seed=77, ss=True),
+    dict(name="c4_k4_ds", N=160, L0=500, W=30, K=4, seed=78),          # BASELINE config 4's shape: both strands, L = 1001
 ]
 
 
@@ -274,6 +275,18 @@ def main():
         return
     if sys.argv[1:] == ["config5"]:
         run_config5_case(R)
+        return
+    if sys.argv[1:2] == ["large"]:                   # one large case by name
+        for spec in LARGE:
+            if spec["name"] in sys.argv[2:]:
+                c = Case(**spec)
+                out = run_case(R, c, store_inputs=False, n_iter=3 if c.K <= 2 else 2, r_seqs=8,
+                               with_optimize=(c.N <= 1000 and c.K <= 2))
+                if c.K > 2:
+                    for key in ("s_0", "n_0", "v_0", "p_final", "logs_final"):
+                        out.pop(key, None)
+                np.savez_compressed(os.path.join(HERE, f"large_{c.name}.npz"), **out)
+                print("wrote", c.name)
         return
     run_mask_cases(R)
     run_config5_case(R)

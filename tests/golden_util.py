@@ -15,6 +15,7 @@ LARGE_SPECS = {
     "g4_1k": dict(name="g4_1k", N=1000, L0=200, W=20, K=2, seed=1234),
     "g4_10k": dict(name="g4_10k", N=10000, L0=200, W=20, K=2, seed=1234),
     "g5_k4": dict(name="g5_k4", N=300, L0=500, W=30, K=4, seed=77, ss=True),
+    "c4_k4_ds": dict(name="c4_k4_ds", N=160, L0=500, W=30, K=4, seed=78),
 }
 
 

@@ -129,6 +129,45 @@ def test_pwm_seeding_matches_oracle_restatement(K, host, orc):
     assert n1 == 1                                           # --maxPWM (MotifSet.cpp:145-147)
 
 
+def pwm_sites(H, pwm, W, K, alpha, vbg, packed, q=0.3, ctx=None, seqs=None):
+    """Motif::initFromPWM through the product's host C++ (or, with ctx/seqs, the device path): (v, z)."""
+    v = np.zeros(bm.v_size(K, W), np.float32)
+    z = np.zeros(max(packed.n_seqs, 1), np.uint32)
+    pwm, alpha, vbg = (np.ascontiguousarray(a, np.float32) for a in (pwm, alpha, vbg))
+    H.bh_last_error.restype = C.c_char_p
+    rc = H.bh_pwm_sites(pwm.ctypes.data_as(C.c_void_p), W, K, alpha.ctypes.data_as(C.c_void_p), 2, vbg.ctypes.data_as(C.c_void_p),
+                        packed._p, C.c_float(q), v.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p),
+                        ctx.h if ctx else None, seqs.h if seqs else None)
+    assert rc == 0, H.bh_last_error()
+    return v, z[: packed.n_seqs]
+
+
+SITE_CASES = [dict(name="s_k2", N=300, L0=120, W=11, K=2, n_frac=0.01, ragged=40),
+              dict(name="s_k1_ss", N=200, L0=90, W=7, K=1, ss=True, ragged=85),      # some sequences shorter than W: no draw
+              dict(name="s_k0", N=150, L0=70, W=9, K=0, n_frac=0.03, ragged=20)]
+
+
+@pytest.mark.parametrize("spec", SITE_CASES, ids=[d["name"] for d in SITE_CASES])
+def test_pwm_seeding_samples_the_same_sites_as_the_oracle(spec, host, orc):
+    """Sequence by sequence: the site the product's host path draws with the real std::mt19937 +
+    std::discrete_distribution is the site the oracle's hand restatement of libstdc++'s algorithm draws
+    (Motif.cpp:296-299) -- the two implementations are pinned to each other through z, not only through the
+    model they lead to.  (Against the reference itself this row stays unpinned: initFromPWM needs the Boost
+    FASTA reader)"""
+    from tests.cases import Case
+    c = Case(**spec)
+    _, kmer, off = orc.encode_set(c.codes, c.in_off, c.ss, 42)
+    packed = bm.PackedSeqs.from_codes(c.codes, c.in_off, c.ss, seed=42)
+    vbg = packed.bg_model(2, np.array([1, 10, 10], np.float32))
+    v, z = pwm_sites(host, c.pwm, c.W, c.K, c.alpha, vbg, packed, q=c.q)
+    v_o, z_o, cnt_o = orc.init_from_pwm_sites(c.pwm, c.W, c.K, c.A, vbg, kmer, off, c.q)
+    assert np.array_equal(z, z_o)
+    assert np.array_equal(v, v_o)
+    lens = np.diff(off.astype(np.int64))
+    assert np.all(z[lens < c.W] == 0) and (z > 0).sum() > 0.2 * c.N and (z == 0).sum() > 0
+    assert cnt_o[: 4 * c.W].reshape(4, c.W).sum(axis=0).tolist() == [int((z > 0).sum())] * c.W
+
+
 def test_bamm_file_roundtrip(host, tmp_path, orc):
     c, g = gu.load("small_k2_ds_N")
     open(tmp_path / "m.ihbcp", "wb").write(g["file_ihbcp"].tobytes())

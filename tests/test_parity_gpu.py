@@ -145,6 +145,7 @@ def test_second_optimize_call_reestimates_q(gpu_ctx, orc):
 
 SLICED_CASES = [
     dict(name="k4", N=60, L0=300, W=30, K=4, ss=True, ragged=40, n_frac=0.01),
+    dict(name="k4_ds_config4_shape", N=48, L0=500, W=30, K=4, ragged=12, n_frac=0.002),    # both strands, L ~ 1001: 16 positions per lane, 768 threads
     dict(name="k4_M96_128", N=5, L0=6600, W=30, K=4, ss=True, ragged=1500, n_frac=0.0005),   # longest length classes
     dict(name="k5_w12", N=30, L0=400, W=12, K=5, ragged=60, n_frac=0.002),                  # E slices carry the chain through HBM
 ]
@@ -173,6 +174,28 @@ def test_sliced_path_for_large_tables(spec, gpu_ctx, orc):
     em.iterate(2)
     assert em.iteration() == 4
     em.close(); ss.close()
+
+
+@pytest.mark.parametrize("spec", SLICED_CASES[:3], ids=[d["name"] for d in SLICED_CASES[:3]])
+def test_sliced_paths_agree_bit_for_bit(spec, gpu_ctx, orc):
+    """k >= 4 with the whole odds table in LDS: the E pass hands the M slices compacted lists of the windows with a
+    non-zero fixed-point addend (default) or all responsibilities (e_list = 0); with e_fused = 0 the E chain itself
+    is cut into column ranges.  The two whole-table variants add the same integers: identical counts."""
+    c = Case(**spec)
+    res = {}
+    for tag, tune in (("list", {}), ("dense", dict(e_list=0)), ("e_sliced", dict(e_fused=0))):
+        gpu_ctx.set_tuning(**tune)
+        try:
+            em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+        finally:
+            gpu_ctx.set_tuning(e_list=1, e_fused=1)
+        em.iterate(3)
+        res[tag] = (em.getCounts(), em.getV(), em.getQ(), em.trace()[0], em.getR())
+        em.close(); ss.close()
+    for k in range(5):
+        assert np.array_equal(res["list"][k], res["dense"][k]), k
+    np.testing.assert_allclose(res["list"][1], res["e_sliced"][1], rtol=2e-6, atol=1e-10)
+    np.testing.assert_allclose(res["list"][4], res["e_sliced"][4], rtol=1e-5, atol=1e-12)
 
 
 def test_optimize_stopping_rule(gpu_ctx, orc):

@@ -10,7 +10,7 @@ import pytest
 import bammmotif2_amd as bm
 from bammmotif2_amd import build
 from tests.cases import Case
-from tests.test_host_io_cpu import FASTA, MEME, load_seed, read_fasta_py
+from tests.test_host_io_cpu import FASTA, MEME, SITE_CASES, load_seed, pwm_sites, read_fasta_py
 
 pytestmark = pytest.mark.gpu
 
@@ -76,6 +76,10 @@ def test_seed_from_pwm_matches_oracle(spec, gpu_ctx, orc):
     u[valid] = mt19937_canonical(int(valid.sum()))
     score = (pwm / vbg[:4, None]).astype(np.float32)
     counts, z = bm.seed_from_pwm(gpu_ctx, ss, c.K, c.W, score.ravel(), c.q, u)
+    # against orc_init_from_pwm directly: the sampled site of every sequence and the site counts of all orders
+    _, z_o, cnt_o = orc.init_from_pwm_sites(c.pwm, c.W, c.K, c.A, vbg, kmer, off, c.q)
+    assert np.array_equal(z, z_o)
+    assert np.array_equal(counts, cnt_o)
     assert np.all(z[~valid] == 0) and np.all(z <= np.maximum(lens - c.W + 1, 0))
     # counts of order 0 = sampled sites per column
     assert np.all(counts[: 4 * c.W].reshape(4, c.W).sum(axis=0) == int((z > 0).sum()))
@@ -107,4 +111,20 @@ def test_device_seeding_equals_host_seeding_on_ragged_set(host, gpu_ctx, orc, tm
     _, Wd, qd, v_dev = load_seed_dev(host, gpu_ctx, ss, str(meme), c.K, c.alpha, vbg, packed)
     assert W == Wd == c.W
     assert np.array_equal(v_host, v_dev)
+    ss.close()
+
+
+@pytest.mark.parametrize("spec", SITE_CASES, ids=[d["name"] for d in SITE_CASES])
+def test_three_seeders_sample_the_same_sites(spec, host, gpu_ctx, orc):
+    """Device kernel, host C++ (std::discrete_distribution) and the oracle restatement, sequence by sequence."""
+    c = Case(**spec)
+    _, kmer, off = orc.encode_set(c.codes, c.in_off, c.ss, 42)
+    packed = bm.PackedSeqs.from_codes(c.codes, c.in_off, c.ss, seed=42)
+    ss = bm.SeqSet(gpu_ctx, packed)
+    vbg = packed.bg_model(2, np.array([1, 10, 10], np.float32))
+    v_h, z_h = pwm_sites(host, c.pwm, c.W, c.K, c.alpha, vbg, packed, q=c.q)
+    v_d, z_d = pwm_sites(host, c.pwm, c.W, c.K, c.alpha, vbg, packed, q=c.q, ctx=gpu_ctx, seqs=ss)
+    v_o, z_o, _ = orc.init_from_pwm_sites(c.pwm, c.W, c.K, c.A, vbg, kmer, off, c.q)
+    assert np.array_equal(z_d, z_o) and np.array_equal(z_h, z_o)
+    assert np.array_equal(v_d, v_o) and np.array_equal(v_h, v_o)
     ss.close()
