@@ -170,6 +170,15 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]: counts of the virtual rows
     const uint32_t logC = ACCUM ? a.logC : 0u;
 
+    // the wave's first sequence is on its way from HBM while the block builds its tables
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    uint32_t t = blockIdx.x * waves_per_block + wave;
+    RawSeqG<M> nxt{};
+    if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
+
     // ---- block prologue: single-column table, grouped table, zeroed counts
     for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
     __syncthreads();
@@ -205,10 +214,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t total_waves = gridDim.x * waves_per_block;
     const float q = *a.q;
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
@@ -220,9 +225,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     uint32_t last_LW1 = 0;
     float pos_i = 0.0f;
 
-    uint32_t t = blockIdx.x * waves_per_block + wave;
-    RawSeqG<M> nxt{};
-    if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
     for (; t < a.sv.count; t += total_waves) {
         const RawSeqG<M> cur = nxt;
         if (t + total_waves < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t + total_waves, lane);   // prefetch

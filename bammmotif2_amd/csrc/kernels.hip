@@ -103,6 +103,15 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     const uint32_t logC = ACCUM ? a.logC : 0u;
     double* stat_lds = reinterpret_cast<double*>(lds + n_off + (ACCUM ? (2u * W * Ys) << logC : 0u));  // [waves][3]
 
+    // the wave's first sequence is on its way from HBM while the block builds its tables
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t waves_per_block = blockDim.x >> 6;
+    const uint32_t total_waves = gridDim.x * waves_per_block;
+    uint32_t t = blockIdx.x * waves_per_block + wave;
+    RawSeq<M> nxt{};
+    if (t < a.sv.count) nxt = fetch_seq<M>(a.sv, t, lane);
+
     for (uint32_t i = threadIdx.x; i < Wq * Ys * 4u; i += blockDim.x) {
         const uint32_t jq = i / (Ys * 4u), rem = i - jq * Ys * 4u, yy = rem >> 2, j = jq * 4u + (rem & 3u);
         // the 4*Wq - W padding columns sit in FRONT of column 0 and hold 1.0f: every quad then takes all
@@ -114,19 +123,12 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         for (uint32_t i = threadIdx.x; i < (W * Ys) << logC; i += blockDim.x) n_lds[i] = 0ull;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t waves_per_block = blockDim.x >> 6;
-    const uint32_t total_waves = gridDim.x * waves_per_block;
     const float q = *a.q;
     const float one_minus_q = 1.0f - q;
 
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0;
 
-    uint32_t t = blockIdx.x * waves_per_block + wave;
-    RawSeq<M> nxt{};
-    if (t < a.sv.count) nxt = fetch_seq<M>(a.sv, t, lane);
     for (; t < a.sv.count; t += total_waves) {
         const RawSeq<M> cur = nxt;
         if (t + total_waves < a.sv.count) nxt = fetch_seq<M>(a.sv, t + total_waves, lane);   // prefetch
@@ -735,20 +737,32 @@ __global__ void k_make_s(const float* v, const float* vbg, uint32_t K, uint32_t 
 }
 
 // ---- model update: one block ----------------------------------------------------------------
+// IN_LDS: all orders of n and v are staged in LDS (8 bytes per cell: K <= 3 at usual widths).  The update is a
+// chain of small dependent phases (marginalise order by order, then v order by order); run on the global
+// arrays each phase pays a store -> barrier -> load round trip through the cache (7.3 us for 1680 cells), in LDS
+// the chain costs a few hundred cycles and global memory sees one read of the accumulator and one write of the
+// results.  Same formulas in the same order either way: bit-identical models.
+template <bool IN_LDS>
 __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
-    __shared__ double shd[1024];
+    extern __shared__ float upd_lds[];
+    __shared__ double shd[16];
+    __shared__ double stat3[3];
     const uint32_t K = a.K, W = a.W;
     const uint32_t YK = 1u << (2 * (K + 1));
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     auto voff = [W](uint32_t k) { return (size_t)W * (((size_t(1) << (2 * (k + 1))) - 4) / 3); };
+    const size_t vsz = voff(K + 1);
+    float* const n = IN_LDS ? upd_lds : a.n;               // all orders, flat [k][y][j]
+    float* const v = IN_LDS ? upd_lds + vsz : a.v;
 
     // order-K counts from the (all-reduced) integer accumulator, which is left zeroed for the next pass
-    float* nK = a.n + voff(K);
-    for (uint32_t i = tid; i < YK * W; i += nt) {
+    float* nK = n + voff(K);
+    float old0 = 0.0f, old1 = 0.0f;                        // IN_LDS: this thread's (at most two) cells of the old v[K], for v_diff
+    for (uint32_t i = tid, u = 0; i < YK * W; i += nt, u++) {
         nK[i] = (float)((double)a.acc[i] * a.count_unit);
         a.acc[i] = 0ll;
+        if (IN_LDS) { const float x = a.v[voff(K) + i]; old0 = u == 0u ? x : old0; old1 = u == 1u ? x : old1; }
     }
-    __shared__ double stat3[3];
     if (tid < 3) {
         const long long x = a.acc[(size_t)YK * W + tid];
         a.acc[(size_t)YK * W + tid] = 0ll;
@@ -757,8 +771,8 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
     __syncthreads();
     // EM.cpp:247-254: n[k-1][y mod 4^k][j] += n[k][y][j], y ascending (same float order)
     for (uint32_t k = K; k > 0; k--) {
-        const float* nk = a.n + voff(k);
-        float* nk1 = a.n + voff(k - 1);
+        const float* nk = n + voff(k);
+        float* nk1 = n + voff(k - 1);
         const uint32_t Yk = 1u << (2 * k);                 // rows of order k-1
         for (uint32_t i = tid; i < Yk * W; i += nt) {
             const uint32_t y2 = i / W, j = i % W;
@@ -773,29 +787,29 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
     double diff = 0.0;
     for (uint32_t j = tid; j < W; j += nt) {
         float sumN = 0.0f;
-        for (uint32_t y = 0; y < 4; y++) sumN += a.n[y * W + j];
+        for (uint32_t y = 0; y < 4; y++) sumN += n[y * W + j];
         for (uint32_t y = 0; y < 4; y++) {
-            const float nv = (a.n[y * W + j] + a.A[j] * a.vbg[y]) / (sumN + a.A[j]);
+            const float nv = (n[y * W + j] + a.A[j] * a.vbg[y]) / (sumN + a.A[j]);
             if (K == 0) diff += (double)fabsf(nv - a.v[y * W + j]);
-            a.v[y * W + j] = nv;
+            v[y * W + j] = nv;
         }
     }
     __syncthreads();
     // Motif.h:121-135: orders 1..K
     for (uint32_t k = 1; k <= K; k++) {
-        const float* nk = a.n + voff(k);
-        const float* nk1 = a.n + voff(k - 1);
-        float* vk = a.v + voff(k);
-        const float* vk1 = a.v + voff(k - 1);
+        const float* nk = n + voff(k);
+        const float* nk1 = n + voff(k - 1);
+        float* vk = v + voff(k);
+        const float* vk1 = v + voff(k - 1);
         const float* Ak = a.A + (size_t)k * W;
         const uint32_t Yk1 = 1u << (2 * (k + 1)), Yk = 1u << (2 * k);
-        for (uint32_t i = tid; i < Yk1 * W; i += nt) {
+        for (uint32_t i = tid, u = 0; i < Yk1 * W; i += nt, u++) {
             const uint32_t y = i / W, j = i % W;
             const uint32_t y2 = y % Yk, yk = y / 4;
             float nv;
             if (j < k) nv = vk1[(size_t)y2 * W + j];
             else nv = (nk[i] + Ak[j] * vk1[(size_t)y2 * W + j]) / (nk1[(size_t)yk * W + j - 1] + Ak[j]);
-            if (k == K) diff += (double)fabsf(nv - vk[i]);
+            if (k == K) diff += (double)fabsf(nv - (IN_LDS ? (u == 0u ? old0 : old1) : a.v[voff(K) + i]));
             vk[i] = nv;
         }
         __syncthreads();
@@ -815,10 +829,12 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         __syncthreads();
     }
     const double v_diff = shd[0];
+    if (IN_LDS)                                            // results out: one coalesced sweep, nobody waits for it
+        for (uint32_t i = tid; i < vsz; i += nt) { a.n[i] = n[i]; a.v[i] = v[i]; }
     // next E-step's odds table (Motif.cpp:485-494)
     {
         const uint32_t Ys = YK + 1u, Yb = 1u << (2 * (a.Kbg + 1));
-        const float* vK = a.v + voff(K);
+        const float* vK = v + voff(K);
         const float* b = a.vbg + (((size_t)Yb - 4) / 3);
         for (uint32_t i = tid; i < W * Ys; i += nt) {
             const uint32_t j = i / Ys, y = i % Ys;
@@ -857,6 +873,8 @@ __global__ void k_stat_only(long long* acc, uint32_t cells, float* status) {
         acc[cells + 0] = 0ll; acc[cells + 1] = 0ll; acc[cells + 2] = 0ll;
     }
 }
+
+inline size_t W_cells(uint32_t K, uint32_t W) { return ((size_t)1 << (2 * (K + 1))) * W; }
 
 template <int M, int THREADS>
 int launch_em_variant(bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks, uint32_t threads,
@@ -1039,7 +1057,14 @@ int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint
 }
 
 int launch_update(const UpdateArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, st, a);
+    const size_t vsz = v_size(a.K, a.W);
+    // n and v of all orders staged in LDS when at most two cells per thread of the top order are in flight
+    // (the old v[K] is kept in two registers) and the tables fit the default 64 KiB
+    if ((size_t)W_cells(a.K, a.W) <= 2048u && 2 * vsz * sizeof(float) <= 60 * 1024) {
+        hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(1024), 2 * vsz * sizeof(float), st, a);
+    } else {
+        hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(1024), 0, st, a);
+    }
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;
 }
