@@ -292,6 +292,7 @@ uint32_t default_threads(const bamm_ctx* c, int mclass) {
 
 // block size of one launch: the grouped kernel's longer length classes are built for fewer waves
 uint32_t bucket_threads(const bamm_ctx* c, const EmBucket& b) {
+    if (b.mclass == kLongClass) return 256u;
     const uint32_t t = default_threads(c, b.mclass);
     return b.grouped ? std::min(t, grp_max_threads(kMClasses[b.mclass])) : t;
 }
@@ -374,6 +375,14 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
         a.acc = em->d_acc;
         a.fix_scale = ldexpf(1.0f, (int)em->fix_shift - 40);
         a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
+        if (bk.mclass == kLongClass) {
+            // the sliced path's getR() reads dense r from d_state (slot layout unless the E pass is k_em_seq)
+            const bool want_r = em->sliced && dense_r;
+            if (want_r && !em->d_state && (rc = dev_alloc(&em->d_state, (size_t)s->total_len))) return rc;
+            a.r_out = em->d_state;
+            if ((rc = launch_long_em(a, accum, want_r, want_r && !em->e_fused, bk.blocks, st))) return rc;
+            continue;
+        }
         const uint32_t threads = bucket_threads(em->ctx, bk);
         if (!em->sliced) {
             rc = launch_fused(em, bk, accum, false, a, threads, st);
@@ -617,15 +626,11 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
     s->h_exc_clean.assign(p->exc_clean + e0, p->exc_clean + e1);
 
     // length buckets: one kernel instantiation per positions-per-lane class
-    std::vector<std::vector<uint32_t>> members(kNumMClasses);
+    // (+ one bucket for the sequences beyond the longest class: long_seq.hip walks those window by window)
+    std::vector<std::vector<uint32_t>> members(kNumMClasses + 1);
     for (uint64_t n = 0; n < s->n; n++) {
-        int mc = m_class_for_len(s->h_len[n]);
-        if (mc < 0) {
-            set_error("sequence %llu has %u positions; the kernels cover L <= %d (reverse complement and separator included)",
-                      (unsigned long long)(begin + n), s->h_len[n], 64 * kMClasses[kNumMClasses - 1]);
-            return BAMM_ERR_UNSUPPORTED;
-        }
-        members[mc].push_back((uint32_t)n);
+        const int mc = m_class_for_len(s->h_len[n]);
+        members[mc < 0 ? kNumMClasses : mc].push_back((uint32_t)n);
     }
     int rc;
     // 80 zero words of slack: the grouped kernel reads a lane's words without checking the sequence's end
@@ -636,13 +641,14 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
     if ((rc = dev_upload(&s->d_len, s->h_len.data(), s->h_len.size(), c->stream))) return rc;
     if ((rc = dev_upload(&s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size(), c->stream))) return rc;
     int used = 0;
-    for (int mc = 0; mc < kNumMClasses; mc++) used += !members[mc].empty();
-    for (int mc = 0; mc < kNumMClasses; mc++) {
+    for (int mc = 0; mc <= kNumMClasses; mc++) used += !members[mc].empty();
+    for (int mc = 0; mc <= kNumMClasses; mc++) {
         if (members[mc].empty()) continue;
         Bucket b;
-        b.mclass = mc;
+        b.mclass = mc < kNumMClasses ? mc : kLongClass;
         b.count = (uint32_t)members[mc].size();
-        b.work = (double)b.count * kMClasses[mc];
+        if (mc < kNumMClasses) b.work = (double)b.count * kMClasses[mc];
+        else for (uint32_t n : members[mc]) b.work += s->h_len[n] / 8.0;   // ~8x the cost per position of the fast kernels
         s->buckets.push_back(b);
         if (used > 1) {
             if ((rc = dev_upload(&s->buckets.back().d_idx, members[mc].data(), members[mc].size(), c->stream))) return rc;
@@ -742,8 +748,10 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         em->e_fused = em_lds_bytes(prm->W, Y, false, 0, 0) <= kLds && c->use_e_fused;
         // sparse M-slices: room for a list of 256 windows + the y of every position per wave (8 waves per
         // block at the longest length class) is taken off the column budget when that costs no extra slice
-        const int Mmax = kMClasses[m_class_for_len(seqs->max_len ? seqs->max_len : 1)];
-        const uint32_t waves = max_threads_for_mclass(m_class_for_len(seqs->max_len ? seqs->max_len : 1)) / 64u;
+        int mc_max = 0;                                      // longest length class present (the long bucket has no class)
+        for (auto& b : seqs->buckets) mc_max = std::max(mc_max, b.mclass);
+        const int Mmax = kMClasses[mc_max];
+        const uint32_t waves = max_threads_for_mclass(mc_max) / 64u;
         const size_t scratch = !c->use_sparse ? 0 : m_slice_wave_bytes(Mmax, 256) * waves;
         uint32_t m_cols_sparse = 0;
         while (scratch && m_cols_sparse < prm->W && m_slice_lds_bytes(m_cols_sparse + 1, Y, 0) + scratch <= kLds) m_cols_sparse++;
@@ -801,6 +809,12 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     // takes (no exception, or all of them within its virtual rows) and the rest
     const bool want_grouped = !sliced && prm->K <= 2u && c->use_grouped;
     for (auto& b : seqs->buckets) {
+        if (b.mclass == kLongClass) {                        // beyond the length classes: long_seq.hip
+            EmBucket eb;
+            eb.mclass = kLongClass; eb.count = b.count; eb.d_idx = b.d_idx; eb.work = b.work;
+            em->ebuckets.push_back(eb);
+            continue;
+        }
         const int Mcls = kMClasses[b.mclass];
         const uint32_t threads = default_threads(c, b.mclass);
         GrpGeom gg{};
@@ -860,6 +874,11 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     for (auto& b : em->ebuckets) total_work += b.work;
     em->total_blocks = 0;
     for (auto& b : em->ebuckets) {
+        if (b.mclass == kLongClass) {                        // a workgroup per sequence
+            b.blocks = std::min(b.count, (uint32_t)std::max(1, c->num_cus) * 8u);
+            em->total_blocks += b.blocks;
+            continue;
+        }
         const uint32_t threads = bucket_threads(c, b);
         // 16 waves per CU saturate the LDS pipe (tools/lds_bench2.hip); the LDS left over goes
         // into private copies of the count table
@@ -1259,6 +1278,8 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         a.s = em->s_last; a.q = em->q_last;                 // the E pass the caller last ran (EM.cpp:521)
         a.acc = nullptr;                                    // responsibilities only
         a.r_out = d_r; a.r_base = base; a.seq_begin = (uint32_t)begin; a.seq_end = (uint32_t)end;
+        a.fix_scale = 1.0f;
+        if (bk.mclass == kLongClass) { rc = launch_long_em(a, false, true, false, bk.blocks, st); continue; }
         rc = launch_fused(em, bk, false, true, a, bucket_threads(em->ctx, bk), st);
     }
     if (!rc) {
@@ -1407,6 +1428,10 @@ int bamm_logodds_subset(bamm_ctx* c, bamm_seqs* s, const uint8_t* seq_mask, uint
         ScoreKernelArgs a{};
         a.sv = make_view(s, exc, bk, d_smask);
         a.K = K; a.W = W; a.Y = Y; a.s = d_tab; a.mops = d_mops; a.mops_off = d_moff; a.zoops = d_zoops; a.z = d_z;
+        if (bk.mclass == kLongClass) {
+            rc = launch_long_score(a, std::min(bk.count, (uint32_t)std::max(1, c->num_cus) * 8u), st);
+            continue;
+        }
         const uint32_t threads = default_threads(c, bk.mclass);
         uint32_t blocks = default_blocks(c, threads);
         blocks = std::max(1u, std::min(blocks, (bk.count + threads / 64u - 1) / (threads / 64u)));

@@ -53,7 +53,8 @@ bamm_ctx* comm_ctx(const bamm_comm* c);
 // positions-per-lane classes the sequence kernels are instantiated for (L <= 64*M)
 constexpr int kNumMClasses = 23;
 extern const int kMClasses[kNumMClasses];
-int m_class_for_len(uint32_t L);  // index into kMClasses, or -1 when L > 64*128
+int m_class_for_len(uint32_t L);  // index into kMClasses, or -1 when L > 64*128 (kLongClass: long_seq.hip)
+constexpr int kLongClass = -1;
 
 // ---------------------------------------------------------------- device views ----------
 struct SeqView {                 // one length bucket of a resident sequence set
@@ -226,6 +227,9 @@ int launch_m_slice(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, 
                    uint32_t threads, hipStream_t st);
 int launch_m_list(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads, hipStream_t st);
 size_t m_list_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC, int M, uint32_t waves);
+// sequences beyond the length classes (long_seq.hip): one workgroup per sequence, window by window
+int launch_long_em(const EmKernelArgs& a, bool accum, bool write_r, bool slot_layout, uint32_t blocks, hipStream_t st);
+int launch_long_score(const ScoreKernelArgs& a, uint32_t blocks, hipStream_t st);
 int launch_score(int mclass, const ScoreKernelArgs& a, uint32_t blocks, uint32_t threads,
                  hipStream_t st);
 // EM::mask only: its kernels still leave one partial table per block; summed into the fused accumulator

@@ -302,19 +302,9 @@ int main(int nargs, char* args[]) {
     bamm_packed* packed = nullptr;
     if (bamm_pack_codes(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, &packed)) die_abi("packing sequences");
     stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
-    // the sequence kernels hold one sequence per wavefront, at most 128 positions per lane (DESIGN.md
-    // section 4, envelope): name the records beyond that instead of failing at the upload
-    if ((o.EM || o.score || o.FDR) && packed->max_len > BAMM_MAX_SEQ_POSITIONS) {
-        size_t shown = 0, total = 0;
-        for (size_t n = 0; n < pos.size(); n++)
-            if (packed->len[n] > BAMM_MAX_SEQ_POSITIONS) {
-                if (shown++ < 5) std::cerr << "  " << pos.headers[n] << " (" << pos.off[n + 1] - pos.off[n] << " bp)" << std::endl;
-                total++;
-            }
-        die("Error: " + std::to_string(total) + " sequence(s) exceed the MI355X build's limit of " +
-            std::to_string(o.ss ? BAMM_MAX_SEQ_POSITIONS : (BAMM_MAX_SEQ_POSITIONS - 1) / 2) + " bp" +
-            (o.ss ? " (--ss)." : " (both strands; twice that with --ss).") + " Split or remove them.");
-    }
+    // records beyond 8192 positions leave the register-resident kernels for the window-by-window path
+    // (csrc/long_seq.hip); initFromPWM's pass over such a record runs on the host
+    if (packed->max_len > BAMM_MAX_SEQ_POSITIONS) o.hostSeeding = true;
 
     if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
     BgModel bg;

@@ -42,7 +42,9 @@ extern "C" {
 #define BAMM_ERR_COMM       -6   /* the caller's all-reduce callback failed                     */
 
 #define BAMM_MAX_ORDER      10   /* kmer_ spans 11 bases (Sequence.cpp:37)                      */
-#define BAMM_MAX_SEQ_POSITIONS 8192u /* per sequence, reverse strand and separator included     */
+#define BAMM_MAX_SEQ_POSITIONS 8192u /* per sequence (reverse strand and separator included): up to
+                                      * here a sequence lives in the registers of one wavefront; longer
+                                      * ones are accepted and walked window by window (long_seq.hip)  */
 
 typedef struct bamm_ctx  bamm_ctx;   /* one device + one stream                                   */
 typedef struct bamm_seqs bamm_seqs;  /* a sequence set resident in HBM (2-bit packed)             */
@@ -124,8 +126,10 @@ int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
 /* ------------------------------------------------------------------ sequences ----------- */
 /* Uploads sequences [begin,end) of `p`; they stay resident and are shared (ref-counted) by
  * any number of EM handles -- CV folds pass a mask instead of copying (FDR.cpp:49-57).
- * Envelope: every sequence at most 8192 positions (reverse complement and separator
- * included, i.e. 4095 bp in the default double-strand mode); BAMM_ERR_UNSUPPORTED otherwise. */
+ * Any length: sequences up to BAMM_MAX_SEQ_POSITIONS go through the register-resident kernels, longer
+ * ones through a window-by-window path with identical results (EM passes, getR, the scorer);
+ * bamm_seed_from_pwm and bamm_em_mask keep a per-wave LDS plan and refuse sets whose longest
+ * sequence exceeds it (about 10 000 / 16 000 positions) with BAMM_ERR_UNSUPPORTED.              */
 int  bamm_seqs_upload(bamm_ctx* ctx, const bamm_packed* p, uint64_t begin, uint64_t end,
                       bamm_seqs** out);
 int  bamm_seqs_destroy(bamm_seqs* s);

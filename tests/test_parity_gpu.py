@@ -392,12 +392,22 @@ def test_long_sequences_match_exact_arithmetic(spec, gpu_ctx, orc):
     em.close(); ss.close()
 
 
-def test_sequence_longer_than_envelope_is_refused(gpu_ctx, orc):
-    c = Case("toolong", N=2, L0=8200, W=8, K=1, ss=True)
-    _, kmer, off, _ = c.encode(orc)
+def test_sequences_beyond_the_length_classes(gpu_ctx, orc):
+    """More than 8192 positions: accepted (csrc/long_seq.hip, tests/test_long_gpu.py checks the numbers); the two
+    entry points that keep a whole sequence in per-wave LDS arrays say so instead of computing something else."""
+    c = Case("toolong", N=2, L0=70000, W=8, K=1, ss=True)
+    _, kmer, off, vbg = c.encode(orc)
+    ss = bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
+    assert ss.info()["max_len"] == 70000
+    em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q)
+    assert em.plan()[2] == 1                                  # one launch: the long bucket
     with pytest.raises(bm.abi.BammError) as e:
-        bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
+        em.mask(0.1)                                          # EM::mask's LDS plan
     assert e.value.code == bm.abi.ERR_UNSUPPORTED
+    with pytest.raises(bm.abi.BammError) as e:
+        bm.seed_from_pwm(gpu_ctx, ss, c.K, c.W, np.ones(4 * c.W, np.float32), 0.3, np.full(c.N, 0.5))
+    assert e.value.code == bm.abi.ERR_UNSUPPORTED
+    em.close(); ss.close()
 
 
 def test_logodds_subset(gpu_ctx, orc):
