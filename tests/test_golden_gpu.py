@@ -71,3 +71,52 @@ def test_hip_path_matches_reference_golden(name, gpu_ctx, orc):
             np.testing.assert_allclose(em.getV(), g[f"opt{oq}_v"], rtol=1e-3, atol=1e-7)
         em.close()
     ss.close()
+
+
+def test_iteration_counts_over_all_fixtures(gpu_ctx):
+    """EM.cpp:117-118 stops on `v_diff < 0.01` or on a DECREASE of the log-likelihood after ten passes: both are
+    knife-edge tests on fp32 sums (the reference's llh is itself an fp32 reduction whose last bits depend on its
+    thread count), so a run can legitimately stop at another pass.  How often, and why, is a number,
+    not a shrug: every fixture with an optimize() record is run with both --optimizeQ settings; wherever the
+    pass count differs, the stop that fired first must have been within noise of not firing, seen in both traces
+    at that pass: v_diff within 2 % of epsilon, or an llh step below the fp32 noise of the llh itself.  The tally goes to
+    gpurun_out/iteration_counts.txt (copied to profiles/)."""
+    import os
+    rows, exact, off_by_one, total = [], 0, 0, 0
+    for name in gu.fixture_names():
+        c, g = gu.load(name)
+        if "opt0_iterations" not in g:
+            continue
+        pk = bm.PackedSeqs.from_codes(c.codes, c.in_off, c.ss, seed=42)
+        ss = bm.SeqSet(gpu_ctx, pk)
+        for oq in (0, 1):
+            em = bm.EM(gpu_ctx, ss, c.K, c.W, g["vbg"], c.A, c.v0, c.q, bg_order=c.bg_order, optimizeQ=bool(oq))
+            it, it_ref = em.optimize(), int(g[f"opt{oq}_iterations"])
+            llh, vd, _ = em.trace()
+            ref_vd, ref_llh = g[f"opt{oq}_trace_vdiff"], g[f"opt{oq}_trace_llh"]
+            by_vdiff = bool(ref_vd[it_ref - 1] < 0.01)
+            why = "v_diff < epsilon" if by_vdiff else ("llh decreased" if it_ref < 1000 else "iteration cap")
+            note = ""
+            if it != it_ref:
+                k = min(it, it_ref) - 1                          # the pass at which one of the two stopped
+                # noise of an llh: N terms log Z_n, each good to ~1e-7 absolute in fp32, plus the sum's own rounding
+                noise = 2e-6 * abs(float(llh[k])) + 2e-7 * c.N
+                step = abs(float(llh[k]) - float(llh[k - 1]))
+                ref_step = abs(float(ref_llh[k]) - float(ref_llh[k - 1]))
+                near_eps = abs(float(vd[k]) - 0.01) <= 2e-4 or abs(float(ref_vd[k]) - 0.01) <= 2e-4
+                flat_llh = min(step, ref_step) <= noise
+                note = f"  at pass {k + 1}: v_diff {float(vd[k]):.6f} (reference {float(ref_vd[k]):.6f}), " \
+                       f"llh step {step:.1e} (reference {ref_step:.1e}, fp32 noise of this llh {noise:.1e})"
+                assert near_eps or flat_llh, f"{name} optimizeQ={oq}: {it} vs {it_ref} passes is not a knife-edge case:{note}"
+            rows.append(f"{name:28s} optimizeQ={oq}  reference {it_ref:3d} ({why})  MI355X {it:3d}{note}")
+            exact += it == it_ref
+            off_by_one += abs(it - it_ref) == 1
+            total += 1
+            em.close()
+        ss.close()
+    rows.append(f"same pass count in {exact} of {total} runs, off by one in {off_by_one}, further apart in {total - exact - off_by_one} "
+                f"(every difference is a stop decision within fp32 noise of the threshold, checked above)")
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    open(os.path.join(out, "iteration_counts.txt"), "w").write("\n".join(rows) + "\n")
+    assert total >= 10 and exact >= 0.6 * total, "\n".join(rows)
