@@ -1,46 +1,7 @@
-// gfx950 kernel of the fused EM pass with GROUPED motif columns (orders K <= 2).
-//
-// Same computation as k_em_seq (kernels.hip): EM::EStep refinement/EM.cpp:149-196, EM::MStep
-// EM.cpp:231-243 and the sum over r of EM.cpp:509-513 -- file:line relative to /root/reference/src.
-//
-// k_em_seq is bound by the LDS pipe: per (position, column) one odds-table gather and one count
-// add.  Here G neighbouring columns share ONE table row.  The row index of position p is the
-// (K+G)-mer ending at p -- 5 bases (1024 rows, G = 5-K) when the tables fit the 160 KiB of a CU,
-// else 4 bases (256 rows, G = 4-K) -- and the table entry of group t is the product of its G column
-// odds, so a window costs T = ceil(W/G) gathers / adds instead of W (7 instead of 20 at K=2, W=20):
-//
-//   U_t(p) = U_{t-1}(p-G) * sG[row(p)][t],      row(p) = kmer_[p] mod 4^(K+G)
-//   nG[t][row(p)] += r(window)                  (marginalised to n[j][y] once per block)
-//
-// What keeps this exact:
-//   * EM.cpp:167 truncation (positions >= L-W+1 take no part): a group cut by that edge only carries
-//     its leading columns.  Two table layouts (grp_geometry, chosen per launch): "partial" table rows
-//     for those G-1 group ends, or per-wave virtual rows like the ones below; beyond the edge the
-//     neutral row.
-//   * N randomisation (Sequence.cpp:38): next to an exception the k-mers of neighbouring positions
-//     disagree, so no (K+G)-mer describes the group.  Those group ends (a handful per sequence:
-//     the strand junction) get per-wave VIRTUAL rows: a few "fix" lanes compute their G-column
-//     products from the single-column table before the chain starts (the exact y of the positions
-//     involved travels inline with the sequence record), and after the M-step move what the
-//     virtual count rows collected into single-column bins.  The chain itself never sees an
-//     exception.  Sequences whose exceptions span more than the virtual rows go through k_em_seq
-//     instead (bamm_em_create splits the buckets).
-//   * counts are 64-bit fixed point (2^-40) as in k_em_seq: sums are exact and order-free, so the
-//     result is bit-identical to k_em_seq's for the same responsibilities.
-// Window products are rounded in a different order than the reference's left-to-right product
-// (groups first): relative difference of a few 2^-24, inside the 1e-5 parity bar.
-//
-// What makes it fast beyond the smaller instruction count: wave priorities by
-// phase (the LDS-bound M-step ahead of the VALU-bound E-step), table rows padded to an odd number of
-// quads (rows start on all 16 bank-quads), a straight-line E-chain, the group index of the count
-// table in the add's immediate offset.
-//
-// Things measured and left out: a compacted list of the non-zero windows for
-// the M-step (built three ways; an LDS add costs in proportion to its active lanes, so 14 full adds
-// plus the list's writes, row reads and waits never beat the 49 sparse ones); the virtual-row counts
-// as no-return atomics on an HBM table instead of the LDS one (+0.19 ms per pass); per-step guards on
-// the run-time group count in the E-chain (each merge point costs M register moves: the chain is
-// straight-line over padded neutral slots instead).
+// Host side of the grouped-column EM kernel (k_em_grp, grouped_kernel.h has the kernel and its design notes):
+// which length classes it is built for, the LDS geometry of its tables, the planner that picks group size,
+// private copies and table layout for a (K, W), and the dispatch of the 2..16 positions-per-lane classes
+// (20..32 live in grouped_long.hip, 40 / 48 in grouped_xl.hip: translation units of their own, compiled side by side).
 
 #include "grouped_kernel.h"
 

@@ -287,7 +287,7 @@ def main():
     llh, vdiff, _ = em.trace()
 
     g_seqs, o_seqs, _ = em.plan()
-    kernel_name = ("k_e_slice + k_m_slice (column-sliced E and M passes)" if K >= 4 else
+    kernel_name = ("k_em_seq (E pass, compacted lists of the non-zero windows) + k_m_list x slices (column-sliced M pass)" if K >= 4 else
                    "k_em_grp (fused E+M, grouped columns)" if o_seqs == 0 else
                    "k_em_seq (fused E+M)" if g_seqs == 0 else "k_em_grp + k_em_seq (fused E+M)")
     if rank == 0:

@@ -4,7 +4,7 @@
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 run() {
   echo "cfg: $*"
-  python3 bench.py --no-cpu-baseline "$@" 2>/dev/null | python3 -c '
+  python3 bench.py --no-cpu-baseline --no-extras "$@" 2>/dev/null | python3 -c '
 import json,sys
 d=json.loads(sys.stdin.read())
 print("%s | %.3f ms/iter | %.1f it/s | %.2e pos/s | %s" % (d["config"]["workload"], d["ms_per_step"], d["iterations_per_s"], d["value"], d["roofline"]["kernel"]))'

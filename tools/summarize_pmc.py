@@ -40,7 +40,7 @@ def hbm_bytes(m):
 
 
 XCDS, CUS = 8.0, 256.0
-seq_kernels = [k for k in summary if any(t in k for t in ("k_em_grp", "k_em_seq", "k_e_slice", "k_m_slice"))]
+seq_kernels = [k for k in summary if any(t in k for t in ("k_em_grp", "k_em_seq", "k_e_slice", "k_m_slice", "k_m_list", "k_long_em"))]
 updates = next((summary[k]["dispatches"] for k in summary if "k_update" in k), None)
 if args.order >= 4 and seq_kernels and updates:
     per_iter, parts = 0.0, {}
