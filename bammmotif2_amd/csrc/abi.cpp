@@ -257,7 +257,9 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
         const uint32_t lo = k->h_ex[e0].x, hi = k->h_ex[e1 - 1].x, L = s->h_len[n];
         const uint32_t hiB = std::min(hi + G - 1u, L - 1u);
         const uint32_t B = hiB - lo + 1u;
-        if (B > 8u || B + G - 1u > 12u || lo >= 4096u) { x.h_B[n] = 255; continue; }
+        // the record holds 12 seven-bit y fields (Y <= 64), or 9 ten-bit ones at K = 3 (Y = 256)
+        const uint32_t max_fields = K == 3u ? 9u : 12u;
+        if (B > 8u || B + G - 1u > max_fields || lo >= 4096u) { x.h_B[n] = 255; continue; }
         x.h_B[n] = (uint8_t)B;
         x.h_lo[n] = lo;
         uint32_t w3[3] = {0, 0, 0};
@@ -269,7 +271,8 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
                 while (e < e1 && (int64_t)k->h_ex[e].x < pos) e++;
                 y = (e < e1 && (int64_t)k->h_ex[e].x == pos) ? k->h_ex[e].y : stream_y(n, pos);
             }
-            w3[i >> 2] |= y << (7u * (i & 3u));
+            if (K == 3u) w3[i / 3u] |= y << (10u * (i % 3u));
+            else w3[i >> 2] |= y << (7u * (i & 3u));
         }
         xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
     }
@@ -807,7 +810,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     memset(em->h_status, 0, 8 * sizeof(float));
     // launches of one pass: every length bucket, split into the sequences the grouped-column kernel
     // takes (no exception, or all of them within its virtual rows) and the rest
-    const bool want_grouped = !sliced && prm->K <= 2u && c->use_grouped;
+    const bool want_grouped = !sliced && prm->K <= 3u && c->use_grouped;
     for (auto& b : seqs->buckets) {
         if (b.mclass == kLongClass) {                        // beyond the length classes: long_seq.hip
             EmBucket eb;

@@ -97,13 +97,14 @@ struct EmKernelArgs {
 // stand in for group ends next to an N exception (Sequence.cpp:38).
 struct GrpGeom {
     uint32_t G, T, Tq, delta;    // group size, groups = ceil(W/G), quads of groups, G*T - W neutral front columns
+    uint32_t Ts;                 // cells per (row, copy) of the count table: T, or T | 1 (layout bit 2)
     uint32_t Rf;                 // full rows = 4^(K+G)
     uint32_t layout, np;         // see grp_geometry(); partial classes of table rows (0 or G-1)
     uint32_t base[3], psize[3];  // partial class d (d+1 trailing positions neutral): first row, rows = 4^(K+G-1-d)
     uint32_t Rn, R0, Bj, Bv, Rtot;   // neutral row, first virtual row, virtual rows per wave for exceptions / in all, rows
     uint32_t rowstride;          // floats per row of the odds table [Rtot][Tq | 1][4] (odd number of quads)
     uint32_t off_sg, off_s1, off_stat, off_ng, off_n1, off_wave, wave_bytes;   // LDS byte offsets
-    uint32_t cap;                // unused (the grouped kernel has no sparse M-step)
+    uint32_t cap;                // K = 3 kernels: 1 = the single-column table is in LDS, 0 = read from global memory
     uint32_t lds_bytes;
 };
 

@@ -8,21 +8,27 @@
 namespace bamm {
 
 // length classes the grouped kernel is instantiated for: 2..48 positions per lane (a plan needs M >= G)
-bool grp_supported_class(int M, uint32_t K) { return K <= 2u && M >= 2 && M <= 48; }
+bool grp_supported_class(int M, uint32_t K) { return K <= 3u && M >= 2 && M <= 48; }
 // 4 / 3 / 2 / 1 waves per SIMD: the grouped kernel's register budget runs out one class earlier than k_em_seq's
 uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : (M <= 32 ? 512u : 256u)); }
 
 // layout: bit 0 = groups cut by the LW1 edge as per-wave virtual rows (else partial table rows),
-//         bit 1 = odd number of quads per table row
+//         bit 1 = odd number of quads per odds-table row,
+//         bit 2 = odd number of cells per count-table row: with an even number of groups T the rows of the
+//                 count table start on every 2nd / 4th / 8th bank pair only (T = 10: 80-byte rows reach half of
+//                 the banks, T = 8: a quarter) and the ds_add_u64 of a wave pile up there; one spare cell per row
+//                 spreads them over all banks (K = 3, W = 20: 1.88 -> see DESIGN.md)
 bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
                   GrpGeom* out) {
-    if (K > 2u || W == 0u || G < 2u || G > 4u || K + G > 5u || (int)G > M) return false;
+    if (K > 3u || W == 0u || G < 2u || G > 4u || K + G > 5u || (int)G > M) return false;
+    const bool fixg = K == 3u;                               // single-column table and virtual-row bins in global memory
     GrpGeom g{};
     g.G = G;
     g.T = (W + g.G - 1u) / g.G;
     if (g.T > 64u) return false;
     g.Tq = (g.T + 3u) / 4u;
     g.delta = g.G * g.T - W;
+    g.Ts = (layout & 4u) ? (g.T | 1u) : g.T;
     g.Rf = 1u << (2u * (K + g.G));
     g.layout = layout;
     g.np = (layout & 1u) ? 0u : g.G - 1u;
@@ -38,33 +44,47 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
     // row, i.e. K-1+G group ends; two more rows cover "NN" and "N.N"), G-1 more for the group ends cut
     // by the LW1 edge when the table has no partial rows for them; one fix lane per (row, group)
     const uint32_t edge = (layout & 1u) ? g.G - 1u : 0u;
-    g.Bj = std::min(8u, K + g.G + 1u);
-    while (g.Bj > 0u && (g.Bj + edge) * g.T > 64u) g.Bj--;
-    if ((g.Bj + edge) * g.T > 64u) return false;
-    g.Bv = g.Bj + edge;
-    g.Rtot = g.R0 + waves * g.Bv;
     const uint32_t Y = 1u << (2u * (K + 1u));
     auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
-    uint32_t off = 0;
-    // layout bit 1, an odd number of quads per row: rows then start on all 16 bank-quads, not on every 2nd / 4th one,
-    // and the 16 lanes of a ds_read_b128 group that read the same quad index of random rows spread over
-    // all of them (with 2 quads per row a group shared 8)
-    g.rowstride = ((layout & 2u) ? (g.Tq | 1u) : g.Tq) * 4u;
-    g.off_sg = off; off = up16(off + g.rowstride * g.Rtot * 4u);
-    g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
-    g.off_stat = off; off = up16(off + 16u * 3u * 8u);
-    g.off_ng = off;
-    if (accum) off = up16(off + ((g.T * g.Rtot) << logC) * 8u);
-    g.off_n1 = off;
-    if (accum) off = up16(off + W * Y * 8u);
-    g.off_wave = off;
     const uint32_t kLds = 160u * 1024u;
-    g.cap = 0;
-    g.wave_bytes = 0u;
-    off += waves * g.wave_bytes;
-    g.lds_bytes = off;
+    // everything that depends on the number of virtual rows per wave; s1_lds: the single-column table in LDS
+    auto lay_out = [&](uint32_t Bj, bool s1_lds) {
+        g.Bj = Bj;
+        g.Bv = g.Bj + edge;
+        g.Rtot = g.R0 + waves * g.Bv;
+        uint32_t off = 0;
+        // layout bit 1, an odd number of quads per row: rows then start on all 16 bank-quads, not on every 2nd / 4th
+        // one, and the 16 lanes of a ds_read_b128 group that read the same quad index of random rows spread over
+        // all of them (with 2 quads per row a group shared 8)
+        g.rowstride = ((layout & 2u) ? (g.Tq | 1u) : g.Tq) * 4u;
+        g.off_sg = off; off = up16(off + g.rowstride * g.Rtot * 4u);
+        g.off_s1 = off; if (s1_lds) off = up16(off + W * (Y + 1u) * 4u);
+        g.off_stat = off; off = up16(off + 16u * 3u * 8u);
+        g.off_ng = off;
+        if (accum) off = up16(off + ((g.Ts * g.Rtot) << logC) * 8u);
+        g.off_n1 = off;
+        if (accum && !fixg) off = up16(off + W * Y * 8u);
+        g.off_wave = off;
+        g.cap = s1_lds ? 1u : 0u;                            // K = 3 kernels: where the single-column table lives
+        g.wave_bytes = 0u;
+        g.lds_bytes = off;
+        return off <= kLds;
+    };
+    uint32_t Bj = std::min(8u, K + g.G + 1u);
+    while (Bj > 0u && (Bj + edge) * g.T > 64u) Bj--;
+    if ((Bj + edge) * g.T > 64u) return false;
+    bool ok;
+    if (!fixg) {
+        ok = lay_out(Bj, true);
+    } else {
+        // K = 3: the single-column table (fix lanes only) stays in LDS when it fits -- a fix lane that has to
+        // fetch its odds through L2 stalls its wave once per sequence -- if need be with one virtual row per
+        // wave fewer (K-1+G rows cover one N; "NN" / "N.N" then go to the per-column kernel); else global memory
+        const uint32_t Bmin = std::min(Bj, K - 1u + g.G);
+        ok = lay_out(Bj, true) || lay_out(Bmin, true) || lay_out(Bj, false);
+    }
     *out = g;
-    return off <= kLds;
+    return ok;
 }
 
 // group size and private copies for (K, W): wider groups first (fewer gathers / adds per window),
@@ -78,12 +98,13 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
     // anyway: virtual edge rows cost them nothing extra, save the decode's partial-row patches and make
     // the tables small enough for the odd stride (K=2: 1.08 -> 1.01 ms, K=1: 1.05 -> 0.98 ms).  Clean
     // sets (single strand, K=0) would pay the fix lanes for the edge alone (+11 %): partial rows there.
-    const uint32_t order_exc[3] = {3u, 2u, 0u}, order_clean[3] = {2u, 0u, 3u};
+    // each with the count rows padded to an odd number of cells first (bit 2; the same thing when T is odd)
+    const uint32_t order_exc[6] = {7u, 3u, 6u, 2u, 4u, 0u}, order_clean[6] = {6u, 2u, 4u, 0u, 7u, 3u};
     for (uint32_t G = 5u - K; G >= 2u && G + 1u >= 5u - K; G--) {          // G = 5-K, then 4-K
         if (G > 4u || (forced && G != forced)) continue;
-        for (int li = 0; li < 3; li++) {
+        for (int li = 0; li < 6; li++) {
             const uint32_t layout = many_exceptions ? order_exc[li] : order_clean[li];
-            if (forced_layout >= 0 && (uint32_t)forced_layout != layout) continue;
+            if (forced_layout >= 0 && (uint32_t)forced_layout != (layout & 3u)) continue;   // the tuning switch names bits 0-1
             for (int lc = 2; lc >= 0; lc--) {
                 GrpGeom g;
                 if (grp_geometry(K, W, G, M, waves, true, (uint32_t)lc, layout, &g)) {

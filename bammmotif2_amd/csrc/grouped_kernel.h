@@ -155,16 +155,23 @@ __device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]
 template <int M, int G, int KG, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     static_assert(M >= G, "a group must not span more than two lanes");
+    // K = 3 (the only order with two columns per 5-mer row): odds and count tables of 10+ groups leave no LDS
+    // for the single-column table and the bins of the virtual rows.  Both serve the few fix lanes only, so
+    // there they live in global memory: fix lanes read `s` through L2 and add the virtual rows' counts straight
+    // into the pass's accumulator; the sequence record carries 10-bit y fields (Y = 256).
+    constexpr bool FIXG = (KG - G == 3);
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const EmKernelArgs& a = ga.e;
     const GrpGeom& g = ga.g;
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
-    const uint32_t T = g.T, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
+    const uint32_t T = g.T, Ts = g.Ts, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
     const uint32_t pad = 4u * Tq - T;                     // neutral table slots in front of the first real group
     float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Rtot][Tq][4]
-    float* s1 = reinterpret_cast<float*>(lds_raw + g.off_s1);                             // [W][Y+1]
+    // [W][Y+1]; K = 3: in LDS when the geometry found room for it (g.cap), else the global table read through L2
+    // (the pointer is then generic: flat loads)
+    const float* s1 = (FIXG && g.cap == 0u) ? a.s : reinterpret_cast<const float*>(lds_raw + g.off_s1);
     double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
-    // count table [Rtot][C][T], groups stored last to first: the M-step walks them in that order and
+    // count table [Rtot][C][Ts] (Ts = T or T | 1: geometry), groups stored last to first: the M-step walks them in that order and
     // reaches a (row, copy)'s next group through the add's immediate offset
     unsigned long long* ng = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);
     unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // [W][Y]: counts of the virtual rows
@@ -180,8 +187,11 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
 
     // ---- block prologue: single-column table, grouped table, zeroed counts
-    for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1[i] = a.s[i];
-    __syncthreads();
+    if (!FIXG || g.cap != 0u) {
+        float* s1w = reinterpret_cast<float*>(lds_raw + g.off_s1);
+        for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1w[i] = a.s[i];
+        __syncthreads();
+    }
     for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
         uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
         if (row < g.Rf) { nreal = G; code = row; }
@@ -209,8 +219,9 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         sg[row * g.rowstride + slot] = 1.0f;
     }
     if (ACCUM) {
-        for (uint32_t i = threadIdx.x; i < (T * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
-        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
+        for (uint32_t i = threadIdx.x; i < (Ts * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
+        if constexpr (!FIXG)
+            for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
     }
     __syncthreads();
 
@@ -342,8 +353,13 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     if (fixJ) {
                         const uint32_t k = lane_b + (uint32_t)c;           // entry of position xlo-G+1+k
                         pos = xlo + k - (uint32_t)(G - 1);                 // wraps for positions before the sequence
-                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
-                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                        if constexpr (FIXG) {                              // 10-bit fields, three per word
+                            const uint32_t word = (k < 3u) ? cur.xr.y : ((k < 6u) ? cur.xr.z : cur.xr.w);
+                            yc = (word >> (10u * (k % 3u))) & 0x3ffu;
+                        } else {
+                            const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                            yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                        }
                     } else {
                         pos = LW1 + (lane_b - g.Bj) - (uint32_t)(G - 1) + (uint32_t)c;
                         yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);   // only used when pos < LW1
@@ -447,7 +463,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
-                    rad[m] = ng_base + (((row[m] << logC) + copy) * T) * 8u;
+                    rad[m] = ng_base + (((row[m] << logC) + copy) * Ts) * 8u;
                 }
                 // F is a ring: after s steps logical slot m lives in F[(m + G*s) mod M]; the G slots
                 // that arrive from the next lane are shifted in place with one DPP pair each, and their
@@ -488,13 +504,16 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 wave_lds_sync();
                 if (fix) {
                     unsigned long long acc = 0ull;
-                    unsigned long long* cell = ng + ((size_t)((vbase + lane_b) << logC)) * T + (T - 1u - lane_t);
-                    for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[(size_t)c * T]; cell[(size_t)c * T] = 0ull; }
+                    unsigned long long* cell = ng + ((size_t)((vbase + lane_b) << logC)) * Ts + (T - 1u - lane_t);
+                    for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[(size_t)c * Ts]; cell[(size_t)c * Ts] = 0ull; }
                     if (acc != 0ull) {
 #pragma unroll
                         for (int c = 0; c < G; c++) {
                             const int col = (int)(G * lane_t + c) - (int)delta;
-                            if (yfix[c] != Y) atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
+                            if (yfix[c] != Y) {
+                                if constexpr (FIXG) acc_add(a.acc + (size_t)yfix[c] * W + (uint32_t)col, (long long)acc);
+                                else atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
+                            }
                         }
                     }
                 }
@@ -517,7 +536,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         for (uint32_t o = threadIdx.x; o < W * Y; o += blockDim.x) {       // o = y*W + j: consecutive global cells
             const uint32_t yy = o / W, j = o - yy * W, i = j * Y + yy;
             const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
-            unsigned long long acc = n1[i];
+            unsigned long long acc = FIXG ? 0ull : n1[i];
             const unsigned long long* tab = ng + (T - 1u - t);          // + ((row << logC) + copy) * T
             // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free
             {
@@ -527,7 +546,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
                         // h digits above y overlap y's own upper digits unless c digits are really free:
                         // the (K+G)-mer has exactly c digits above y_c, so the mask above is a no-op
-                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
+                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * Ts];
                     }
             }
 #pragma unroll
@@ -538,7 +557,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     for (uint32_t h = 0; h < (1u << (2u * c)); h++)
                         for (uint32_t l = 0; l < (1u << lowd); l++) {
                             const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
-                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * T];
+                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * Ts];
                         }
                 }
             }
@@ -581,6 +600,7 @@ int launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t bl
 // one length class of the dispatch switch (key = class * 64 + G * 8 + K + G), every (G, K+G) the planner can ask for
 #define BAMM_GRP_CASES(idx, M, T)                                                                           \
     case idx * 64 + 2 * 8 + 4: if (int rc = launch_variant<M, 2, 4, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
+    case idx * 64 + 2 * 8 + 5: if (int rc = launch_variant<M, 2, 5, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
     case idx * 64 + 3 * 8 + 4: if (int rc = launch_variant<M, 3, 4, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
     case idx * 64 + 4 * 8 + 4: if (int rc = launch_variant<M, 4, 4, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \
     case idx * 64 + 3 * 8 + 5: if (int rc = launch_variant<M, 3, 5, T>(accum, write_r, a, blocks, threads, st)) return rc; break;   \

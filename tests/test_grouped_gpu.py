@@ -1,7 +1,7 @@
 """The grouped-column kernel (bammmotif2_amd/csrc/grouped.hip) against the pinned oracle, and against
-the one-column-at-a-time kernel it replaces for orders K <= 2.
+the one-column-at-a-time kernel it replaces for orders K <= 3.
 
-What is specific to it and therefore tested here: G = 4-K columns per table row (K = 0, 1, 2), the
+What is specific to it and therefore tested here: G = 5-K or 4-K columns per table row (K = 0..3), the
 partial rows at the EM.cpp:167 truncation edge (W not a multiple of G, W < G), the virtual rows next
 to N exceptions (Sequence.cpp:38; the strand junction of every double-stranded sequence, and N inside
 a sequence), the split of a bucket into sequences the kernel takes and the rest, and every length
@@ -51,6 +51,15 @@ GROUPED_CASES = [
     dict(name="g_k2_m2_ds", N=200, L0=40, W=12, K=2, n_frac=0.002, ragged=6),        # L 69..93: G = 2
     dict(name="g_k2_m3_ds", N=160, L0=80, W=10, K=2, n_frac=0.002, ragged=12),       # L 137..185: G = 3
     dict(name="g_k1_m3_ss", N=160, L0=160, W=8, K=1, ss=True, ragged=30),            # G = 3 (4 does not fit a lane)
+    # K = 3: two columns per 5-mer row, single-column table and virtual-row bins in global memory, 10-bit record fields
+    dict(name="g_k3_ds_m7", N=120, L0=200, W=20, K=3, n_frac=0.002, ragged=0),       # the bench shape at k = 3
+    dict(name="g_k3_ds_m5_odd", N=80, L0=150, W=13, K=3, n_frac=0.004, ragged=20),   # W odd: a group cut in front
+    dict(name="g_k3_ss", N=64, L0=300, W=10, K=3, ss=True, n_frac=0.005, ragged=40),
+    dict(name="g_k3_w1", N=40, L0=160, W=1, K=3, ragged=12),
+    dict(name="g_k3_w22", N=32, L0=260, W=22, K=3, ragged=10),                       # the widest motif whose tables fit
+    dict(name="g_k3_m16_24", N=20, L0=560, W=16, K=3, n_frac=0.001, ragged=100),     # L 921..1121
+    dict(name="g_k3_m40_48", N=8, L0=1400, W=12, K=3, n_frac=0.0005, ragged=200),    # L 2401..2801
+    dict(name="g_k3_m2_ds", N=200, L0=40, W=8, K=3, n_frac=0.002, ragged=6),
 ]
 
 
@@ -110,7 +119,10 @@ def test_grouped_kernel_matches_exact_arithmetic(spec, gpu_ctx, orc):
     em.close(); ss.close()
 
 
-@pytest.mark.parametrize("spec", GROUPED_CASES[:5], ids=[d["name"] for d in GROUPED_CASES[:5]])
+_VS_PER_COLUMN = GROUPED_CASES[:5] + [d for d in GROUPED_CASES if d["name"] in ("g_k3_ds_m7", "g_k3_ds_m5_odd")]
+
+
+@pytest.mark.parametrize("spec", _VS_PER_COLUMN, ids=[d["name"] for d in _VS_PER_COLUMN])
 def test_grouped_equals_per_column_kernel(spec, gpu_ctx, orc):
     """Same handle twice, once with the grouped kernel switched off: counts are sums of the same
     fixed-point addends up to the rounding of r, llh and q chain identically."""
