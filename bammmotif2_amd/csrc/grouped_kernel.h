@@ -186,13 +186,38 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     RawSeqG<M> nxt{};
     if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
 
-    // ---- block prologue: single-column table, grouped table, zeroed counts
-    if (!FIXG || g.cap != 0u) {
+    // ---- block prologue: single-column table, grouped table, zeroed counts.  The loads of `s` are issued
+    // first and everything that does not need them (zeroed counts, neutral slots) runs under their latency.
+    const bool s1_to_lds = !FIXG || g.cap != 0u;
+    const bool s1_in_regs = s1_to_lds && W * Ys <= 2u * blockDim.x;      // at most two cells per thread: K <= 2 at usual widths
+    float s1_r0 = 1.0f, s1_r1 = 1.0f;
+    if (s1_in_regs) {
+        if (threadIdx.x < W * Ys) s1_r0 = a.s[threadIdx.x];
+        if (threadIdx.x + blockDim.x < W * Ys) s1_r1 = a.s[threadIdx.x + blockDim.x];
+    }
+    if (ACCUM) {
+        for (uint32_t i = threadIdx.x; i < (Ts * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
+        if constexpr (!FIXG)
+            for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
+    }
+    // the neutral row and the virtual rows as a whole (the real slots of a virtual row are rewritten per sequence)
+    for (uint32_t i = threadIdx.x; i < (Rtot - Rn) * 4u * Tq; i += blockDim.x) {
+        const uint32_t row = Rn + i / (4u * Tq), slot = i % (4u * Tq);
+        sg[row * g.rowstride + slot] = 1.0f;
+    }
+    if (s1_to_lds) {
         float* s1w = reinterpret_cast<float*>(lds_raw + g.off_s1);
-        for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1w[i] = a.s[i];
+        if (s1_in_regs) {
+            if (threadIdx.x < W * Ys) s1w[threadIdx.x] = s1_r0;
+            if (threadIdx.x + blockDim.x < W * Ys) s1w[threadIdx.x + blockDim.x] = s1_r1;
+        } else {
+            for (uint32_t i = threadIdx.x; i < W * Ys; i += blockDim.x) s1w[i] = a.s[i];
+        }
         __syncthreads();
     }
-    for (uint32_t row = threadIdx.x; row <= Rn; row += blockDim.x) {       // a row per thread, its T groups in a loop
+    // a table row per thread (1024 full rows = one each at 1024 threads; the neutral row was filled above), its T
+    // groups in a loop: the G column odds of a group multiplied in column order
+    for (uint32_t row = threadIdx.x; row < Rn; row += blockDim.x) {
         uint32_t nreal = 0, code = 0;                          // leading positions of the group that are real
         if (row < g.Rf) { nreal = G; code = row; }
 #pragma unroll
@@ -201,6 +226,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         uint32_t yc[G];
 #pragma unroll
         for (int c = 0; c < G; c++) yc[c] = (code >> (2u * ((nreal - 1u - c) & 15u))) & (Y - 1u);
+        float* out = sg + row * g.rowstride;
+        for (uint32_t slot = 0; slot < pad; slot++) out[slot] = 1.0f;       // neutral slots in front
         for (uint32_t t = 0; t < T; t++) {
             float f = 1.0f;
 #pragma unroll
@@ -208,20 +235,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 const int col = (int)(G * t + c) - (int)delta;
                 if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
             }
-            sg[row * g.rowstride + pad + t] = f;
+            out[pad + t] = f;
         }
-        for (uint32_t slot = 0; slot < pad; slot++) sg[row * g.rowstride + slot] = 1.0f;   // neutral slots in front
-    }
-    // the virtual rows as a whole (their real slots are rewritten per sequence); a table row's neutral
-    // slots were written with the row
-    for (uint32_t i = threadIdx.x; i < (Rtot - Rn - 1u) * 4u * Tq; i += blockDim.x) {
-        const uint32_t row = Rn + 1u + i / (4u * Tq), slot = i % (4u * Tq);
-        sg[row * g.rowstride + slot] = 1.0f;
-    }
-    if (ACCUM) {
-        for (uint32_t i = threadIdx.x; i < (Ts * Rtot) << logC; i += blockDim.x) ng[i] = 0ull;
-        if constexpr (!FIXG)
-            for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
     }
     __syncthreads();
 
@@ -538,27 +553,35 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
             unsigned long long acc = FIXG ? 0ull : n1[i];
             const unsigned long long* tab = ng + (T - 1u - t);          // + ((row << logC) + copy) * T
-            // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free
+            // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free -- 4^(G-1) rows
+            // whatever c is.  One flat loop with a compile-time trip count (the digit split is data, not loop
+            // bounds: lanes of a wave differ in c) and independent loads: as nested loops over (h, l) with
+            // per-lane bounds the wave ran the union of the lanes' iterations with every load waited for, 3.6 us
+            // per cell and half of a launch's fixed cost.
             {
-                const uint32_t lowd = 2u * ((uint32_t)G - 1u - c);
-                for (uint32_t h = 0; h < (1u << (2u * c)); h++)
-                    for (uint32_t l = 0; l < (1u << lowd); l++) {
-                        const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
-                        // h digits above y overlap y's own upper digits unless c digits are really free:
-                        // the (K+G)-mer has exactly c digits above y_c, so the mask above is a no-op
-                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * Ts];
-                    }
+                constexpr uint32_t NR = 1u << (2u * (uint32_t)(G - 1));
+                const uint32_t lowd = 2u * ((uint32_t)G - 1u - c), lmask = (1u << lowd) - 1u;
+                unsigned long long part[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+                for (uint32_t r = 0; r < NR; r++) {
+                    const uint32_t h = r >> lowd, l = r & lmask;
+                    // the (K+G)-mer has exactly c digits above y_c, so the mask is a no-op
+                    const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
+                    for (uint32_t cc = 0; cc < C; cc++) part[r & 3u] += tab[(((size_t)row << logC) + cc) * Ts];
+                }
+                acc += (part[0] + part[1]) + (part[2] + part[3]);
             }
 #pragma unroll
             for (uint32_t d = 0; d < (uint32_t)(G - 1); d++) {   // partial rows: positions c < G-1-d are real
                 const uint32_t nreal = (uint32_t)G - 1u - d;
                 if (d < g.np && c < nreal) {
-                    const uint32_t lowd = 2u * (nreal - 1u - c);
-                    for (uint32_t h = 0; h < (1u << (2u * c)); h++)
-                        for (uint32_t l = 0; l < (1u << lowd); l++) {
-                            const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
-                            for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * Ts];
-                        }
+                    const uint32_t NRp = 1u << (2u * (nreal - 1u));
+                    const uint32_t lowd = 2u * (nreal - 1u - c), lmask = (1u << lowd) - 1u;
+                    for (uint32_t r = 0; r < NRp; r++) {
+                        const uint32_t h = r >> lowd, l = r & lmask;
+                        const uint32_t row = g.base[d] + ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l);
+                        for (uint32_t cc = 0; cc < C; cc++) acc += tab[(((size_t)row << logC) + cc) * Ts];
+                    }
                 }
             }
             if (acc) acc_add(a.acc + o, (long long)acc);
