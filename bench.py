@@ -360,7 +360,11 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
 
-    em.close(); seqs.close(); ctx.close()
+    em.close(); seqs.close()
+    for obj in keep:
+        if isinstance(obj, bm.Comm):
+            obj.close()
+    ctx.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
