@@ -152,6 +152,9 @@ struct bamm_em {
     float* d_list_r = nullptr;
     uint16_t* d_list_p = nullptr;
     uint32_t* d_list_n = nullptr;
+    // K = 3 through the grouped kernel: per-wave log of the virtual rows' counts (grouped_kernel.h), grown on demand
+    unsigned long long* d_fix_log = nullptr;
+    size_t fix_log_words = 0;
     ExcK* exc = nullptr;
     bool estep_done = false;
     float llh_prev = 0.0f;                      // EM.h:61
@@ -352,6 +355,18 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
     if (!grp_geometry(em->prm.K, em->prm.W, eb.G, kMClasses[eb.mclass], threads / 64u, accum, accum ? eb.logc : 0u, eb.layout, &ga.g)) {
         set_error("grouped kernel geometry does not fit (K=%u W=%u)", em->prm.K, em->prm.W);
         return BAMM_ERR_UNSUPPORTED;
+    }
+    if (em->prm.K == 3u && accum) {
+        const size_t waves = (size_t)eb.blocks * (threads / 64u);
+        const size_t cap = ((eb.count + waves - 1) / waves) * std::min<size_t>(64, (size_t)ga.g.Bv * ga.g.T);   // entries per wave
+        const size_t need = waves * cap * 2;                  // 16-byte entries, in 8-byte words
+        if (need > em->fix_log_words) {
+            if (em->d_fix_log) { BAMM_HIP(hipStreamSynchronize(st)); BAMM_HIP(hipFree(em->d_fix_log)); em->d_fix_log = nullptr; em->fix_log_words = 0; }
+            if (int rc = dev_alloc(&em->d_fix_log, need)) return rc;
+            em->fix_log_words = need;
+        }
+        ga.fix_log = em->d_fix_log;
+        ga.fix_log_cap = (uint32_t)cap;
     }
     return launch_em_grp(eb.mclass, accum, write_r, ga, eb.blocks, threads, st);
 }
@@ -691,7 +706,7 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->acc_external ? nullptr : em->d_acc),
-                    (void*)em->d_state, (void*)em->d_list_r, (void*)em->d_list_p, (void*)em->d_list_n, (void*)em->d_s_alt,
+                    (void*)em->d_state, (void*)em->d_list_r, (void*)em->d_list_p, (void*)em->d_list_n, (void*)em->d_s_alt, (void*)em->d_fix_log,
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
                     (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})

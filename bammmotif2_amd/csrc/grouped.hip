@@ -21,7 +21,7 @@ uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : (M <
 bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
                   GrpGeom* out) {
     if (K > 3u || W == 0u || G < 2u || G > 4u || K + G > 5u || (int)G > M) return false;
-    const bool fixg = K == 3u;                               // single-column table and virtual-row bins in global memory
+    const bool fixg = K == 3u;                               // single-column table in global memory unless it fits, bins in the epilogue
     GrpGeom g{};
     g.G = G;
     g.T = (W + g.G - 1u) / g.G;
@@ -64,6 +64,11 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
         if (accum) off = up16(off + ((g.Ts * g.Rtot) << logC) * 8u);
         g.off_n1 = off;
         if (accum && !fixg) off = up16(off + W * Y * 8u);
+        // K = 3: no room beside the tables; the bins take the odds table's place once the block's sequences are done
+        if (fixg) {
+            g.off_n1 = g.off_sg;
+            if (accum && W * Y * 8u > g.rowstride * g.Rtot * 4u) return false;
+        }
         g.off_wave = off;
         g.cap = s1_lds ? 1u : 0u;                            // K = 3 kernels: where the single-column table lives
         g.wave_bytes = 0u;

@@ -156,9 +156,14 @@ template <int M, int G, int KG, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     static_assert(M >= G, "a group must not span more than two lanes");
     // K = 3 (the only order with two columns per 5-mer row): odds and count tables of 10+ groups leave no LDS
-    // for the single-column table and the bins of the virtual rows.  Both serve the few fix lanes only, so
-    // there they live in global memory: fix lanes read `s` through L2 and add the virtual rows' counts straight
-    // into the pass's accumulator; the sequence record carries 10-bit y fields (Y = 256).
+    // for the bins of the virtual rows (41 KB) and often none for the single-column table.  Both serve the few
+    // fix lanes only.  The single-column table is read through L2 when the geometry finds no room for it.  What
+    // a fix lane takes out of its virtual count row is LOGGED (the non-zero sums of a sequence, compacted: 16
+    // bytes each, plain stores) and folded in the block epilogue, when the odds table's LDS is free for the
+    // bins.  Adding those counts
+    // straight into the pass's accumulator with global atomics (round 2's first version) cost 0.5-1.6 ms per
+    // pass: a CU retires one scattered device-scope atomic per ~18 ns (tools/atomic_scatter_bench.hip), and a
+    // sequence issued 14-19 of them.  The sequence record carries 10-bit y fields (Y = 256).
     constexpr bool FIXG = (KG - G == 3);
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const EmKernelArgs& a = ga.e;
@@ -167,9 +172,11 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     const uint32_t T = g.T, Ts = g.Ts, Tq = g.Tq, Rtot = g.Rtot, Rn = g.Rn, delta = g.delta;
     const uint32_t pad = 4u * Tq - T;                     // neutral table slots in front of the first real group
     float* sg = reinterpret_cast<float*>(lds_raw + g.off_sg);                             // [Rtot][Tq][4]
-    // [W][Y+1]; K = 3: in LDS when the geometry found room for it (g.cap), else the global table read through L2
-    // (the pointer is then generic: flat loads)
-    const float* s1 = (FIXG && g.cap == 0u) ? a.s : reinterpret_cast<const float*>(lds_raw + g.off_s1);
+    // [W][Y+1]; K = 3: in LDS when the geometry found room for it (g.cap), else the global table read through L2.
+    // Two explicit paths (a pointer chosen at run time would be generic: flat loads count on both memory counters)
+    const float* s1_lds = reinterpret_cast<const float*>(lds_raw + g.off_s1);
+    const bool s1_global = FIXG && g.cap == 0u;
+    auto s1_at = [&](uint32_t idx) -> float { return s1_global ? a.s[idx] : s1_lds[idx]; };
     double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
     // count table [Rtot][C][Ts] (Ts = T or T | 1: geometry), groups stored last to first: the M-step walks them in that order and
     // reaches a (row, copy)'s next group through the add's immediate offset
@@ -233,7 +240,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
             for (int c = 0; c < G; c++) {
                 const int col = (int)(G * t + c) - (int)delta;
-                if ((uint32_t)c < nreal && col >= 0) f *= s1[(uint32_t)col * Ys + yc[c]];
+                if ((uint32_t)c < nreal && col >= 0) f *= s1_at((uint32_t)col * Ys + yc[c]);
             }
             out[pad + t] = f;
         }
@@ -250,6 +257,11 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     uint32_t seq_cnt = 0;
     uint32_t last_LW1 = 0;
     float pos_i = 0.0f;
+    // K = 3: this wave's log of virtual-row counts (see FIXG above): entries {sum, bins of its G columns}
+    [[maybe_unused]] ulonglong2* my_log = nullptr;
+    [[maybe_unused]] uint32_t nlog = 0;
+    if constexpr (FIXG && ACCUM)
+        my_log = reinterpret_cast<ulonglong2*>(ga.fix_log) + (size_t)(blockIdx.x * waves_per_block + wave) * ga.fix_log_cap;
 
     for (; t < a.sv.count; t += total_waves) {
         const RawSeqG<M> cur = nxt;
@@ -381,13 +393,12 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     }
                     if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
                     yfix[c] = yc;
-                    if (yc != Y) f *= s1[(uint32_t)col * Ys + yc];
+                    if (yc != Y) f *= s1_at((uint32_t)col * Ys + yc);
                 }
                 sg[(vbase + lane_b) * g.rowstride + pad + lane_t] = f;
             }
             wave_lds_sync();
         }
-
         // ---- E-step: slot p after group t holds the product of groups 0..t of the window whose
         // group t ends at p (EM.cpp:167-176); after the last group that is window p-(W-1)
         __builtin_amdgcn_s_setprio(2);                       // chain
@@ -517,20 +528,34 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             // ---- virtual count rows -> single-column bins (exact: one window per cell)
             if (any_fix) {
                 wave_lds_sync();
+                unsigned long long acc = 0ull;
                 if (fix) {
-                    unsigned long long acc = 0ull;
                     unsigned long long* cell = ng + ((size_t)((vbase + lane_b) << logC)) * Ts + (T - 1u - lane_t);
                     for (uint32_t c = 0; c < (1u << logC); c++) { acc += cell[(size_t)c * Ts]; cell[(size_t)c * Ts] = 0ull; }
-                    if (acc != 0ull) {
+                    if constexpr (!FIXG) {
+                        if (acc != 0ull) {
 #pragma unroll
-                        for (int c = 0; c < G; c++) {
-                            const int col = (int)(G * lane_t + c) - (int)delta;
-                            if (yfix[c] != Y) {
-                                if constexpr (FIXG) acc_add(a.acc + (size_t)yfix[c] * W + (uint32_t)col, (long long)acc);
-                                else atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
+                            for (int c = 0; c < G; c++) {
+                                const int col = (int)(G * lane_t + c) - (int)delta;
+                                if (yfix[c] != Y) atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
                             }
                         }
                     }
+                }
+                if constexpr (FIXG) {                            // the non-zero sums, compacted: {sum, bin of column 0 | bin of column 1 << 16}
+                    static_assert(!FIXG || G == 2, "two bins per entry");
+                    const unsigned long long nzm = __ballot(acc != 0ull);
+                    if (acc != 0ull) {
+                        uint32_t bins = 0;
+#pragma unroll
+                        for (int c = 0; c < G; c++) {
+                            const int col = (int)(G * lane_t + c) - (int)delta;
+                            bins |= ((yfix[c] != Y) ? (uint32_t)col * Y + yfix[c] : 0xffffu) << (16 * c);
+                        }
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
+                        my_log[nlog + rank] = make_ulonglong2(acc, (unsigned long long)bins);
+                    }
+                    nlog += (uint32_t)__builtin_popcountll(nzm);
                 }
                 wave_lds_sync();
             }
@@ -546,12 +571,42 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     }
     __syncthreads();
     if (a.acc == nullptr) return;                        // getR(): responsibilities only
+    if constexpr (FIXG && ACCUM) {
+        // the logged virtual-row counts -> single-column bins [j][y], which take the odds table's place (every
+        // wave is past its last sequence).  A wave reads back only what it wrote itself, after the barrier above
+        // (its stores have left the CU; the loads go to L2).
+        for (uint32_t i = threadIdx.x; i < W * Y; i += blockDim.x) n1[i] = 0ull;
+        __syncthreads();
+        // every lane takes entries of the wave's log, NB loads in flight
+        constexpr uint32_t NB = 8;
+        for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
+            unsigned long long acc[NB], bins[NB];
+#pragma unroll
+            for (uint32_t u = 0; u < NB; u++) {
+                const uint32_t e = e0 + u * 64u + (uint32_t)lane;
+                const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(my_log + min(e, nlog - 1u));
+                acc[u] = __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bins[u] = __hip_atomic_load(ent + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < NB; u++) {
+                if (e0 + u * 64u + (uint32_t)lane < nlog) {
+#pragma unroll
+                    for (int c = 0; c < G; c++) {
+                        const uint32_t bin = ((uint32_t)bins[u] >> (16 * c)) & 0xffffu;
+                        if (bin != 0xffffu) atomicAdd(&n1[bin], acc[u]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
     if (ACCUM) {
         const uint32_t C = 1u << logC;
         for (uint32_t o = threadIdx.x; o < W * Y; o += blockDim.x) {       // o = y*W + j: consecutive global cells
             const uint32_t yy = o / W, j = o - yy * W, i = j * Y + yy;
             const uint32_t t = (j + delta) / G, c = (j + delta) - t * G;
-            unsigned long long acc = FIXG ? 0ull : n1[i];
+            unsigned long long acc = n1[i];
             const unsigned long long* tab = ng + (T - 1u - t);          // + ((row << logC) + copy) * T
             // full rows whose position c carries yy: c higher digits, G-1-c lower digits are free -- 4^(G-1) rows
             // whatever c is.  One flat loop with a compile-time trip count (the digit split is data, not loop

@@ -209,15 +209,30 @@ def main():
     if use_dist and args.dist_backend == "nccl" and not args.torch_allreduce:
         # the library's own collective: ncclAllReduce(int64, sum) on the context's stream, no Python in the
         # loop.  Rank 0's unique id travels over the torch process group that also serves the barriers.
+        comm = None
         try:
-            uid = [bm.Comm.unique_id() if rank == 0 else None]
+            try:
+                uid = [bm.Comm.unique_id() if rank == 0 else None]
+            except Exception as e:                       # every rank must still take part in the broadcast
+                uid = [None]
+                print(f"[bench] rank {rank}: {e}", file=sys.stderr)
             dist.broadcast_object_list(uid, src=0)
+            if uid[0] is None:
+                raise RuntimeError("rank 0 could not create a communicator id")
             comm = bm.Comm.init_rank(ctx, uid[0], rank, world)
+        except Exception as e:   # report it, then fall back to the torch path below
+            print(f"[bench] rank {rank}: native RCCL path unavailable ({e})", file=sys.stderr)
+        # all ranks take the same path: one that failed pulls everybody to the torch collective
+        agreed = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=torch.device("cuda", local_rank))
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
             em.set_comm(comm)
             keep.append(comm)
             allreduce_kind = "rccl (libbamm_em, ncclAllReduce int64 on the kernels' stream)"
-        except Exception as e:   # report it, then fall back to the torch path below
-            print(f"[bench] native RCCL path unavailable ({e}); using torch.distributed.all_reduce", file=sys.stderr)
+        else:
+            if comm is not None:
+                comm.close()
+            print("[bench] using torch.distributed.all_reduce on every rank", file=sys.stderr)
     if use_dist and allreduce_kind == "none":
         allreduce_kind = "torch.distributed.all_reduce (%s) from a callback" % args.dist_backend
         _, n = em.reduce_buffer()

@@ -167,9 +167,11 @@ def test_group_sizes_agree(gpu_ctx, orc):
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-6)
 
 
-def test_grouped_with_fold_mask_and_optimize(gpu_ctx, orc):
-    """CV-fold mask + the full optimize() loop through the grouped kernel vs the oracle."""
-    c = Case(name="g_opt", N=400, L0=200, W=12, K=2, n_frac=0.0)
+@pytest.mark.parametrize("K", [2, 3])
+def test_grouped_with_fold_mask_and_optimize(K, gpu_ctx, orc):
+    """CV-fold mask + the full optimize() loop through the grouped kernel vs the oracle (K = 3: sequences the
+    mask skips leave no entry in the fix lanes' log)."""
+    c = Case(name="g_opt", N=400, L0=200, W=12, K=K, n_frac=0.0)
     seq, kmer, off, vbg = c.encode(orc)
     pk = bm.PackedSeqs.from_kmers(kmer, off)
     ss = bm.SeqSet(gpu_ctx, pk)

@@ -77,6 +77,107 @@ __global__ void __launch_bounds__(1024) k_mix(int iters, int active_per_64, floa
     if (acc == 12345.678f) sink[0] = acc;
 }
 
+
+// The LDS traffic of a COMPACTED M-step (not built into the kernel unless this wins): the
+// non-zero windows of a sequence (nnz of them, ~105 on the bench data) leave the lanes as (end position, r) pairs
+// in a per-wave list, every lane of a round takes one listed window, re-derives its T rows from a per-wave copy
+// of the 2-bit stream (26 words: broadcast reads, no bank conflicts) and issues T full adds.  Same 14 gathers.
+__global__ void __launch_bounds__(1024) k_mix_list(int iters, int active_per_64, int nnz, float* sink) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t sg_bytes = ROWS * ROWSTRIDE_B, ng_off = (sg_bytes + 15u) & ~15u;
+    const uint32_t wave_off = ng_off + ROWS * T * 8u;                  // per wave: list 256 x 8 B, stream 32 words, region 64 floats
+    for (uint32_t i = threadIdx.x; i < (wave_off + 16u * (2048u + 128u + 256u)) / 4u; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1.0f;
+    __syncthreads();
+    const uint32_t sg_base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    const uint32_t ng_base = sg_base + ng_off;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t list_base = sg_base + wave_off + wave * (2048u + 128u + 256u), str_base = list_base + 2048u, reg_base = str_base + 128u;
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    float acc = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        uint32_t row[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) { x = x * 1664525u + 1013904223u; row[m] = (x >> 8) % ROWS; }
+        {
+            f32x4 v[2 * M];
+#pragma unroll
+            for (int m = 0; m < M; m++) v[m] = rd128<0>(sg_base + row[m] * ROWSTRIDE_B);
+#pragma unroll
+            for (int m = 0; m < M; m++) v[M + m] = rd128<16>(sg_base + row[m] * ROWSTRIDE_B);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+#pragma unroll
+            for (int m = 1; m < 2 * M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
+#pragma unroll
+            for (int m = 0; m < 2 * M; m++) acc += v[m].x;
+        }
+        // stream copy: lanes 0..25 one word each
+        if (lane < 26u) asm volatile("ds_write_b32 %0, %1" :: "v"(str_base + lane * 4u), "v"(x) : "memory");
+        // list: 7 predicated 8-byte writes, compacted (rank within the slot + running count)
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            x = x * 1664525u + 1013904223u;
+            const bool on = (int)((x >> 10) & 63u) < active_per_64;
+            const unsigned long long mk = __ballot(on);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+            if (on && cnt + rank < 256u) asm volatile("ds_write_b64 %0, %1" :: "v"(list_base + (cnt + rank) * 8u), "v"((unsigned long long)x) : "memory");
+            cnt += (uint32_t)__builtin_popcountll(mk);
+            // region copy of r for the fix lanes: 8 lanes
+            if ((lane & 7u) == 3u && lane < 64u) asm volatile("ds_write_b32 %0, %1" :: "v"(reg_base + (lane >> 3) * 28u + m * 4u), "v"(x) : "memory");
+        }
+        // rounds over the listed windows (nnz fixed by the caller so that runs are comparable)
+        for (int base = 0; base < nnz; base += 64) {
+            const bool on = (int)lane + base < nnz;
+            if (on) {
+                unsigned long long e;
+                uint32_t w0, w1, w2;
+                const uint32_t k = (x >> 7) % 24u;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(e) : "v"(list_base + ((lane + base) & 255u) * 8u));
+                asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(str_base + k * 4u));
+                asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(w1) : "v"(str_base + k * 4u));
+                asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(w2) : "v"(str_base + k * 4u));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(e), "+v"(w0), "+v"(w1), "+v"(w2));
+                x ^= (uint32_t)e ^ w0 ^ w1 ^ w2;
+                uint32_t h = x;
+#pragma unroll
+                for (int u = 0; u < T; u++) {
+                    h = h * 1664525u + 1013904223u;
+                    const uint32_t a = ng_base + ((h >> 8) % ROWS) * (T * 8u) + u * 8u;
+                    asm volatile("ds_add_u64 %0, %1" :: "v"(a), "v"(3ull) : "memory");
+                }
+            }
+        }
+        // fix lanes: two reads of the region, three adds into single-column bins
+        if (lane < 42u) {
+            uint32_t r0, r1;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(r0) : "v"(reg_base + (lane % 56u) * 4u));
+            asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(r1) : "v"(reg_base + (lane % 56u) * 4u));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r0), "+v"(r1));
+            const uint32_t a = ng_base + ((r0 ^ r1 ^ lane * 977u) % (ROWS * T)) * 8u;
+            asm volatile("ds_add_u64 %0, %1" :: "v"(a), "v"(1ull) : "memory");
+            asm volatile("ds_add_u64 %0, %1 offset:8" :: "v"(a), "v"(1ull) : "memory");
+            asm volatile("ds_add_u64 %0, %1 offset:16" :: "v"(a), "v"(1ull) : "memory");
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+int run_list(int iters, int active, int nnz, float* sink) {
+    const size_t lds = ((ROWS * ROWSTRIDE_B + 15) & ~15) + ROWS * T * 8 + 16 * (2048 + 128 + 256);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mix_list), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mix_list, dim3(256), dim3(1024), lds, 0, iters / 10, active, nnz, sink);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_mix_list, dim3(256), dim3(1024), lds, 0, iters, active, nnz, sink);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("compacted M-step, nnz %3d       %8.3f ms  %6.2f ns per sequence-equivalent per CU\n", nnz, ms, ms * 1e6 / (16.0 * iters));
+    return 0;
+}
+
 template <bool R, bool A>
 int run(const char* name, int per_iter, int iters, int active, float* sink, double* rate_out) {
     const size_t lds = ((ROWS * ROWSTRIDE_B + 15) & ~15) + ROWS * T * 8;
@@ -105,6 +206,10 @@ int main(int argc, char** argv) {
     if (run<true, false>("14 ds_read_b128", 14, iters, active, sink, &r)) return 1;
     if (run<false, true>("49 ds_add_u64", 49, iters, active, sink, &a)) return 1;
     if (run<true, true>("14 reads + 49 adds", 63, iters, active, sink, &mix)) return 1;
+    if (argc > 2) {                                      // the compacted formulation's LDS traffic, for comparison
+        const int nnzs[] = {64, 105, 128, 160, 192, 256};
+        for (int nnz : nnzs) if (run_list(iters, active, nnz, sink)) return 1;
+    }
     printf("{\"wave_instr_per_s\": %.6e, \"reads_only_wave_instr_per_s\": %.6e, \"adds_only_wave_instr_per_s\": %.6e, "
            "\"active_lanes_per_add\": %d, \"what\": \"LDS-only loop of k_em_grp's mix on the bench workload: 14 ds_read_b128 + 49 "
            "predicated ds_add_u64 per sequence, random rows of the same tables, 16 waves per CU (tools/lds_mix_bench.hip)\"}\n",
