@@ -136,7 +136,14 @@ struct bamm_em {
     bool acc_external = false;                 // caller-owned (bamm_em_set_reduce_buffer)
     bool acc_dirty = false;                    // holds sums nobody consumed (accumulate without update, getR replay)
     uint32_t fix_shift = 40;                   // counts travel in units of 2^-fix_shift (40 unless the set is huge)
-    float* h_status = nullptr;                  // pinned, 8 floats
+    float* h_status = nullptr;                  // pinned, 8 floats (+ 2 x 8 for optimize()'s look-ahead)
+    float* d_status_mirror = nullptr;           // h_status as the device addresses it (k_update writes optimize()'s slots itself)
+    uint32_t* d_stop = nullptr;                 // optimize(): set by k_update when the stop rule fires
+    const uint32_t* stop_arg = nullptr;         // what the kernels are handed: d_stop inside optimize(), else null
+    hipEvent_t opt_events[2] = {nullptr, nullptr};
+    // this optimize() call's stop rule for k_update (run_update fills UpdateArgs from it)
+    uint32_t opt_iteration = 0;
+    float opt_llh_prev = 0.0f;
     uint32_t total_blocks = 0;
     std::vector<EmBucket> ebuckets;             // launches of one pass (length class x kernel flavour)
     std::vector<uint32_t*> owned_idx;           // index lists made for this handle (capable / other split)
@@ -392,6 +399,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
         a.q = replay_last ? em->q_last : em->d_q;
         a.acc = em->d_acc;
         a.fix_scale = ldexpf(1.0f, (int)em->fix_shift - 40);
+        a.stop = em->stop_arg;
         a.r_out = nullptr; a.r_base = 0; a.seq_begin = 0; a.seq_end = 0;
         if (bk.mclass == kLongClass) {
             // the sliced path's getR() reads dense r from d_state (slot layout unless the E pass is k_em_seq)
@@ -497,6 +505,11 @@ int run_update(bamm_em* em, bool q_window) {
     u.q = em->d_q; u.q_out = q_out; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
     u.iteration = em->d_iteration; u.optimize_q = (em->prm.optimize_q && q_window) ? 1 : 0;
     u.n_seqs_override = (double)em->prm.n_seqs_global;
+    if (em->stop_arg) {
+        u.stop = em->d_stop; u.epsilon = em->prm.epsilon; u.opt_iteration = em->opt_iteration;
+        u.llh_prev = em->opt_llh_prev; u.llh_prev_from_status = em->opt_iteration > 1u ? 1 : 0;
+        u.status_mirror = em->d_status_mirror ? em->d_status_mirror + 8 + 8 * (em->opt_iteration & 1u) : nullptr;
+    }
     int rc = use_device(em->ctx);
     if (!rc) rc = launch_update(u, em->ctx->stream);
     if (rc) return rc;
@@ -713,6 +726,8 @@ int bamm_em_destroy(bamm_em* em) {
         (void)hipFree(p);
     for (uint32_t* p : em->owned_idx) (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
+    (void)hipFree(em->d_stop);
+    for (hipEvent_t e : em->opt_events) if (e) (void)hipEventDestroy(e);
     for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     bamm_seqs_destroy(em->seqs);
     delete em;
@@ -818,11 +833,12 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         if ((rc = dev_upload(&em->d_mask, seq_mask, seqs->n, st))) return fail(rc);
     em->n_active = seqs->n;
     if (seq_mask) em->n_active = (uint64_t)std::count_if(seq_mask, seq_mask + seqs->n, [](uint8_t m) { return m != 0; });
-    if (hipHostMalloc((void**)&em->h_status, 8 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&em->h_status, 24 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         return fail(BAMM_ERR_HIP);
     }
-    memset(em->h_status, 0, 8 * sizeof(float));
+    memset(em->h_status, 0, 24 * sizeof(float));
+    if (hipHostGetDevicePointer((void**)&em->d_status_mirror, em->h_status, 0) != hipSuccess) em->d_status_mirror = nullptr;   // then: copies
     // launches of one pass: every length bucket, split into the sequences the grouped-column kernel
     // takes (no exception, or all of them within its virtual rows) and the rest
     const bool want_grouped = !sliced && prm->K <= 3u && c->use_grouped;
@@ -1054,24 +1070,75 @@ int bamm_em_iterate(bamm_em* em, uint32_t n) {
 int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
     em->events_used = 0; em->pass_no = 0;
-    bool iterate = true;
-    uint32_t iteration = 0;
+    if (iterations) *iterations = 0;
+    const uint32_t max_it = em->prm.max_iterations;
+    if (max_it == 0) return BAMM_OK;
+    int rc = use_device(em->ctx);
+    if (rc) return rc;
+    hipStream_t st = em->ctx->stream;
+    // The stop rule (EM.cpp:117-118) needs (llh, v_diff) of a pass on the host: a read-back and a stream
+    // synchronisation per pass, 13 us during which the GPU idles (half of a pass at 300 sequences, a sixth at 50k).
+    // So the loop runs ONE pass ahead: pass i+1 is enqueued before pass i's numbers are waited for.  k_update
+    // evaluates the same rule on the device and raises a flag; a pass enqueued behind a raised flag does nothing
+    // (every kernel of it returns at entry), so the model is exactly what pass i left, and the host takes back
+    // the bookkeeping of that one pass.
+    if (!em->d_stop && (rc = dev_alloc(&em->d_stop, 1))) return rc;
+    for (hipEvent_t& e : em->opt_events)
+        if (!e) BAMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    BAMM_HIP(hipMemsetAsync(em->d_stop, 0, sizeof(uint32_t), st));
+    struct Book {                                        // host-side state a pass moves
+        float *d_s, *d_s_alt, *d_q; const float *s_last, *q_last;
+        uint32_t host_iteration; bool estep_done, acc_dirty, mask_done;
+    };
+    auto capture = [&]() { return Book{em->d_s, em->d_s_alt, em->d_q, em->s_last, em->q_last, em->host_iteration, em->estep_done, em->acc_dirty, em->mask_done}; };
+    auto restore = [&](const Book& b) {
+        em->d_s = b.d_s; em->d_s_alt = b.d_s_alt; em->d_q = b.d_q; em->s_last = b.s_last; em->q_last = b.q_last;
+        em->host_iteration = b.host_iteration; em->estep_done = b.estep_done; em->acc_dirty = b.acc_dirty; em->mask_done = b.mask_done;
+    };
+    em->stop_arg = em->d_stop;
+    em->opt_llh_prev = em->llh_prev;
+    auto enqueue = [&](uint32_t it) -> int {              // pass `it` (1-based), its status on the way to slot it & 1
+        em->opt_iteration = it;
+        int r = run_accumulate(em, true);
+        if (!r) r = run_allreduce(em);
+        if (!r) r = run_update(em, it <= 5u);                                   // EM.cpp:99
+        if (r) return r;
+        if (!em->d_status_mirror)
+            BAMM_HIP(hipMemcpyAsync(em->h_status + 8 + 8 * (it & 1u), em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+        BAMM_HIP(hipEventRecord(em->opt_events[it & 1u], st));
+        return BAMM_OK;
+    };
+    auto leave = [&](int r) { em->stop_arg = nullptr; return r; };
+    uint32_t enqueued = 1, done = 0;
     float llh = em->llh_prev;
-    while (iterate && iteration < em->prm.max_iterations) {     // EM.cpp:81
-        iteration++;
+    if ((rc = enqueue(1))) return leave(rc);
+    for (;;) {                                                              // EM.cpp:81
+        const Book before_ahead = capture();
+        bool ahead = false;
+        if (enqueued < max_it) {
+            if ((rc = enqueue(enqueued + 1u))) return leave(rc);
+            enqueued++;
+            ahead = true;
+        }
+        done++;
+        BAMM_HIP(hipEventSynchronize(em->opt_events[done & 1u]));
+        const float* hs = em->h_status + 8 + 8 * (done & 1u);
         const float llh_prev = llh;
-        int rc = run_accumulate(em, true);
-        if (!rc) rc = run_allreduce(em);
-        if (!rc) rc = run_update(em, iteration <= 5u);                  // EM.cpp:99
-        if (!rc) rc = fetch_status(em);
-        if (rc) return rc;
-        llh = em->h_status[0];
-        const float v_diff = em->h_status[1];
-        if (v_diff < em->prm.epsilon) iterate = false;                     // EM.cpp:117
-        if (llh - llh_prev < 0 && iteration > 10) iterate = false;         // EM.cpp:118
+        llh = hs[0];
+        const float v_diff = hs[1];
+        bool iterate = true;
+        if (v_diff < em->prm.epsilon) iterate = false;                      // EM.cpp:117
+        if (llh - llh_prev < 0 && done > 10) iterate = false;               // EM.cpp:118
+        if (!iterate) {
+            if (ahead) restore(before_ahead);                               // that pass found the flag raised: it did nothing
+            memcpy(em->h_status, hs, 8 * sizeof(float));
+            break;
+        }
+        if (done == max_it) { memcpy(em->h_status, hs, 8 * sizeof(float)); break; }
     }
+    em->stop_arg = nullptr;
     em->llh_prev = llh;
-    if (iterations) *iterations = iteration;
+    if (iterations) *iterations = done;
     return BAMM_OK;
 }
 

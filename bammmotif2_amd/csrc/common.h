@@ -89,6 +89,9 @@ struct EmKernelArgs {
     float*    list_r;            // [pos_off[seq] + k] responsibility of the k-th listed window
     uint16_t* list_p;            // [pos_off[seq] + k] its slot: the position of the window's last column
     uint32_t* list_n;            // [seq] listed windows
+    // bamm_em_optimize() enqueues one pass ahead of the pass whose (llh, v_diff) it is waiting for; k_update sets
+    // this word when the stop rule (EM.cpp:117-118) fires, and a pass enqueued behind it does nothing
+    const uint32_t* stop;        // nullable
 };
 
 // ---- grouped-column kernel (grouped.hip): G motif columns (K+G = 4 or 5) share one table row ------
@@ -174,6 +177,14 @@ struct UpdateArgs {
     uint32_t* iteration;         // device counter
     int32_t optimize_q;          // re-estimate q in this pass (EM.cpp:99: the first five passes of an optimize() call)
     double n_seqs_override;      // >0: use instead of red[..+2]
+    // optimize(): the stop rule evaluated where its inputs are (EM.cpp:117-118, same float comparisons as the host's)
+    uint32_t* stop;              // nullable; set to 1 when the rule fires; a non-zero word makes this launch a no-op
+    float epsilon;               // EM.h:62
+    float llh_prev;              // likelihood before this pass when it is the call's first ...
+    int32_t llh_prev_from_status;   // ... else status[0] as the previous update left it
+    uint32_t opt_iteration;      // 1-based pass number inside this optimize() call (`iteration > 10`)
+    float* status_mirror;        // nullable: pinned host memory (device address) that receives the 8 status words as
+                                 // well, so that the host needs no copy in the stream to see them
 };
 
 struct MaskSelect {              // device state of the radix select (EM.cpp:329-343)

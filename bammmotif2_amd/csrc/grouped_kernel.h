@@ -165,6 +165,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // pass: a CU retires one scattered device-scope atomic per ~18 ns (tools/atomic_scatter_bench.hip), and a
     // sequence issued 14-19 of them.  The sequence record carries 10-bit y fields (Y = 256).
     constexpr bool FIXG = (KG - G == 3);
+    if (ga.e.stop != nullptr && *ga.e.stop != 0u) return;    // optimize(): the stop rule fired in an earlier pass
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const EmKernelArgs& a = ga.e;
     const GrpGeom& g = ga.g;

@@ -87,6 +87,8 @@ __device__ __forceinline__ void dense_count_walk(uint32_t ncols, uint32_t col, u
 // ---- fused E+M sequence kernel --------------------------------------------------------------
 template <int M, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
+    if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+
     extern __shared__ __align__(16) float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
     const uint32_t Wq = (W + 3u) >> 2;
@@ -368,6 +370,8 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 // slot p holds r(p + W-1-j), which it reads straight from the buffer.
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0, uint32_t j1, int last) {
+    if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0;
     float* s_lds = lds;                                               // [nc][Y+1]
@@ -449,6 +453,8 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
 // k_em_seq (a ds_add_u64 costs the same LDS cycles whether 3 or 64 lanes take part).
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0, uint32_t j1, int r_reversed) {
+    if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;
     unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y+1][C], row Y = dump
@@ -565,6 +571,8 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
 // walk of k_m_slice, so the counts are bit-identical; nothing is compacted or converted here any more.
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0, uint32_t j1) {
+    if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;
     unsigned long long* n_lds = reinterpret_cast<unsigned long long*>(lds);      // [nc][Y+1][C], row Y = dump
@@ -744,6 +752,8 @@ __global__ void k_make_s(const float* v, const float* vbg, uint32_t K, uint32_t 
 // results.  Same formulas in the same order either way: bit-identical models.
 template <bool IN_LDS>
 __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
+    if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+
     extern __shared__ float upd_lds[];
     __shared__ double shd[16];
     __shared__ double stat3[3];
@@ -850,12 +860,20 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         if (a.optimize_q)                                  // EM.cpp:515; the host applies EM.cpp:99's `iteration <= 5`
             q = (float)((nseq - sum_r + 1.0) / (nseq + 2.0));
         *a.q_out = q;
+        if (a.stop != nullptr) {                           // EM.cpp:117-118
+            const float llh_prev = a.llh_prev_from_status ? a.status[0] : a.llh_prev;
+            if ((float)v_diff < a.epsilon || ((float)llh - llh_prev < 0 && a.opt_iteration > 10u)) *a.stop = 1u;
+        }
         a.status[0] = (float)llh;
         a.status[1] = (float)v_diff;
         a.status[2] = q;
         a.status[3] = (float)it;
         a.status[4] = (float)sum_r;
         a.status[5] = (float)nseq;
+        if (a.status_mirror != nullptr) {
+            a.status_mirror[0] = (float)llh; a.status_mirror[1] = (float)v_diff; a.status_mirror[2] = q; a.status_mirror[3] = (float)it;
+            a.status_mirror[4] = (float)sum_r; a.status_mirror[5] = (float)nseq;
+        }
         if (a.trace && it - 1u < a.trace_cap) {
             a.trace[(size_t)(it - 1u) * 3 + 0] = (float)llh;
             a.trace[(size_t)(it - 1u) * 3 + 1] = (float)v_diff;

@@ -72,6 +72,8 @@ __device__ __forceinline__ double block_sum(double x, double* sh) {       // 256
 // slot_layout: r goes to state[p] with p = i + W - 1 (what the column-sliced E pass leaves) instead of the
 // reference's r[L-W-i]
 __global__ void __launch_bounds__(256) k_long_em(EmKernelArgs a, int accum, int write_r, int slot_layout) {
+    if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+
     __shared__ double sh[4];
     const uint32_t W = a.W, Y = a.Y;
     const float q = *a.q, one_minus_q = 1.0f - q;
