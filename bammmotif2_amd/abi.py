@@ -51,7 +51,7 @@ SYMBOLS = [
     "bamm_em_set_allreduce", "bamm_em_set_comm", "bamm_comm_init_all", "bamm_comm_unique_id", "bamm_comm_init_rank",
     "bamm_comm_info", "bamm_comm_destroy", "bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s", "bamm_em_get_q",
     "bamm_em_get_llh", "bamm_em_get_vdiff", "bamm_em_get_iteration", "bamm_em_get_r",
-    "bamm_em_get_trace", "bamm_em_kernel_time", "bamm_em_set_kernel_timing", "bamm_em_plan", "bamm_seed_from_pwm", "bamm_set_host_threads", "bamm_logodds", "bamm_logodds_subset", "bamm_bg_model", "bamm_calculate_p", "bamm_v_size",
+    "bamm_em_get_trace", "bamm_em_kernel_time", "bamm_em_set_kernel_timing", "bamm_em_plan", "bamm_em_plan_mixed", "bamm_seed_from_pwm", "bamm_set_host_threads", "bamm_logodds", "bamm_logodds_subset", "bamm_bg_model", "bamm_calculate_p", "bamm_v_size",
     "bamm_v_offset", "bamm_bg_size",
 ]
 
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     L.bamm_em_kernel_time.argtypes = [vp, P(f), P(u32)]
     L.bamm_em_set_kernel_timing.argtypes = [vp, u32]
     L.bamm_em_plan.argtypes = [vp, P(u64), P(u64), P(u32)]
+    L.bamm_em_plan_mixed.argtypes = [vp, P(u64)]
     L.bamm_set_host_threads.argtypes = [u32]
     L.bamm_set_host_threads.restype = None
     L.bamm_seed_from_pwm.argtypes = [vp, vp, u32, u32, f32p, f, vp, vp, vp]

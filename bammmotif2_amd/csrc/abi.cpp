@@ -363,7 +363,7 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
         set_error("grouped kernel geometry does not fit (K=%u W=%u)", em->prm.K, em->prm.W);
         return BAMM_ERR_UNSUPPORTED;
     }
-    if (em->prm.K == 3u && accum) {
+    if ((em->prm.K == 3u || (eb.layout & 8u)) && accum) {      // kernels whose fix lanes log their sums
         const size_t waves = (size_t)eb.blocks * (threads / 64u);
         const size_t cap = ((eb.count + waves - 1) / waves) * std::min<size_t>(64, (size_t)ga.g.Bv * ga.g.T);   // entries per wave
         const size_t need = waves * cap * 2;                  // 16-byte entries, in 8-byte words
@@ -613,7 +613,7 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
         if (value != 0 && (value < 2 || value > 4)) { set_error("group_size must be 0 (auto) or 2..4"); return BAMM_ERR_ARG; }
         c->group_size = (uint32_t)value;
     } else if (k == "group_layout") {
-        if (value < -1 || value > 3) { set_error("group_layout must be -1 (auto) or 0..3"); return BAMM_ERR_ARG; }
+        if (value < -1 || (value > 3 && value != 8)) { set_error("group_layout must be -1 (auto), 0..3 or 8 (mixed rows)"); return BAMM_ERR_ARG; }
         c->group_layout = value;
     } else { set_error("bamm_ctx_set_tuning: unknown key '%s'", key); return BAMM_ERR_ARG; }
     return BAMM_OK;
@@ -1400,6 +1400,14 @@ int bamm_em_plan(bamm_em* em, uint64_t* grouped_seqs, uint64_t* percolumn_seqs, 
     if (grouped_seqs) *grouped_seqs = g;
     if (percolumn_seqs) *percolumn_seqs = o;
     if (launches) *launches = (uint32_t)em->ebuckets.size();
+    return BAMM_OK;
+}
+
+int bamm_em_plan_mixed(bamm_em* em, uint64_t* mixed_seqs) {
+    if (!em || !mixed_seqs) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    uint64_t m = 0;
+    for (auto& b : em->ebuckets) if (b.grouped && (b.layout & 8u)) m += b.count;
+    *mixed_seqs = m;
     return BAMM_OK;
 }
 

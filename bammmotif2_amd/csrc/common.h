@@ -109,6 +109,9 @@ struct GrpGeom {
     uint32_t off_sg, off_s1, off_stat, off_ng, off_n1, off_wave, wave_bytes;   // LDS byte offsets
     uint32_t cap;                // K = 3 kernels: 1 = the single-column table is in LDS, 0 = read from global memory
     uint32_t lds_bytes;
+    // layout bit 3, mixed rows (mixed_kernel.h, K = 2): mixB groups of 3 columns on 5-mer rows (the fields above
+    // describe that narrow table; G = 4 is the widest group), then mixA groups of 4 columns on 6-mer rows
+    uint32_t mixA, mixB, off_sg6, off_ng6;
 };
 
 struct GrpKernelArgs {
@@ -133,6 +136,10 @@ int launch_em_grp_long(int mclass, bool accum, bool write_r, const GrpKernelArgs
 int launch_em_grp_xl(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                      hipStream_t st);     // grouped_xl.hip: 40 / 48 positions per lane
 uint32_t grp_max_threads(int M);   // block size the grouped kernel of this length class is built for
+// mixed rows: geometry (false: does not apply / does not fit) and the launchers of its two translation units
+bool mix_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, GrpGeom* out);
+int launch_em_mix(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st);
+int launch_em_mix1(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st);
 int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                   hipStream_t st);
 

@@ -14,10 +14,20 @@ __device__ __forceinline__ float wave_shr1(float oldv, float x) {
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, oldv), __builtin_bit_cast(int, x),
                                            0x138, 0xf, 0xf, false));
 }
-__device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x) {   // lane 63 receives 0
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x & 0xffffffffull), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), 0x130, 0xf, 0xf, false);
+// lane l takes lane l+1's value; lane 63 receives 0 (bound_ctrl: no pre-set destination, ONE v_mov_b32_dpp per
+// dword -- with a destination to preserve the compiler emits a v_mov in front of every one of them)
+__device__ __forceinline__ unsigned long long wave_shl1_u64(unsigned long long x) {
+    const int lo = __builtin_amdgcn_mov_dpp((int)(unsigned)(x & 0xffffffffull), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(unsigned)(x >> 32), 0x130, 0xf, 0xf, true);
     return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// f * (value of x in lane l-1), lane 0: f * 1 -- the E-chain's carry across lanes, as ONE v_mul_f32_dpp (a lane
+// without a source keeps the destination, which holds f).  hipcc emits v_mov 1.0 / v_mov_dpp / v_mul for the
+// same thing.  s_nop 1: a DPP read needs two wait states after a VALU write of its source, and the hazard
+// recogniser does not look into inline asm.
+__device__ __forceinline__ float mul_wave_shr1(float f, float x) {
+    asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(f) : "v"(x));
+    return f;
 }
 // r in [0,1] -> round(r * 2^40); exact integer accumulation up to 2^24 sequences per block
 __device__ __forceinline__ unsigned long long to_fixed40(float r) {

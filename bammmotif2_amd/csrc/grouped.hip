@@ -18,8 +18,47 @@ uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : (M <
 //                 count table start on every 2nd / 4th / 8th bank pair only (T = 10: 80-byte rows reach half of
 //                 the banks, T = 8: a quarter) and the ds_add_u64 of a wave pile up there; one spare cell per row
 //                 spreads them over all banks (K = 3, W = 20: 1.88 -> see DESIGN.md)
+// Mixed rows (mixed_kernel.h): K = 2, W = 3 B + 4 A with A = W mod 3 in {1, 2} wide groups.  Row counts are
+// compile-time constants of the kernel (16 or 12 waves per block, 9 virtual rows per wave).
+bool mix_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, GrpGeom* out) {
+    if (K != 2u || M < 4 || 2 * (M - 1) + 12 > 32 || (waves != 16u && waves != 12u)) return false;
+    if (waves != grp_max_threads(M) / 64u) return false;
+    const uint32_t A = W % 3u;
+    if (A == 0u || W < 4u * A + 3u) return false;
+    const uint32_t B = (W - 4u * A) / 3u, T = A + B, Bj = 6u, Bv = 9u;
+    if (B > 8u || Bv * T > 64u) return false;
+    // measured (tools/mix_probe.py, 1M x 200 bp): the group saved pays when the narrow groups fill one quad and the
+    // motif is not short (W = 13, 14, 16, 17, 20: 3-5 % faster than the uniform rows; W = 10, 11, 19, 22: slower)
+    if (B > 4u || W < 13u) return false;
+    GrpGeom g{};
+    g.G = 4u; g.T = T; g.Tq = (B + 3u) / 4u; g.delta = 0u; g.Ts = 0u; g.Rf = 1024u;
+    g.np = 0u; g.Rn = 1024u; g.R0 = 1025u; g.Bj = Bj; g.Bv = Bv; g.Rtot = 1025u + waves * Bv;
+    g.mixA = A; g.mixB = B; g.cap = 1u;
+    const uint32_t R6T = 4097u + waves * Bv, Y = 64u;
+    auto up16 = [](uint32_t x) { return (x + 15u) & ~15u; };
+    for (int odd = 1; odd >= 0; odd--) {                     // narrow odds rows of an odd number of quads when that fits
+        g.rowstride = (odd ? (g.Tq | 1u) : g.Tq) * 4u;
+        g.layout = 8u | 1u | (odd ? 2u : 0u);
+        uint32_t off = 0;
+        g.off_sg6 = off; off = up16(off + R6T * A * 4u);
+        g.off_sg = off; off = up16(off + g.Rtot * g.rowstride * 4u);
+        g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
+        g.off_stat = off; off = up16(off + 16u * 3u * 8u);
+        g.off_ng6 = off; if (accum) off = up16(off + A * R6T * 8u);
+        g.off_ng = off; if (accum) off = up16(off + B * g.Rtot * 8u);
+        g.off_n1 = g.off_sg6;                                // epilogue only
+        g.off_wave = off; g.wave_bytes = 0u;
+        g.lds_bytes = off;
+        if (accum && W * Y * 8u > R6T * A * 4u) continue;
+        if (off <= 160u * 1024u) { *out = g; return true; }
+        if (g.Tq & 1u) break;                                // the stride was odd already
+    }
+    return false;
+}
+
 bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
                   GrpGeom* out) {
+    if (layout & 8u) return G == 4u && logC == 0u && mix_geometry(K, W, M, waves, accum, out);
     if (K > 3u || W == 0u || G < 2u || G > 4u || K + G > 5u || (int)G > M) return false;
     const bool fixg = K == 3u;                               // single-column table in global memory unless it fits, bins in the epilogue
     GrpGeom g{};
@@ -105,6 +144,16 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
     // sets (single strand, K=0) would pay the fix lanes for the edge alone (+11 %): partial rows there.
     // each with the count rows padded to an odd number of cells first (bit 2; the same thing when T is odd)
     const uint32_t order_exc[6] = {7u, 3u, 6u, 2u, 4u, 0u}, order_clean[6] = {6u, 2u, 4u, 0u, 7u, 3u};
+    // K = 2, W not a multiple of 3: one group less with the motif's last columns on 6-mer rows (mixed_kernel.h);
+    // its edge rows are virtual, so like layouts 3 / 7 it is for sets that run the fix lanes per sequence anyway
+    if (K == 2u && many_exceptions && (forced == 0u || forced == 4u) && (forced_layout < 0 || forced_layout == 8)) {
+        GrpGeom g;
+        if (mix_geometry(K, W, M, waves, true, &g)) {
+            *G_out = 4u; *logC_out = 0u; *layout_out = g.layout;
+            return true;
+        }
+    }
+    if (forced_layout == 8) return false;
     for (uint32_t G = 5u - K; G >= 2u && G + 1u >= 5u - K; G--) {          // G = 5-K, then 4-K
         if (G > 4u || (forced && G != forced)) continue;
         for (int li = 0; li < 6; li++) {
@@ -134,6 +183,9 @@ int launch_em_grp(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, 
         set_error("bad launch of the grouped kernel (%u x %u, %u bytes of LDS)", blocks, threads, a.g.lds_bytes);
         return BAMM_ERR_ARG;
     }
+    if (a.g.layout & 8u)
+        return a.g.mixA == 2u ? launch_em_mix(mclass, accum, write_r, a, blocks, threads, st)
+                              : launch_em_mix1(mclass, accum, write_r, a, blocks, threads, st);
     if (kMClasses[mclass] > 16) return launch_em_grp_long(mclass, accum, write_r, a, blocks, threads, st);
     const uint32_t KG = a.e.K + a.g.G;                       // row = (K+G)-mer: 4 or 5 bases
     switch (mclass * 64 + (int)a.g.G * 8 + (int)KG) {

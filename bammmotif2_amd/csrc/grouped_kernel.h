@@ -112,11 +112,11 @@ template <int M, int G>
 __device__ __forceinline__ void grp_step(float (&U)[M], const float (&f)[M]) {
     float cy[G];
 #pragma unroll
-    for (int c = 0; c < G; c++) cy[c] = wave_shr1(1.0f, U[M - G + c]);
+    for (int c = 0; c < G; c++) cy[c] = mul_wave_shr1(f[c], U[M - G + c]);     // before the slots are overwritten
 #pragma unroll
     for (int m = M - 1; m >= G; m--) U[m] = U[m - G] * f[m];
 #pragma unroll
-    for (int m = 0; m < G; m++) U[m] = cy[m] * f[m];
+    for (int m = 0; m < G; m++) U[m] = cy[m];
 }
 
 // E-step chain over NQ quads of group slots, straight-line: EVERY slot of a quad is multiplied in
@@ -394,9 +394,9 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     }
                     if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
                     yfix[c] = yc;
-                    if (yc != Y) f *= s1_at((uint32_t)col * Ys + yc);
+                    if (yc != Y) f *= s1_at(__umul24((uint32_t)col, Ys) + yc);
                 }
-                sg[(vbase + lane_b) * g.rowstride + pad + lane_t] = f;
+                sg[__umul24(vbase + lane_b, g.rowstride) + pad + lane_t] = f;
             }
             wave_lds_sync();
         }
@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             uint32_t ra[M];
             const uint32_t sg_base = lds_offset(sg);
 #pragma unroll
-            for (int m = 0; m < M; m++) ra[m] = sg_base + row[m] * (g.rowstride * 4u);
+            for (int m = 0; m < M; m++) ra[m] = sg_base + __umul24(row[m], g.rowstride * 4u);   // v_mad_u32_u24: full rate (v_mul_lo_u32 is not)
             switch (Tq) {
                 case 1: grp_chain<M, G, 1>(ra, U); break;
                 case 2: grp_chain<M, G, 2>(ra, U); break;
@@ -490,7 +490,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
                 for (int m = 0; m < M; m++) {
                     nz[m] = __ballot(F[m] != 0ull);          // adding an exact 0 is a no-op: those lanes sit out
-                    rad[m] = ng_base + (((row[m] << logC) + copy) * Ts) * 8u;
+                    rad[m] = ng_base + __umul24((row[m] << logC) + copy, Ts * 8u);
                 }
                 // F is a ring: after s steps logical slot m lives in F[(m + G*s) mod M]; the G slots
                 // that arrive from the next lane are shifted in place with one DPP pair each, and their

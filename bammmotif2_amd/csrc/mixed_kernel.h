@@ -1,0 +1,416 @@
+// gfx950 kernel of the fused EM pass at K = 2 with MIXED table rows: the motif's first B groups of 3 columns
+// on 5-mer rows as in k_em_grp (grouped_kernel.h), its last A = W mod 3 groups of FOUR columns on 6-mer rows.
+//
+// Same computation as k_em_grp / k_em_seq: EM::EStep refinement/EM.cpp:149-196, EM::MStep EM.cpp:231-243, the
+// sum over r of EM.cpp:509-513 -- file:line relative to /root/reference/src.
+//
+// Why: k_em_grp is bound by LDS instructions, T = ceil(W/3) gathers of group odds and T count adds per
+// position, and a predicated ds_add_u64 costs 6.4-6.7 LDS cycles however few lanes take part (DESIGN.md
+// section 4).  When W is not a multiple of 3 the last group of the uniform layout is mostly padding: W = 20 is
+// 7 groups.  A 6-mer row holds four columns, so 20 = 3+3+3+3 + 4+4 is SIX groups: 42 adds instead of 49 per
+// sequence of 7 positions per lane, and one b128 + one b64 gather per position instead of two b128.  An LDS-only
+// loop of that mix (tools/lds_mix_bench.hip) runs in 165 ns per sequence and CU against 197 ns.  The price is
+// LDS: a wide group takes 16 KB of odds and 32 KB of counts (4096 rows) against 4 + 8 KB, so at most two of
+// them fit, the count tables are group-major (no padding cell), and the bins of the virtual rows only exist
+// in the block epilogue (the fix lanes log their sums, as k_em_grp does at K = 3).
+//
+//   U_t(p) = U_{t-1}(p - G_t) * tab_t[row_t(p)]     narrow t < B: G_t = 3, row = kmer_[p] mod 4^5; wide: 4, 4^6
+//   cnt_t[row_t(p)] += r(window whose group t ends at p)          (2^-40 fixed point, marginalised per block)
+//
+// Everything else is k_em_grp's: one wavefront per sequence, M positions per lane, per-wave virtual rows for the
+// group ends next to an N exception (Sequence.cpp:38) and for those cut by the EM.cpp:167 edge -- one virtual
+// row index serves both tables --, wave priorities by phase, the straight-line chain.
+#pragma once
+#include "grouped_kernel.h"
+
+namespace bamm {
+namespace {
+
+constexpr uint32_t kMixBj = 6u, kMixNe = 3u, kMixBv = kMixBj + kMixNe;   // virtual rows per wave: exceptions, edge
+
+template <int OFF>
+__device__ __forceinline__ void lds_add_u64_exec_big(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    lds_add_u64_exec<OFF>(byte_addr, v, mask);
+}
+
+template <int M, int A, int NQ, bool ACCUM, bool WRITE_R, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
+    static_assert(M >= 4 && 2 * (M - 1) + 12 <= 32, "a wide group within one lane's run, rows out of one stream window");
+    static_assert(A == 1 || A == 2, "wide groups");
+    constexpr uint32_t WAVES = THREADS / 64, V = WAVES * kMixBv;
+    constexpr uint32_t R5N = 1024u, R5V0 = R5N + 1u, R5T = R5V0 + V;          // neutral row, first virtual row, rows
+    constexpr uint32_t R6N = 4096u, R6V0 = R6N + 1u, R6T = R6V0 + V;
+    constexpr uint32_t Y = 64u, Ys = 65u;                      // K = 2
+    if (ga.e.stop != nullptr && *ga.e.stop != 0u) return;    // optimize(): the stop rule fired in an earlier pass
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const EmKernelArgs& a = ga.e;
+    const GrpGeom& g = ga.g;
+    const uint32_t W = a.W, T = g.T, B = g.mixB;             // T = B + A groups
+    const uint32_t pad = 4u * NQ - B;                        // neutral slots in front of the first narrow group
+    const uint32_t rs5 = g.rowstride;                        // floats per narrow odds row
+    float* sg5 = reinterpret_cast<float*>(lds_raw + g.off_sg);                            // [R5T][rs5]
+    float* sg6 = reinterpret_cast<float*>(lds_raw + g.off_sg6);                           // [R6T][A]
+    const float* s1 = reinterpret_cast<const float*>(lds_raw + g.off_s1);                 // [W][Y+1]
+    double* stat_lds = reinterpret_cast<double*>(lds_raw + g.off_stat);                   // [16][3]
+    // count tables, group-major, groups stored LAST TO FIRST (the M-step walks them in that order and reaches the
+    // next group through the add's immediate offset): cnt5[B-1-t][row], cnt6[T-1-t][row]
+    unsigned long long* cnt5 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng);
+    unsigned long long* cnt6 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_ng6);
+    unsigned long long* n1 = reinterpret_cast<unsigned long long*>(lds_raw + g.off_n1);   // epilogue only: over sg6
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total_waves = gridDim.x * WAVES;
+    uint32_t t = blockIdx.x * WAVES + wave;
+    RawSeqG<M> nxt{};
+    if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
+
+    // ---- block prologue
+    {
+        float* s1w = reinterpret_cast<float*>(lds_raw + g.off_s1);
+        for (uint32_t i = threadIdx.x; i < W * Ys; i += THREADS) s1w[i] = a.s[i];
+        if (ACCUM) {
+            for (uint32_t i = threadIdx.x; i < B * R5T; i += THREADS) cnt5[i] = 0ull;
+            for (uint32_t i = threadIdx.x; i < A * R6T; i += THREADS) cnt6[i] = 0ull;
+        }
+        for (uint32_t i = threadIdx.x; i < (R5T - R5N) * rs5; i += THREADS) sg5[R5N * rs5 + i] = 1.0f;
+        for (uint32_t i = threadIdx.x; i < (R6T - R6N) * A; i += THREADS) sg6[R6N * A + i] = 1.0f;
+        __syncthreads();
+        for (uint32_t row = threadIdx.x; row < R5N; row += THREADS) {      // a group's 3 column odds in column order
+            float* out = sg5 + row * rs5;
+            for (uint32_t slot = 0; slot < pad; slot++) out[slot] = 1.0f;
+            for (uint32_t slot = pad + B; slot < rs5; slot++) out[slot] = 1.0f;
+            for (uint32_t tt = 0; tt < B; tt++) {
+                float f = 1.0f;
+#pragma unroll
+                for (int c = 0; c < 3; c++) f *= s1[(3u * tt + c) * Ys + ((row >> (2 * (2 - c))) & 63u)];
+                out[pad + tt] = f;
+            }
+        }
+        for (uint32_t row = threadIdx.x; row < R6N; row += THREADS) {
+#pragma unroll
+            for (int w = 0; w < A; w++) {
+                float f = 1.0f;
+#pragma unroll
+                for (int c = 0; c < 4; c++) f *= s1[(3u * B + 4u * w + c) * Ys + ((row >> (2 * (3 - c))) & 63u)];
+                sg6[row * A + w] = f;
+            }
+        }
+        __syncthreads();
+    }
+
+    const float q = *a.q;
+    const float one_minus_q = 1.0f - q;
+    const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles: (row, group)
+    const bool lane_wide = lane_t >= B;
+    const uint32_t lane_G = lane_wide ? 4u : 3u;
+    const uint32_t lane_col0 = lane_wide ? 3u * B + 4u * (lane_t - B) : 3u * lane_t;
+    const uint32_t vbase5 = R5V0 + wave * kMixBv, vbase6 = R6V0 + wave * kMixBv;
+    const uint32_t sg5_base = lds_offset(sg5), sg6_base = lds_offset(sg6);
+
+    double llh_acc = 0.0, sumr_acc = 0.0;
+    uint32_t seq_cnt = 0, last_LW1 = 0;
+    float pos_i = 0.0f;
+    [[maybe_unused]] ulonglong2* my_log = nullptr;           // the fix lanes' non-zero sums: {sum, 4 bins of 16 bits}
+    [[maybe_unused]] uint32_t nlog = 0;
+    if constexpr (ACCUM)
+        my_log = reinterpret_cast<ulonglong2*>(ga.fix_log) + (size_t)(blockIdx.x * WAVES + wave) * ga.fix_log_cap;
+
+    for (; t < a.sv.count; t += total_waves) {
+        const RawSeqG<M> cur = nxt;
+        if (t + total_waves < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t + total_waves, lane);
+        const uint32_t seq = cur.seq;
+        if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
+        if (!cur.ok) continue;
+        __builtin_amdgcn_s_setprio(0);                       // decode, fix lanes
+        const uint32_t L = __builtin_amdgcn_readfirstlane(cur.L);
+        const uint32_t LW1 = L - W + 1u;
+        const uint32_t p0 = (uint32_t)lane * M;
+
+        // ---- rows of every position out of one 32-bit stream window per lane; sE = the window ending at LW1-1
+        uint32_t row5[M], row6[M];
+        uint32_t sE;
+        {
+            constexpr int NSEL = RawSeqG<M>::NSEL;
+            const uint32_t wi0 = p0 >> 4;
+            const uint32_t pE = LW1 - 1u, lpE = pE / (uint32_t)M;
+            const uint32_t pe = p0 + (uint32_t)(M - 1);
+            const uint32_t sel = (pe >> 4) - wi0;
+            uint32_t lo = cur.w[1], hi = cur.w[0];
+#pragma unroll
+            for (int c = 1; c < NSEL; c++) {
+                lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
+                hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
+            }
+            const uint32_t X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const bool in = p0 + m < LW1;                                            // EM.cpp:167
+                row5[m] = in ? ((X >> (2 * (M - 1 - m))) & 1023u) : R5N;
+                row6[m] = in ? ((X >> (2 * (M - 1 - m))) & 4095u) : R6N;
+            }
+            sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
+        }
+
+        // ---- virtual rows (one index for both tables): B group ends from xlo on next to an exception, the
+        // positions LW1 .. LW1+2 whose groups are cut by the edge
+        const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
+        const uint32_t Bx = (xw >> 12) & 0xfu;
+        const uint32_t xlo = xw & 0xfffu;
+        const uint32_t nE = min(kMixNe, L - LW1);
+        uint32_t yfix[4] = {Y, Y, Y, Y};
+        const bool fixJ = lane_b < Bx;
+        const bool fixE = lane_b >= kMixBj && lane_b < kMixBj + nE;
+        const bool fix = fixJ || fixE;
+        {
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
+                if (k2 < Bx) { row5[m] = vbase5 + k2; row6[m] = vbase6 + k2; }
+                if (k3 < nE) { row5[m] = vbase5 + kMixBj + k3; row6[m] = vbase6 + kMixBj + k3; }
+            }
+            if (fix) {
+                float f = 1.0f;
+                const uint32_t pv = fixJ ? xlo + lane_b : LW1 + (lane_b - kMixBj);     // the row's position
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if ((uint32_t)c < lane_G) {
+                        const uint32_t pos = pv - (lane_G - 1u) + (uint32_t)c;       // wraps for positions before the sequence
+                        uint32_t yc;
+                        if (fixJ) {                                                // record fields start at position xlo-3
+                            const uint32_t k = lane_b + (uint32_t)c + 4u - lane_G;
+                            const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                            yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                        } else {
+                            yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);
+                        }
+                        if (pos >= LW1) yc = Y;                                    // EM.cpp:167 (also pos < 0)
+                        yfix[c] = yc;
+                        if (yc != Y) f *= s1[__umul24(lane_col0 + (uint32_t)c, Ys) + yc];
+                    }
+                }
+                if (lane_wide) sg6[(vbase6 + lane_b) * A + (lane_t - B)] = f;
+                else sg5[__umul24(vbase5 + lane_b, rs5) + pad + lane_t] = f;
+            }
+            wave_lds_sync();
+        }
+
+        // ---- E-step: narrow groups (straight-line over NQ quads, neutral slots in front), then the wide ones
+        __builtin_amdgcn_s_setprio(2);
+        float U[M];
+        {
+            uint32_t ra[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) ra[m] = sg5_base + __umul24(row5[m], rs5 * 4u);        // v_mad_u32_u24: full rate
+            grp_chain<M, 3, NQ>(ra, U);
+            if constexpr (A == 2) {
+                float w0[M], w1[M];
+                float2 pr[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) asm volatile("ds_read_b64 %0, %1" : "=v"(pr[m]) : "v"(sg6_base + row6[m] * 8u));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[0]));
+#pragma unroll
+                for (int m = 1; m < M; m++) asm volatile("" : "+v"(pr[m]) : "v"(pr[0]));
+#pragma unroll
+                for (int m = 0; m < M; m++) { w0[m] = pr[m].x; w1[m] = pr[m].y; }
+                grp_step<M, 4>(U, w0);
+                grp_step<M, 4>(U, w1);
+            } else {
+                float w0[M];
+#pragma unroll
+                for (int m = 0; m < M; m++) asm volatile("ds_read_b32 %0, %1" : "=v"(w0[m]) : "v"(sg6_base + row6[m] * 4u));
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0[0]));
+#pragma unroll
+                for (int m = 1; m < M; m++) asm volatile("" : "+v"(w0[m]) : "v"(w0[0]));
+                grp_step<M, 4>(U, w0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);                       // normalisation, statistics
+        if (LW1 != last_LW1) { pos_i = q / (float)LW1; last_LW1 = LW1; }                 // EM.cpp:160
+        float zpart = 0.0f;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t p = p0 + m;
+            const bool valid = (p + 1u >= W) && (p < L);
+            U[m] = valid ? U[m] * pos_i : 0.0f;              // EM.cpp:180
+            zpart += U[m];
+        }
+        const float Z = one_minus_q + wave_sum(zpart);       // EM.cpp:154,181
+        float invZ = __builtin_amdgcn_rcpf(Z);
+        invZ = fmaf(fmaf(-Z, invZ, 1.0f), invZ, invZ);
+        const float invZs = ACCUM ? invZ * a.fix_scale : invZ;
+#pragma unroll
+        for (int m = 0; m < M; m++) U[m] = U[m] * invZs;     // EM.cpp:185-187
+        llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);          // EM.cpp:195
+        sumr_acc += (double)invZ;
+        seq_cnt++;
+
+        if (WRITE_R) {                                       // EM::getR layout: r[L-W-i], i = p-W+1
+            float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                if (p < L) ro[L - 1u - p] = U[m];
+            }
+        }
+
+        if (ACCUM) {
+            // ---- M-step (EM.cpp:236-242): the adjoint chain, wide groups first (they are the motif's last)
+            __builtin_amdgcn_s_setprio(3);
+            unsigned long long F[M], nz[M];
+            uint32_t rad6[M], rad5[M];
+            const uint32_t c5 = lds_offset(cnt5), c6 = lds_offset(cnt6);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                F[m] = to_fixed40(U[m]);
+                nz[m] = __ballot(F[m] != 0ull);
+                rad6[m] = c6 + row6[m] * 8u;
+                rad5[m] = c5 + row5[m] * 8u;
+            }
+            // F is a ring: logical slot m lives in F[(m + off) mod M]; a step of G moves the G slots that arrive
+            // from the next lane in place (one DPP pair each) and their non-zero masks with them
+            static_for<A>([&](auto wc) {
+                constexpr int w = decltype(wc)::value;
+                constexpr int off = (4 * w) % M;
+#pragma unroll
+                for (int m = 0; m < M; m++)
+                    lds_add_u64_exec_big<(int)(w * R6T * 8u)>(rad6[m], F[(m + off) % M], nz[(m + off) % M]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int idx = (c + off) % M;
+                    F[idx] = wave_shl1_u64(F[idx]);
+                    nz[idx] >>= 1;
+                }
+            });
+            static_for<4 * NQ>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if ((uint32_t)u < B) {
+                    constexpr int off = (4 * A + 3 * u) % M;
+#pragma unroll
+                    for (int m = 0; m < M; m++)
+                        lds_add_u64_exec_big<(int)(u * R5T * 8u)>(rad5[m], F[(m + off) % M], nz[(m + off) % M]);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const int idx = (c + off) % M;
+                        F[idx] = wave_shl1_u64(F[idx]);
+                        nz[idx] >>= 1;
+                    }
+                }
+            });
+            // ---- what the virtual count rows collected (one window per cell) goes to the log
+            wave_lds_sync();
+            unsigned long long acc = 0ull;
+            if (fix) {
+                unsigned long long* cell = lane_wide ? cnt6 + (size_t)(T - 1u - lane_t) * R6T + vbase6 + lane_b
+                                                     : cnt5 + (size_t)(B - 1u - lane_t) * R5T + vbase5 + lane_b;
+                acc = *cell;
+                *cell = 0ull;
+            }
+            const unsigned long long nzm = __ballot(acc != 0ull);
+            if (acc != 0ull) {
+                unsigned long long bins = 0ull;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t bin = ((uint32_t)c < lane_G && yfix[c] != Y) ? (lane_col0 + (uint32_t)c) * Y + yfix[c] : 0xffffu;
+                    bins |= (unsigned long long)bin << (16 * c);
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
+                my_log[nlog + rank] = make_ulonglong2(acc, bins);
+            }
+            nlog += (uint32_t)__builtin_popcountll(nzm);
+            wave_lds_sync();
+        }
+    }
+
+    // ---- block epilogue
+    lds_drain();
+    if (lane == 0) {
+        stat_lds[wave * 3 + 0] = llh_acc;
+        stat_lds[wave * 3 + 1] = (double)seq_cnt - (double)one_minus_q * sumr_acc;
+        stat_lds[wave * 3 + 2] = (double)seq_cnt;
+    }
+    __syncthreads();
+    if (a.acc == nullptr) return;                            // getR(): responsibilities only
+    if constexpr (ACCUM) {
+        // logged virtual-row sums -> single-column bins [j][y], which take the wide odds table's place
+        for (uint32_t i = threadIdx.x; i < W * Y; i += THREADS) n1[i] = 0ull;
+        __syncthreads();
+        constexpr uint32_t NB = 8;
+        for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
+            unsigned long long acc[NB], bins[NB];
+#pragma unroll
+            for (uint32_t u = 0; u < NB; u++) {
+                const uint32_t e = e0 + u * 64u + (uint32_t)lane;
+                const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(my_log + min(e, nlog - 1u));
+                acc[u] = __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bins[u] = __hip_atomic_load(ent + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < NB; u++) {
+                if (e0 + u * 64u + (uint32_t)lane < nlog) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const uint32_t bin = (uint32_t)(bins[u] >> (16 * c)) & 0xffffu;
+                        if (bin != 0xffffu) atomicAdd(&n1[bin], acc[u]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t o = threadIdx.x; o < W * Y; o += THREADS) {           // o = y*W + j: consecutive global cells
+            const uint32_t yy = o / W, j = o - yy * W;
+            unsigned long long acc = n1[j * Y + yy];
+            // rows whose position c carries yy: c digits above the 3-mer, G-1-c below it are free
+            if (j < 3u * B) {
+                const uint32_t tt = j / 3u, c = j - 3u * tt;
+                const unsigned long long* tab = cnt5 + (size_t)(B - 1u - tt) * R5T;
+                const uint32_t lowd = 2u * (2u - c), lmask = (1u << lowd) - 1u;
+                unsigned long long part[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+                for (uint32_t r = 0; r < 16u; r++) {
+                    const uint32_t h = r >> lowd, l = r & lmask;
+                    part[r & 3u] += tab[((((h << 6) | yy) << lowd) | l) & 1023u];
+                }
+                acc += (part[0] + part[1]) + (part[2] + part[3]);
+            } else {
+                const uint32_t jj = j - 3u * B, w = jj >> 2, c = jj & 3u;
+                const unsigned long long* tab = cnt6 + (size_t)((uint32_t)A - 1u - w) * R6T;
+                const uint32_t lowd = 2u * (3u - c), lmask = (1u << lowd) - 1u;
+                unsigned long long part[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll 8
+                for (uint32_t r = 0; r < 64u; r++) {
+                    const uint32_t h = r >> lowd, l = r & lmask;
+                    part[r & 3u] += tab[((((h << 6) | yy) << lowd) | l) & 4095u];
+                }
+                acc += (part[0] + part[1]) + (part[2] + part[3]);
+            }
+            if (acc) acc_add(a.acc + o, (long long)acc);
+        }
+    }
+    if (threadIdx.x < 3) {
+        double acc = 0.0;
+        for (uint32_t w = 0; w < WAVES; w++) acc += stat_lds[w * 3 + threadIdx.x];
+        acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
+    }
+}
+
+template <int M, int A, int NQ, int THREADS>
+int launch_mix_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, hipStream_t st) {
+    const size_t lds = a.g.lds_bytes;
+    int rc;
+    if (write_r) {
+        if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, false, true, THREADS>), lds))) return rc;
+        hipLaunchKernelGGL((k_em_mix<M, A, NQ, false, true, THREADS>), dim3(blocks), dim3(THREADS), lds, st, a);
+    } else if (accum) {
+        if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, true, false, THREADS>), lds))) return rc;
+        hipLaunchKernelGGL((k_em_mix<M, A, NQ, true, false, THREADS>), dim3(blocks), dim3(THREADS), lds, st, a);
+    } else {
+        if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, false, false, THREADS>), lds))) return rc;
+        hipLaunchKernelGGL((k_em_mix<M, A, NQ, false, false, THREADS>), dim3(blocks), dim3(THREADS), lds, st, a);
+    }
+    return BAMM_OK;
+}
+
+}  // namespace
+}  // namespace bamm

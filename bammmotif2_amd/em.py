@@ -382,6 +382,12 @@ class EM:
         check(self.lib.bamm_em_plan(self.h, C.byref(g), C.byref(o), C.byref(n)))
         return int(g.value), int(o.value), int(n.value)
 
+    def plan_mixed(self) -> int:
+        """Sequences (of the grouped ones) that go through the mixed-row kernel (csrc/mixed_kernel.h)."""
+        m = C.c_uint64()
+        check(self.lib.bamm_em_plan_mixed(self.h, C.byref(m)))
+        return int(m.value)
+
     def close(self):
         if self.h:
             self.lib.bamm_em_destroy(self.h)

@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--blocks", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--group-layout", type=int, default=-1,
+                    help="table layout of the grouped kernel (bamm_ctx_set_tuning group_layout: 0..3 uniform rows, "
+                         "8 mixed rows); default: the planner's choice")
     ap.add_argument("--force-dist", action="store_true",
                     help="exercise the RCCL all-reduce path even with one rank (self-test)")
     ap.add_argument("--torch-allreduce", action="store_true",
@@ -199,6 +202,8 @@ def main():
     ctx = bm.Context(local_rank, tstream.cuda_stream)
     if args.blocks or args.threads:
         ctx.set_launch(args.blocks, args.threads)
+    if args.group_layout >= 0:
+        ctx.set_tuning(group_layout=args.group_layout)
     begin, end = packed.shard_range(W, rank, world)
     seqs = bm.SeqSet(ctx, packed, begin, end)
     em = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=args.steps + args.warmup + 8,
@@ -302,7 +307,9 @@ def main():
     llh, vdiff, _ = em.trace()
 
     g_seqs, o_seqs, _ = em.plan()
+    mixed_seqs = em.plan_mixed()
     kernel_name = ("k_em_seq (E pass, compacted lists of the non-zero windows) + k_m_list x slices (column-sliced M pass)" if K >= 4 else
+                   "k_em_mix (fused E+M, grouped columns: 5-mer rows, the last groups on 6-mer rows)" if o_seqs == 0 and mixed_seqs == g_seqs else
                    "k_em_grp (fused E+M, grouped columns)" if o_seqs == 0 else
                    "k_em_seq (fused E+M)" if g_seqs == 0 else "k_em_grp + k_em_seq (fused E+M)")
     if rank == 0:

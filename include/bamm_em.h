@@ -249,6 +249,9 @@ int  bamm_em_set_kernel_timing(bamm_em* em, uint32_t every);
 /* how one pass is laid out: sequences that go through the grouped-column kernel (grouped.hip)
  * and through the one-column-at-a-time kernel (kernels.hip), and the kernel launches per pass. */
 int  bamm_em_plan(bamm_em* em, uint64_t* grouped_seqs, uint64_t* percolumn_seqs, uint32_t* launches);
+/* of the grouped ones: sequences that go through the mixed-row flavour (csrc/mixed_kernel.h: K = 2, the motif's
+ * last W mod 3 groups of four columns on 6-mer rows)                                              */
+int  bamm_em_plan_mixed(bamm_em* em, uint64_t* mixed_seqs);
 
 /* ------------------------------------------------------------------ seeding ------------- */
 /* The pass over the sequences of Motif::initFromPWM (Motif.cpp:228-311): 0th-order posterior of

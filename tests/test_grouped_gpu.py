@@ -47,6 +47,11 @@ GROUPED_CASES = [
     dict(name="g_k2_m40_48", N=10, L0=1280, W=20, K=2, n_frac=0.0005, ragged=240),    # L 2081..3041
     dict(name="g_k1_m40_48_ss", N=10, L0=2600, W=14, K=1, ss=True, n_frac=0.0005, ragged=460),
     dict(name="g_k0_m48", N=6, L0=1500, W=8, K=0, ragged=30),                        # L 2941..3061
+    # mixed rows (csrc/mixed_kernel.h: K = 2, both strands, W = 3 B + 4 A): one and two wide groups, 4..8 positions per lane
+    dict(name="g_mix_a1_m4", N=96, L0=110, W=13, K=2, ragged=10),
+    dict(name="g_mix_a2_m5", N=96, L0=140, W=14, K=2, n_frac=0.002, ragged=12),
+    dict(name="g_mix_a1_m6", N=80, L0=170, W=16, K=2, n_frac=0.002, ragged=14),
+    dict(name="g_mix_a2_m8", N=64, L0=235, W=17, K=2, n_frac=0.002, ragged=16),
     # 2 and 3 positions per lane (short reads: 65..192 positions), where a group is as wide as a lane's run
     dict(name="g_k2_m2_ds", N=200, L0=40, W=12, K=2, n_frac=0.002, ragged=6),        # L 69..93: G = 2
     dict(name="g_k2_m3_ds", N=160, L0=80, W=10, K=2, n_frac=0.002, ragged=12),       # L 137..185: G = 3
@@ -220,6 +225,34 @@ def test_handles_created_from_several_host_threads(gpu_ctx, orc):
         assert np.array_equal(em.getV(), out[f])
         em.close()
     ss.close()
+
+
+_MIXED = [d for d in GROUPED_CASES if d["name"].startswith("g_mix_") or d["name"] in ("g_k2_ds_m7_N", "g_k2_m10")]
+
+
+@pytest.mark.parametrize("spec", _MIXED, ids=[d["name"] for d in _MIXED])
+def test_mixed_rows_are_planned_and_agree_with_uniform_rows(spec, gpu_ctx, orc):
+    """The planner sends these shapes through k_em_mix (the motif's last W mod 3 groups on 6-mer rows); the uniform
+    5-mer rows (group_layout 3) compute the same model: products are rounded group-wise either way."""
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    grouped = em.plan()[0]
+    assert grouped > 0 and em.plan_mixed() == grouped
+    em.iterate(4)
+    v_mix, llh_mix, n_mix = em.getV(), em.trace()[0].copy(), em.getCounts()
+    em.close()
+    gpu_ctx.set_tuning(group_layout=3)
+    try:
+        em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order)
+    finally:
+        gpu_ctx.set_tuning(group_layout=-1)
+    # (with scattered N the split differs by a sequence or two: a group of four reaches one position further)
+    assert abs(em.plan()[0] - grouped) <= 2 and em.plan_mixed() == 0
+    em.iterate(4)
+    np.testing.assert_allclose(llh_mix, em.trace()[0], rtol=2e-6)
+    np.testing.assert_allclose(n_mix, em.getCounts(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(v_mix, em.getV(), rtol=2e-5, atol=1e-9)
+    em.close(); ss.close()
 
 
 @pytest.mark.parametrize("layout", [0, 2, 3])

@@ -178,6 +178,67 @@ int run_list(int iters, int active, int nnz, float* sink) {
     return 0;
 }
 
+// A mixed-row formulation (not built): W = 20 at K = 2 as groups of 4+4+3+3+3+3 columns -- two groups on 6-mer rows
+// (4096 rows: odds [4096][2] floats, counts [4096][2] u64), four on 5-mer rows (odds [1100][4] floats, counts
+// [1100][5] u64, odd stride) -- 6 adds and one b64 + one b128 gather per position instead of 7 and two b128.
+__global__ void __launch_bounds__(1024) k_mix_66(int iters, int active_per_64, float* sink) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    constexpr uint32_t R6 = 4096u + 128u, R5 = 1100u;
+    const uint32_t o6 = 0, o5 = o6 + R6 * 8u, c6 = o5 + R5 * 16u, c5 = c6 + R6 * 16u, total = c5 + R5 * 40u;
+    for (uint32_t i = threadIdx.x; i < total / 4u; i += blockDim.x) reinterpret_cast<float*>(lds)[i] = 1.0f;
+    __syncthreads();
+    const uint32_t base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds;
+    uint32_t x = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    float acc = 0.0f;
+    for (int it = 0; it < iters; it++) {
+        uint32_t r6[M], r5[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) { x = x * 1664525u + 1013904223u; r6[m] = (x >> 8) & 4095u; r5[m] = (x >> 20) % R5; }
+        {
+            f32x4 v[M];
+            float2 w[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) asm volatile("ds_read_b64 %0, %1" : "=v"(w[m]) : "v"(base + o6 + r6[m] * 8u));
+#pragma unroll
+            for (int m = 0; m < M; m++) v[m] = rd128<0>(base + o5 + r5[m] * 16u);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
+#pragma unroll
+            for (int m = 0; m < M; m++) asm volatile("" : "+v"(v[m]), "+v"(w[m]) : "v"(v[0]));
+#pragma unroll
+            for (int m = 0; m < M; m++) acc += v[m].x + w[m].x;
+        }
+        unsigned long long mask[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) { x = x * 1664525u + 1013904223u; mask[m] = __ballot((int)((x >> 10) & 63u) < active_per_64); }
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const uint32_t a6 = base + c6 + r6[m] * 16u, a5 = base + c5 + r5[m] * 40u;
+            add64<0>(a6, 3ull, mask[m]); add64<8>(a6, 3ull, mask[(m + 1) % M]);
+            add64<0>(a5, 3ull, mask[(m + 2) % M]); add64<8>(a5, 3ull, mask[(m + 3) % M]);
+            add64<16>(a5, 3ull, mask[(m + 4) % M]); add64<24>(a5, 3ull, mask[(m + 5) % M]);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (acc == 12345.678f) sink[0] = acc;
+}
+
+int run_66(int iters, int active, float* sink, double* rate_out) {
+    const size_t lds = (4096 + 128) * 8 + 1100 * 16 + (4096 + 128) * 16 + 1100 * 40;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mix_66), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mix_66, dim3(256), dim3(1024), lds, 0, iters / 10, active, sink);
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(k_mix_66, dim3(256), dim3(1024), lds, 0, iters, active, sink);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("mixed rows (4+4 on 6-mers, 3+3+3+3 on 5-mers): 7 b64 + 7 b128 gathers + 42 adds  %8.3f ms  %6.2f ns per sequence-equivalent per CU\n",
+           ms, ms * 1e6 / (16.0 * iters));
+    if (rate_out) *rate_out = 256.0 * 16.0 * (double)iters * 56.0 / (ms * 1e-3);
+    return 0;
+}
+
 template <bool R, bool A>
 int run(const char* name, int per_iter, int iters, int active, float* sink, double* rate_out) {
     const size_t lds = ((ROWS * ROWSTRIDE_B + 15) & ~15) + ROWS * T * 8;
@@ -210,9 +271,14 @@ int main(int argc, char** argv) {
         const int nnzs[] = {64, 105, 128, 160, 192, 256};
         for (int nnz : nnzs) if (run_list(iters, active, nnz, sink)) return 1;
     }
+    double mixed = 0;
+    if (run_66(iters, active, sink, &mixed)) return 1;
     printf("{\"wave_instr_per_s\": %.6e, \"reads_only_wave_instr_per_s\": %.6e, \"adds_only_wave_instr_per_s\": %.6e, "
            "\"active_lanes_per_add\": %d, \"what\": \"LDS-only loop of k_em_grp's mix on the bench workload: 14 ds_read_b128 + 49 "
-           "predicated ds_add_u64 per sequence, random rows of the same tables, 16 waves per CU (tools/lds_mix_bench.hip)\"}\n",
-           mix, r, a, active);
+           "predicated ds_add_u64 per sequence, random rows of the same tables, 16 waves per CU (tools/lds_mix_bench.hip)\", "
+           "\"mixed_rows_wave_instr_per_s\": %.6e, \"mixed_rows_what\": \"LDS-only loop of k_em_mix's mix on the bench workload: 7 ds_read_b64 "
+           "+ 7 ds_read_b128 + 42 predicated ds_add_u64 per sequence, random rows of the same tables, 16 waves per CU "
+           "(tools/lds_mix_bench.hip)\"}\n",
+           mix, r, a, active, mixed);
     return 0;
 }

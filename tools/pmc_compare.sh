@@ -28,7 +28,7 @@ for d in sys.argv[2:]:
             acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("== bench.py", flags)
 for k, cs in acc.items():
-    if not any(t in k for t in ("k_em_grp", "k_em_seq")): continue
+    if not any(t in k for t in ("k_em_grp", "k_em_seq", "k_em_mix")): continue
     print("  ", k[:70])
     for c_, v in sorted(cs.items()):
         print("      %-26s %.4g  (%d dispatches)" % (c_, sum(v) / len(v), len(v)))

@@ -40,7 +40,7 @@ def hbm_bytes(m):
 
 
 XCDS, CUS = 8.0, 256.0
-seq_kernels = [k for k in summary if any(t in k for t in ("k_em_grp", "k_em_seq", "k_e_slice", "k_m_slice", "k_m_list", "k_long_em"))]
+seq_kernels = [k for k in summary if any(t in k for t in ("k_em_grp", "k_em_mix", "k_em_seq", "k_e_slice", "k_m_slice", "k_m_list", "k_long_em"))]
 updates = next((summary[k]["dispatches"] for k in summary if "k_update" in k), None)
 if args.order >= 4 and seq_kernels and updates:
     per_iter, parts = 0.0, {}
@@ -59,7 +59,8 @@ if args.order >= 4 and seq_kernels and updates:
     res.update(kernel="E pass + M slices of one iteration", hbm_bytes_per_launch=per_iter, per_kernel=parts,
                gpu_cycles_per_iteration=cyc)
 else:
-    main = next((k for k in summary if "k_em_grp" in k and "true, false" in k), None) or \
+    main = next((k for k in summary if "k_em_mix" in k and "true, false" in k), None) or \
+        next((k for k in summary if "k_em_grp" in k and "true, false" in k), None) or \
         next((k for k in summary if "k_em_seq" in k), None)
     m = summary.get(main, {}) if main else {}
     if main and "FETCH_SIZE" in m and "WRITE_SIZE" in m:
@@ -80,5 +81,10 @@ if args.lds_mix and os.path.exists(args.lds_mix):
     for line in open(args.lds_mix):
         if line.startswith("{"):
             res["lds_mix_bench"] = json.loads(line)
+            if "k_em_mix" in str(res.get("kernel", "")) and "mixed_rows_wave_instr_per_s" in res["lds_mix_bench"]:
+                # the ceiling that belongs to the kernel that ran: the mixed-row instruction mix
+                res["lds_mix_bench"]["uniform_rows_wave_instr_per_s"] = res["lds_mix_bench"]["wave_instr_per_s"]
+                res["lds_mix_bench"]["wave_instr_per_s"] = res["lds_mix_bench"]["mixed_rows_wave_instr_per_s"]
+                res["lds_mix_bench"]["what"] = res["lds_mix_bench"]["mixed_rows_what"]
 json.dump(res, open(args.out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_mean_counters"}))
