@@ -37,6 +37,18 @@ __device__ __forceinline__ unsigned long long to_fixed40(float r) {
     const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(a) * 4294967296.0f);   // v_fract_f32: a - floor(a), exact
     return ((unsigned long long)hi << 32) | lo;
 }
+// a * b with 0 * anything = 0 (v_mul_legacy_f32; identical to the IEEE product for non-zero finite operands)
+__device__ __forceinline__ float mul_legacy(float a, float b) {
+    float r;
+    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// the same for a = r * 2^8 (the caller folds the power of two into a factor it applies anyway): same integer
+__device__ __forceinline__ unsigned long long to_fixed40_pre(float a) {
+    const uint32_t hi = (uint32_t)a;
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(a) * 4294967296.0f);
+    return ((unsigned long long)hi << 32) | lo;
+}
 constexpr double kFixedScaleInv = 1.0 / 1099511627776.0;
 // the pass statistics travel in the same integer accumulator as the counts: log-likelihood in units of
 // 2^-24 (|log Z| < 89 per sequence: 2^32 sequences fit), sum of r in units of 2^-30, the sequence count as is

@@ -258,6 +258,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     uint32_t seq_cnt = 0;
     uint32_t last_LW1 = 0;
     float pos_i = 0.0f;
+    constexpr bool kCachePos = M <= 16;                      // the longer classes have no registers to spare for it
+    [[maybe_unused]] float pos_m[kCachePos ? M : 1];
+#pragma unroll
+    for (int m = 0; m < (kCachePos ? M : 1); m++) pos_m[m] = 0.0f;
     // K = 3: this wave's log of virtual-row counts (see FIXG above): entries {sum, bins of its G columns}
     [[maybe_unused]] ulonglong2* my_log = nullptr;
     [[maybe_unused]] uint32_t nlog = 0;
@@ -439,17 +443,36 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             }
         }
         __builtin_amdgcn_s_setprio(1);                       // normalisation, statistics
-        if (LW1 != last_LW1) {                           // EM.cpp:160; one IEEE division per distinct length
-            pos_i = q / (float)LW1;
-            last_LW1 = LW1;
-        }
         float zpart = 0.0f;
+        if constexpr (kCachePos) {
+            if (LW1 != last_LW1) {                       // EM.cpp:160; one IEEE division per distinct length
+                pos_i = q / (float)LW1;
+                last_LW1 = LW1;
+                // q/LW1 for the slots that hold a window (it ends at p: p + 1 >= W and p < L), 0 for the others:
+                // kept per distinct length, one multiply per slot instead of two compares, a select and a multiply
 #pragma unroll
-        for (int m = 0; m < M; m++) {
-            const uint32_t p = p0 + m;
-            const bool valid = (p + 1u >= W) && (p < L);
-            U[m] = valid ? U[m] * pos_i : 0.0f;          // EM.cpp:180
-            zpart += U[m];
+                for (int m = 0; m < M; m++) {
+                    const uint32_t p = p0 + m;
+                    pos_m[m] = ((p + 1u >= W) && (p < L)) ? pos_i : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                U[m] = mul_legacy(U[m], pos_m[m]);   // EM.cpp:180; v_mul_legacy: 0 * anything = 0
+                zpart += U[m];
+            }
+        } else {
+            if (LW1 != last_LW1) {
+                pos_i = q / (float)LW1;
+                last_LW1 = LW1;
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                const bool valid = (p + 1u >= W) && (p < L);
+                U[m] = valid ? U[m] * pos_i : 0.0f;      // EM.cpp:180
+                zpart += U[m];
+            }
         }
         const float Z = one_minus_q + wave_sum(zpart);   // EM.cpp:154,181
         // 1/Z: v_rcp_f32 (1 ulp) + one Newton step (error well below an ulp; r = U * invZ stays within
@@ -457,7 +480,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         float invZ = __builtin_amdgcn_rcpf(Z);
         invZ = fmaf(fmaf(-Z, invZ, 1.0f), invZ, invZ);
         // the M-step wants r in units of the count accumulator: the power-of-two scale rides on 1/Z (exact)
-        const float invZs = ACCUM ? invZ * a.fix_scale : invZ;
+        const float invZs = ACCUM ? invZ * (a.fix_scale * 256.0f) : invZ;    // 2^8: the fixed-point split below starts there
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZs; // EM.cpp:185-187
         // EM.cpp:195.  v_log_f32 (log2, 1 ulp of its result) times ln 2: as close to logf(Z) as Z itself is
@@ -481,7 +504,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
             __builtin_amdgcn_s_setprio(3);                   // M-step
             unsigned long long F[M];
 #pragma unroll
-            for (int m = 0; m < M; m++) F[m] = to_fixed40(U[m]);
+            for (int m = 0; m < M; m++) F[m] = to_fixed40_pre(U[m]);
             const uint32_t ng_base = lds_offset(ng);
 
             {

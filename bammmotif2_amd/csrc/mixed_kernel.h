@@ -112,6 +112,9 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0, last_LW1 = 0;
     float pos_i = 0.0f;
+    float pos_m[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) pos_m[m] = 0.0f;
     [[maybe_unused]] ulonglong2* my_log = nullptr;           // the fix lanes' non-zero sums: {sum, 4 bins of 16 bits}
     [[maybe_unused]] uint32_t nlog = 0;
     if constexpr (ACCUM)
@@ -128,9 +131,8 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
 
-        // ---- rows of every position out of one 32-bit stream window per lane; sE = the window ending at LW1-1
-        uint32_t row5[M], row6[M];
-        uint32_t sE;
+        // ---- one 32-bit stream window per lane (it ends at the lane's last position); sE = the window ending at LW1-1
+        uint32_t X, sE;
         {
             constexpr int NSEL = RawSeqG<M>::NSEL;
             const uint32_t wi0 = p0 >> 4;
@@ -143,18 +145,14 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                 lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
                 hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
             }
-            const uint32_t X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                const bool in = p0 + m < LW1;                                            // EM.cpp:167
-                row5[m] = in ? ((X >> (2 * (M - 1 - m))) & 1023u) : R5N;
-                row6[m] = in ? ((X >> (2 * (M - 1 - m))) & 4095u) : R6N;
-            }
+            X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
             sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
         }
 
         // ---- virtual rows (one index for both tables): B group ends from xlo on next to an exception, the
-        // positions LW1 .. LW1+2 whose groups are cut by the edge
+        // positions LW1 .. LW1+2 whose groups are cut by the edge.  The fix lanes' reads of the single-column table
+        // are issued first and waited for after the rows of all positions are decoded: the wave is not yet bound
+        // by the LDS pipe here, the round trip is latency it would otherwise sit out.
         const uint32_t xw = __builtin_amdgcn_readfirstlane(cur.xr.x);
         const uint32_t Bx = (xw >> 12) & 0xfu;
         const uint32_t xlo = xw & 0xfffu;
@@ -163,38 +161,46 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         const bool fixJ = lane_b < Bx;
         const bool fixE = lane_b >= kMixBj && lane_b < kMixBj + nE;
         const bool fix = fixJ || fixE;
-        {
+        float fs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (fix) {
+            const uint32_t pv = fixJ ? xlo + lane_b : LW1 + (lane_b - kMixBj);         // the row's position
+            const uint32_t s1_base = lds_offset(s1);
 #pragma unroll
-            for (int m = 0; m < M; m++) {
-                const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
-                if (k2 < Bx) { row5[m] = vbase5 + k2; row6[m] = vbase6 + k2; }
-                if (k3 < nE) { row5[m] = vbase5 + kMixBj + k3; row6[m] = vbase6 + kMixBj + k3; }
-            }
-            if (fix) {
-                float f = 1.0f;
-                const uint32_t pv = fixJ ? xlo + lane_b : LW1 + (lane_b - kMixBj);     // the row's position
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    if ((uint32_t)c < lane_G) {
-                        const uint32_t pos = pv - (lane_G - 1u) + (uint32_t)c;       // wraps for positions before the sequence
-                        uint32_t yc;
-                        if (fixJ) {                                                // record fields start at position xlo-3
-                            const uint32_t k = lane_b + (uint32_t)c + 4u - lane_G;
-                            const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
-                            yc = (word >> (7u * (k & 3u))) & 0x7fu;
-                        } else {
-                            yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);
-                        }
-                        if (pos >= LW1) yc = Y;                                    // EM.cpp:167 (also pos < 0)
-                        yfix[c] = yc;
-                        if (yc != Y) f *= s1[__umul24(lane_col0 + (uint32_t)c, Ys) + yc];
+            for (int c = 0; c < 4; c++) {
+                uint32_t yc = Y;                                                       // the column's neutral entry
+                const uint32_t colc = min(lane_col0 + (uint32_t)c, W - 1u);
+                if ((uint32_t)c < lane_G) {
+                    const uint32_t pos = pv - (lane_G - 1u) + (uint32_t)c;           // wraps for positions before the sequence
+                    if (fixJ) {                                                        // record fields start at position xlo-3
+                        const uint32_t k = lane_b + (uint32_t)c + 4u - lane_G;
+                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                    } else {
+                        yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);
                     }
+                    if (pos >= LW1) yc = Y;                                            // EM.cpp:167 (also pos < 0)
                 }
-                if (lane_wide) sg6[(vbase6 + lane_b) * A + (lane_t - B)] = f;
-                else sg5[__umul24(vbase5 + lane_b, rs5) + pad + lane_t] = f;
+                yfix[c] = yc;
+                asm volatile("ds_read_b32 %0, %1" : "=v"(fs[c]) : "v"(s1_base + (__umul24(colc, Ys) + yc) * 4u));
             }
-            wave_lds_sync();
         }
+        uint32_t row5[M], row6[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            const bool in = p0 + m < LW1;                                                // EM.cpp:167
+            row5[m] = in ? ((X >> (2 * (M - 1 - m))) & 1023u) : R5N;
+            row6[m] = in ? ((X >> (2 * (M - 1 - m))) & 4095u) : R6N;
+            const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
+            if (k2 < Bx) { row5[m] = vbase5 + k2; row6[m] = vbase6 + k2; }
+            if (k3 < nE) { row5[m] = vbase5 + kMixBj + k3; row6[m] = vbase6 + kMixBj + k3; }
+        }
+        if (fix) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0]), "+v"(fs[1]), "+v"(fs[2]), "+v"(fs[3]));
+            const float f = ((fs[0] * fs[1]) * fs[2]) * fs[3];                         // column order; a neutral entry is 1.0f
+            if (lane_wide) sg6[(vbase6 + lane_b) * A + (lane_t - B)] = f;
+            else sg5[__umul24(vbase5 + lane_b, rs5) + pad + lane_t] = f;
+        }
+        wave_lds_sync();
 
         // ---- E-step: narrow groups (straight-line over NQ quads, neutral slots in front), then the wide ones
         __builtin_amdgcn_s_setprio(2);
@@ -203,43 +209,50 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             uint32_t ra[M];
 #pragma unroll
             for (int m = 0; m < M; m++) ra[m] = sg5_base + __umul24(row5[m], rs5 * 4u);        // v_mad_u32_u24: full rate
-            grp_chain<M, 3, NQ>(ra, U);
+            // the wide groups' odds are on their way while the narrow groups are chained (one round trip, not two)
+            float2 pr[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                if constexpr (A == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(pr[m]) : "v"(sg6_base + row6[m] * 8u));
+                else asm volatile("ds_read_b32 %0, %1" : "=v"(pr[m].x) : "v"(sg6_base + row6[m] * 4u));
+            }
+            grp_chain<M, 3, NQ>(ra, U);                      // waits with lgkmcnt(0): the reads above have landed as well
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[0]));
+#pragma unroll
+            for (int m = 1; m < M; m++) asm volatile("" : "+v"(pr[m]) : "v"(pr[0]));
+            float w0[M];
+#pragma unroll
+            for (int m = 0; m < M; m++) w0[m] = pr[m].x;
+            grp_step<M, 4>(U, w0);
             if constexpr (A == 2) {
-                float w0[M], w1[M];
-                float2 pr[M];
+                float w1[M];
 #pragma unroll
-                for (int m = 0; m < M; m++) asm volatile("ds_read_b64 %0, %1" : "=v"(pr[m]) : "v"(sg6_base + row6[m] * 8u));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[0]));
-#pragma unroll
-                for (int m = 1; m < M; m++) asm volatile("" : "+v"(pr[m]) : "v"(pr[0]));
-#pragma unroll
-                for (int m = 0; m < M; m++) { w0[m] = pr[m].x; w1[m] = pr[m].y; }
-                grp_step<M, 4>(U, w0);
+                for (int m = 0; m < M; m++) w1[m] = pr[m].y;
                 grp_step<M, 4>(U, w1);
-            } else {
-                float w0[M];
-#pragma unroll
-                for (int m = 0; m < M; m++) asm volatile("ds_read_b32 %0, %1" : "=v"(w0[m]) : "v"(sg6_base + row6[m] * 4u));
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0[0]));
-#pragma unroll
-                for (int m = 1; m < M; m++) asm volatile("" : "+v"(w0[m]) : "v"(w0[0]));
-                grp_step<M, 4>(U, w0);
             }
         }
         __builtin_amdgcn_s_setprio(1);                       // normalisation, statistics
-        if (LW1 != last_LW1) { pos_i = q / (float)LW1; last_LW1 = LW1; }                 // EM.cpp:160
+        if (LW1 != last_LW1) {                           // EM.cpp:160; one IEEE division per distinct length
+            pos_i = q / (float)LW1;
+            last_LW1 = LW1;
+            // q/LW1 for the slots that hold a window (it ends at p: p + 1 >= W and p < L), 0 for the others: kept
+            // per distinct length, one multiply per slot instead of two compares, a select and a multiply
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const uint32_t p = p0 + m;
+                pos_m[m] = ((p + 1u >= W) && (p < L)) ? pos_i : 0.0f;
+            }
+        }
         float zpart = 0.0f;
 #pragma unroll
         for (int m = 0; m < M; m++) {
-            const uint32_t p = p0 + m;
-            const bool valid = (p + 1u >= W) && (p < L);
-            U[m] = valid ? U[m] * pos_i : 0.0f;              // EM.cpp:180
+            U[m] = mul_legacy(U[m], pos_m[m]);   // EM.cpp:180; v_mul_legacy: 0 * anything = 0
             zpart += U[m];
         }
         const float Z = one_minus_q + wave_sum(zpart);       // EM.cpp:154,181
         float invZ = __builtin_amdgcn_rcpf(Z);
         invZ = fmaf(fmaf(-Z, invZ, 1.0f), invZ, invZ);
-        const float invZs = ACCUM ? invZ * a.fix_scale : invZ;
+        const float invZs = ACCUM ? invZ * (a.fix_scale * 256.0f) : invZ;    // 2^8: the fixed-point split below starts there
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZs;     // EM.cpp:185-187
         llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);          // EM.cpp:195
@@ -263,7 +276,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             const uint32_t c5 = lds_offset(cnt5), c6 = lds_offset(cnt6);
 #pragma unroll
             for (int m = 0; m < M; m++) {
-                F[m] = to_fixed40(U[m]);
+                F[m] = to_fixed40_pre(U[m]);
                 nz[m] = __ballot(F[m] != 0ull);
                 rad6[m] = c6 + row6[m] * 8u;
                 rad5[m] = c5 + row5[m] * 8u;
