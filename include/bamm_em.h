@@ -113,9 +113,11 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
 
 /* kernel-selection switches, applied to EM handles created afterwards (benchmarks and the tests that
  * compare one kernel with another; results agree within the parity bar whatever is chosen):
- *   "grouped"      1/0  grouped-column kernel for K <= 2 (default 1; 0 = one column at a time)
+ *   "grouped"      1/0  grouped-column kernel for K <= 3 (default 1; 0 = one column at a time)
  *   "group_size"   0 = planner's choice, 2..4 = columns per table row
- *   "group_layout" -1 = planner's choice, 0..3 = table layout (csrc/grouped.hip: grp_geometry)
+ *   "group_layout" -1 = planner's choice, 0..3 = table layout of the uniform rows (csrc/grouped.hip:
+ *                       grp_geometry), 8 = mixed rows only (csrc/mixed_kernel.h; where they do not apply
+ *                       the sequences go one column at a time)
  *   "sparse"       1/0  compacted lists of the non-zero windows in the M-step (default 1)
  *   "e_fused"      1/0  sliced path: whole-table E pass when the odds table fits LDS (default 1)
  *   "e_list"       1/0  sliced path: the E pass hands the M slices compacted lists of the non-zero
