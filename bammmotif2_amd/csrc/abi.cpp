@@ -863,7 +863,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
         }
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
-            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
+            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, (uint64_t)b.count * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge

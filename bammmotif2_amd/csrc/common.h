@@ -128,8 +128,10 @@ struct GrpKernelArgs {
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply
 bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, bool accum, uint32_t logC, uint32_t layout,
                   GrpGeom* out);
-bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t forced_G, int forced_layout,
-              uint32_t* G, uint32_t* logC, uint32_t* layout);   // false: use k_em_seq
+// enough_work: the launch has enough sequences for the mixed rows' larger tables to pay (their prologue and
+// epilogue cost 4-8 us more per launch: break-even near 40k sequences of 200 bp)
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, bool enough_work, uint32_t forced_G,
+              int forced_layout, uint32_t* G, uint32_t* logC, uint32_t* layout);   // false: use k_em_seq
 bool grp_supported_class(int M, uint32_t K);
 int launch_em_grp_long(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,
                        hipStream_t st);   // grouped_long.hip: 20..32 positions per lane

@@ -136,8 +136,8 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
 // `many_exceptions`: most sequences of the launch carry exceptions anyway (double-stranded sets: the
 // strand junction), so the fix lanes run per sequence whether or not the edge rows are virtual.
 // forced / forced_layout: bamm_ctx_set_tuning("group_size" / "group_layout"), 0 / -1 = the planner's choice
-bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, uint32_t forced, int forced_layout,
-              uint32_t* G_out, uint32_t* logC_out, uint32_t* layout_out) {
+bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exceptions, bool enough_work, uint32_t forced,
+              int forced_layout, uint32_t* G_out, uint32_t* logC_out, uint32_t* layout_out) {
     // layouts in order of preference.  Sets with exceptions everywhere run the fix lanes per sequence
     // anyway: virtual edge rows cost them nothing extra, save the decode's partial-row patches and make
     // the tables small enough for the odd stride (K=2: 1.08 -> 1.01 ms, K=1: 1.05 -> 0.98 ms).  Clean
@@ -146,7 +146,7 @@ bool grp_plan(uint32_t K, uint32_t W, int M, uint32_t waves, bool many_exception
     const uint32_t order_exc[6] = {7u, 3u, 6u, 2u, 4u, 0u}, order_clean[6] = {6u, 2u, 4u, 0u, 7u, 3u};
     // K = 2, W not a multiple of 3: one group less with the motif's last columns on 6-mer rows (mixed_kernel.h);
     // its edge rows are virtual, so like layouts 3 / 7 it is for sets that run the fix lanes per sequence anyway
-    if (K == 2u && many_exceptions && (forced == 0u || forced == 4u) && (forced_layout < 0 || forced_layout == 8)) {
+    if (K == 2u && many_exceptions && (forced == 0u || forced == 4u) && ((forced_layout < 0 && enough_work) || forced_layout == 8)) {
         GrpGeom g;
         if (mix_geometry(K, W, M, waves, true, &g)) {
             *G_out = 4u; *logC_out = 0u; *layout_out = g.layout;

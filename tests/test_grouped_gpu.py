@@ -231,14 +231,30 @@ _MIXED = [d for d in GROUPED_CASES if d["name"].startswith("g_mix_") or d["name"
 
 
 @pytest.mark.parametrize("spec", _MIXED, ids=[d["name"] for d in _MIXED])
-def test_mixed_rows_are_planned_and_agree_with_uniform_rows(spec, gpu_ctx, orc):
-    """The planner sends these shapes through k_em_mix (the motif's last W mod 3 groups on 6-mer rows); the uniform
-    5-mer rows (group_layout 3) compute the same model: products are rounded group-wise either way."""
+def test_mixed_rows_agree_with_exact_arithmetic_and_uniform_rows(spec, gpu_ctx, orc):
+    """k_em_mix (the motif's last W mod 3 groups on 6-mer rows; group_layout 8 -- the planner picks it by itself
+    only for launches of tens of thousands of sequences) against the fp64 restatement, the oracle's r, and the
+    uniform 5-mer rows (group_layout 3): products are rounded group-wise either way."""
     c = Case(**spec)
-    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    gpu_ctx.set_tuning(group_layout=8)
+    try:
+        em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
+    finally:
+        gpu_ctx.set_tuning(group_layout=-1)
     grouped = em.plan()[0]
     assert grouped > 0 and em.plan_mixed() == grouped
-    em.iterate(4)
+    # E-step against the oracle, then one step against exact arithmetic
+    em.EStep()
+    Kb = min(c.bg_order, c.K)
+    r_o, llh_o = orc.estep(kmer, off, c.K, c.W, orc.linear_s(c.v0, vbg, c.K, c.W, Kb), c.q)
+    r_g = em.getR()
+    np.testing.assert_allclose(r_g, r_o, rtol=1e-5, atol=1e-12)
+    assert np.array_equal(r_g == 0, r_o == 0)
+    np.testing.assert_allclose(em.getLLH(), llh_o, rtol=2e-6, atol=2e-6 * c.N)
+    v64, *_ = orc.em_step_f64(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q)
+    em.iterate(1)
+    np.testing.assert_allclose(em.getV(), v64, rtol=1e-6, atol=1e-9)
+    em.iterate(3)
     v_mix, llh_mix, n_mix = em.getV(), em.trace()[0].copy(), em.getCounts()
     em.close()
     gpu_ctx.set_tuning(group_layout=3)
@@ -253,6 +269,19 @@ def test_mixed_rows_are_planned_and_agree_with_uniform_rows(spec, gpu_ctx, orc):
     np.testing.assert_allclose(n_mix, em.getCounts(), rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(v_mix, em.getV(), rtol=2e-5, atol=1e-9)
     em.close(); ss.close()
+
+
+def test_planner_picks_mixed_rows_for_large_launches(gpu_ctx, orc):
+    """The bench shape (W = 20, K = 2, both strands) with enough sequences goes through k_em_mix by itself; a small
+    set of the same shape stays on the uniform rows (the larger tables cost 4-8 us per launch)."""
+    for n, mixed in ((60000, True), (3000, False)):
+        c = Case(name="g_plan", N=n, L0=200, W=20, K=2, ragged=0)
+        em, ss, *_ = make_em(gpu_ctx, c, orc)
+        assert em.plan()[0] == n
+        assert (em.plan_mixed() == n) == mixed
+        em.iterate(2)
+        assert np.isfinite(em.getLLH())
+        em.close(); ss.close()
 
 
 @pytest.mark.parametrize("layout", [0, 2, 3])
