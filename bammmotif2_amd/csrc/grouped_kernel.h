@@ -35,12 +35,13 @@
 // quads (rows start on all 16 bank-quads), a straight-line E-chain, the group index of the count
 // table in the add's immediate offset.
 //
-// Things measured and left out: a compacted list of the non-zero windows for
-// the M-step (built three ways; an LDS add costs in proportion to its active lanes, so 14 full adds
-// plus the list's writes, row reads and waits never beat the 49 sparse ones); the virtual-row counts
-// as no-return atomics on an HBM table instead of the LDS one (+0.19 ms per pass); per-step guards on
-// the run-time group count in the E-chain (each merge point costs M register moves: the chain is
-// straight-line over padded neutral slots instead).
+// Things measured and left out (DESIGN.md sections 4 and 7): a compacted list of the non-zero windows for the
+// M-step (built three ways in round 1, and its LDS traffic alone measured in round 2: a predicated LDS write or
+// add costs 6.4 cycles however few lanes take part, so 14 full adds plus the list's writes, row reads and waits
+// never beat the 49 sparse ones); the virtual-row counts as no-return atomics on an HBM table instead of the
+// LDS one (a CU retires one scattered device-scope atomic per ~18 ns); per-step guards on the run-time group
+// count in the E-chain (each merge point costs M register moves: the chain is straight-line over padded
+// neutral slots instead).
 
 #pragma once
 #include "device_utils.h"
@@ -284,26 +285,33 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
 
-        // ---- row index of every position; sE = the 32-bit stream window that ends at position LW1-1
+        // ---- row index of every position; sE = the 32-bit stream window that ends at position LW1-1.  With one
+        // stream window per lane (up to 12 positions per lane) the rows themselves are decoded AFTER the fix lanes
+        // have issued their reads of the single-column table (decode_rows below): the round trip runs under them.
         uint32_t row[M];
         uint32_t sE;
-        {
-            constexpr int NSEL = RawSeqG<M>::NSEL;
-            const uint32_t wi0 = p0 >> 4;
-            const uint32_t pE = LW1 - 1u, lpE = pE / (uint32_t)M;            // lane that holds position LW1-1
-            constexpr bool kOneWindow = 2 * (M - 1) + 10 <= 32;               // rows are at most 10 bits (K+G <= 5)
-            if constexpr (kOneWindow) {
-                // one 32-bit window of the stream ending at the lane's LAST position; position p0+m
-                // is that window shifted by a compile-time 2*(M-1-m) bits
-                const uint32_t pe = p0 + (uint32_t)(M - 1);
-                const uint32_t sel = (pe >> 4) - wi0;
-                uint32_t lo = cur.w[1], hi = cur.w[0];
+        constexpr int NSEL = RawSeqG<M>::NSEL;
+        constexpr bool kOneWindow = 2 * (M - 1) + 10 <= 32;                   // rows are at most 10 bits (K+G <= 5)
+        const uint32_t wi0 = p0 >> 4;
+        const uint32_t pE = LW1 - 1u, lpE = pE / (uint32_t)M;                // lane that holds position LW1-1
+        [[maybe_unused]] uint32_t X = 0;
+        if constexpr (kOneWindow) {
+            // one 32-bit window of the stream ending at the lane's LAST position; position p0+m
+            // is that window shifted by a compile-time 2*(M-1-m) bits
+            const uint32_t pe = p0 + (uint32_t)(M - 1);
+            const uint32_t sel = (pe >> 4) - wi0;
+            uint32_t lo = cur.w[1], hi = cur.w[0];
 #pragma unroll
-                for (int c = 1; c < NSEL; c++) {
-                    lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
-                    hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
-                }
-                const uint32_t X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
+            for (int c = 1; c < NSEL; c++) {
+                lo = (sel == (uint32_t)c) ? cur.w[c + 1] : lo;
+                hi = (sel == (uint32_t)c) ? cur.w[c] : hi;
+            }
+            X = __builtin_amdgcn_alignbit(hi, lo, 30u - 2u * (pe & 15u));
+            // lane lpE's window, shifted so that it ends at pE (at least 32 - 2(M-1) >= 10 bits stay valid)
+            sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
+        }
+        auto decode_rows = [&]() {
+            if constexpr (kOneWindow) {
 #pragma unroll
                 for (int m = 0; m < M; m++)
                     row[m] = (p0 + m < LW1) ? ((X >> (2 * (M - 1 - m))) & (g.Rf - 1u)) : Rn;   // EM.cpp:167
@@ -322,8 +330,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         }
                     }
                 }
-                // lane lpE's window, shifted so that it ends at pE (at least 32 - 2(M-1) >= 10 bits stay valid)
-                sE = (uint32_t)__builtin_amdgcn_readlane((int)X, (int)lpE) >> (2u * ((uint32_t)(M - 1) - (pE - lpE * (uint32_t)M)));
             } else {
                 uint32_t vE = 0;
 #pragma unroll
@@ -349,7 +355,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 }
                 sE = (uint32_t)__builtin_amdgcn_readlane((int)vE, (int)lpE);
             }
-        }
+        };
+        if constexpr (!kOneWindow) decode_rows();            // sE comes out of the per-position windows
 
         // ---- group ends that no table row describes get per-wave VIRTUAL rows:
         //   * next to an N exception (Sequence.cpp:38): B positions from xlo on; the record carries the
@@ -369,6 +376,39 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const bool fixE = lane_b >= g.Bj && lane_b < g.Bj + nE;
         const bool fix = fixJ || fixE;
         const bool any_fix = (B | nE) != 0u;                 // wave-uniform
+        // the fix lanes' G factors: requested from the LDS table by hand and waited for after the row decode (the
+        // neutral entry y = Y of a column is 1.0f); from the global table (K = 3 without room) as ordinary loads
+        float fs[G];
+#pragma unroll
+        for (int c = 0; c < G; c++) fs[c] = 1.0f;
+        if (any_fix && fix) {
+            const uint32_t s1_base = lds_offset(s1_lds);
+#pragma unroll
+            for (int c = 0; c < G; c++) {
+                const int col = (int)(G * lane_t + c) - (int)delta;
+                uint32_t yc, pos;
+                if (fixJ) {
+                    const uint32_t k = lane_b + (uint32_t)c;           // entry of position xlo-G+1+k
+                    pos = xlo + k - (uint32_t)(G - 1);                 // wraps for positions before the sequence
+                    if constexpr (FIXG) {                              // 10-bit fields, three per word
+                        const uint32_t word = (k < 3u) ? cur.xr.y : ((k < 6u) ? cur.xr.z : cur.xr.w);
+                        yc = (word >> (10u * (k % 3u))) & 0x3ffu;
+                    } else {
+                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
+                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                    }
+                } else {
+                    pos = LW1 + (lane_b - g.Bj) - (uint32_t)(G - 1) + (uint32_t)c;
+                    yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);   // only used when pos < LW1
+                }
+                if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
+                yfix[c] = yc;
+                const uint32_t idx = __umul24((uint32_t)max(col, 0), Ys) + yc;
+                if (s1_global) fs[c] = a.s[idx];
+                else asm volatile("ds_read_b32 %0, %1" : "=v"(fs[c]) : "v"(s1_base + idx * 4u));
+            }
+        }
+        if constexpr (kOneWindow) decode_rows();
         if (any_fix) {
 #pragma unroll
             for (int m = 0; m < M; m++) {
@@ -377,29 +417,14 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 if (k3 < nE) row[m] = vbase + g.Bj + k3;
             }
             if (fix) {
+                if (!s1_global) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0]));
+#pragma unroll
+                    for (int c = 1; c < G; c++) asm volatile("" : "+v"(fs[c]) : "v"(fs[0]));
+                }
                 float f = 1.0f;
 #pragma unroll
-                for (int c = 0; c < G; c++) {
-                    const int col = (int)(G * lane_t + c) - (int)delta;
-                    uint32_t yc, pos;
-                    if (fixJ) {
-                        const uint32_t k = lane_b + (uint32_t)c;           // entry of position xlo-G+1+k
-                        pos = xlo + k - (uint32_t)(G - 1);                 // wraps for positions before the sequence
-                        if constexpr (FIXG) {                              // 10-bit fields, three per word
-                            const uint32_t word = (k < 3u) ? cur.xr.y : ((k < 6u) ? cur.xr.z : cur.xr.w);
-                            yc = (word >> (10u * (k % 3u))) & 0x3ffu;
-                        } else {
-                            const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
-                            yc = (word >> (7u * (k & 3u))) & 0x7fu;
-                        }
-                    } else {
-                        pos = LW1 + (lane_b - g.Bj) - (uint32_t)(G - 1) + (uint32_t)c;
-                        yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);   // only used when pos < LW1
-                    }
-                    if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
-                    yfix[c] = yc;
-                    if (yc != Y) f *= s1_at(__umul24((uint32_t)col, Ys) + yc);
-                }
+                for (int c = 0; c < G; c++) f *= fs[c];                // column order; a neutral entry is 1.0f
                 sg[__umul24(vbase + lane_b, g.rowstride) + pad + lane_t] = f;
             }
             wave_lds_sync();

@@ -172,17 +172,21 @@ def test_group_sizes_agree(gpu_ctx, orc):
     np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-6)
 
 
-@pytest.mark.parametrize("K", [2, 3])
-def test_grouped_with_fold_mask_and_optimize(K, gpu_ctx, orc):
-    """CV-fold mask + the full optimize() loop through the grouped kernel vs the oracle (K = 3: sequences the
-    mask skips leave no entry in the fix lanes' log)."""
-    c = Case(name="g_opt", N=400, L0=200, W=12, K=K, n_frac=0.0)
+@pytest.mark.parametrize("K,W,layout", [(2, 12, -1), (3, 12, -1), (2, 14, 8)], ids=["k2", "k3", "k2_mixed_rows"])
+def test_grouped_with_fold_mask_and_optimize(K, W, layout, gpu_ctx, orc):
+    """CV-fold mask + the full optimize() loop through the grouped kernels vs the oracle (K = 3 and the mixed
+    rows: sequences the mask skips leave no entry in the fix lanes' log)."""
+    c = Case(name="g_opt", N=400, L0=200, W=W, K=K, n_frac=0.0)
     seq, kmer, off, vbg = c.encode(orc)
     pk = bm.PackedSeqs.from_kmers(kmer, off)
     ss = bm.SeqSet(gpu_ctx, pk)
     mask = (np.arange(c.N) % 5 != 2).astype(np.uint8)
-    em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, mask=mask, max_iterations=8)
-    assert em.plan()[0] == c.N
+    gpu_ctx.set_tuning(group_layout=layout)
+    try:
+        em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, mask=mask, max_iterations=8)
+    finally:
+        gpu_ctx.set_tuning(group_layout=-1)
+    assert em.plan()[0] == c.N and (em.plan_mixed() == c.N) == (layout == 8)
     em.optimize()
     keep = np.flatnonzero(mask)
     sub_off = np.zeros(len(keep) + 1, np.uint64)
