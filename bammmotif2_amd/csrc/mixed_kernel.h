@@ -113,8 +113,13 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     uint32_t seq_cnt = 0, last_LW1 = 0;
     float pos_i = 0.0f;
     float pos_m[M];
+    constexpr bool kCacheSpec = M <= 7 || THREADS < 1024;
+    [[maybe_unused]] int spec[kCacheSpec ? M : 1];           // per slot: offset from the neutral row, -1 = a stream row
+    [[maybe_unused]] uint32_t spec_LW1 = 0, spec_xw = 0xffffffffu;
 #pragma unroll
     for (int m = 0; m < M; m++) pos_m[m] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < (kCacheSpec ? M : 1); m++) spec[m] = -1;
     [[maybe_unused]] ulonglong2* my_log = nullptr;           // the fix lanes' non-zero sums: {sum, 4 bins of 16 bits}
     [[maybe_unused]] uint32_t nlog = 0;
     if constexpr (ACCUM)
@@ -184,15 +189,42 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                 asm volatile("ds_read_b32 %0, %1" : "=v"(fs[c]) : "v"(s1_base + (__umul24(colc, Ys) + yc) * 4u));
             }
         }
-        uint32_t row5[M], row6[M];
+        // Which slots do not take their row from the stream -- beyond the EM.cpp:167 edge (neutral row), a
+        // virtual row -- depends on (L, the record's first word) only, and sets of one length with the strand
+        // junction in one place repeat both: the slot's offset from the neutral row (the virtual rows follow it
+        // in both tables; -1: a stream row) is kept until either changes.  2 bit-field extracts, 1 compare, 2 adds
+        // and 2 selects per slot instead of 17 instructions.
+        // (8 positions per lane at 1024 threads have no registers to spare for it: the offsets are recomputed)
+        auto slot_offsets = [&](int (&o)[M]) {
 #pragma unroll
-        for (int m = 0; m < M; m++) {
-            const bool in = p0 + m < LW1;                                                // EM.cpp:167
-            row5[m] = in ? ((X >> (2 * (M - 1 - m))) & 1023u) : R5N;
-            row6[m] = in ? ((X >> (2 * (M - 1 - m))) & 4095u) : R6N;
-            const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
-            if (k2 < Bx) { row5[m] = vbase5 + k2; row6[m] = vbase6 + k2; }
-            if (k3 < nE) { row5[m] = vbase5 + kMixBj + k3; row6[m] = vbase6 + kMixBj + k3; }
+            for (int m = 0; m < M; m++) {
+                const uint32_t k2 = p0 + m - xlo, k3 = p0 + m - LW1;
+                o[m] = (p0 + m < LW1) ? -1 : 0;                                          // EM.cpp:167
+                if (k2 < Bx) o[m] = (int)(1u + wave * kMixBv + k2);
+                if (k3 < nE) o[m] = (int)(1u + wave * kMixBv + kMixBj + k3);
+            }
+        };
+        uint32_t row5[M], row6[M];
+        if constexpr (kCacheSpec) {
+            if (LW1 != spec_LW1 || xw != spec_xw) {
+                spec_LW1 = LW1; spec_xw = xw;
+                slot_offsets(spec);
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const bool stream = spec[m] < 0;
+                row5[m] = stream ? ((X >> (2 * (M - 1 - m))) & 1023u) : R5N + (uint32_t)spec[m];
+                row6[m] = stream ? ((X >> (2 * (M - 1 - m))) & 4095u) : R6N + (uint32_t)spec[m];
+            }
+        } else {
+            int o[M];
+            slot_offsets(o);
+#pragma unroll
+            for (int m = 0; m < M; m++) {
+                const bool stream = o[m] < 0;
+                row5[m] = stream ? ((X >> (2 * (M - 1 - m))) & 1023u) : R5N + (uint32_t)o[m];
+                row6[m] = stream ? ((X >> (2 * (M - 1 - m))) & 4095u) : R6N + (uint32_t)o[m];
+            }
         }
         if (fix) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0]), "+v"(fs[1]), "+v"(fs[2]), "+v"(fs[3]));
