@@ -158,10 +158,10 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             for (int m = 0; m < M; m++) U[m] = s_lds[(size_t)(pad >> 2) * Ys * 4u + (pad & 3u) + y[m] * 4u];
             for (uint32_t j = 1; j < W; j++) {
                 const float* sj = s_lds + (size_t)((j + pad) >> 2) * Ys * 4u + ((j + pad) & 3u);
-                const float carry = wave_shr1(1.0f, U[M - 1]);
+                const float u0 = mul_wave_shr1(sj[y[0] * 4u], U[M - 1]);    // one v_mul_f32_dpp: lane 0 multiplies by 1
 #pragma unroll
                 for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m] * 4u];
-                U[0] = carry * sj[y[0] * 4u];
+                U[0] = u0;
             }
         } else {
         uint32_t sa[M];                                  // LDS byte address of row y(p) in the current quad
@@ -169,9 +169,9 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 #pragma unroll
         for (int m = 0; m < M; m++) sa[m] = s_base + y[m] * 16u;
 #define BAMM_SEQ_STEP(COMP)                                                     \
-            { const float c = wave_shr1(1.0f, U[M - 1]);                        \
+            { const float c = mul_wave_shr1(sv[0].COMP, U[M - 1]);              \
               _Pragma("unroll") for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sv[m].COMP; \
-              U[0] = c * sv[0].COMP; }
+              U[0] = c; }
         {                                                // first quad: its column 0 starts the chain
             f32x4 sv[M];
 #pragma unroll
@@ -408,10 +408,10 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
             for (int m = 0; m < M; m++) U[m] = (p0 + m < L) ? state[p0 + m] : 1.0f;
         }
         for (; j < j1; j++, sj += Ys) {
-            const float carry = wave_shr1(1.0f, U[M - 1]);
+            const float u0 = mul_wave_shr1(sj[y[0]], U[M - 1]);
 #pragma unroll
             for (int m = M - 1; m >= 1; m--) U[m] = U[m - 1] * sj[y[m]];
-            U[0] = carry * sj[y[0]];
+            U[0] = u0;
         }
         if (last) {
             const float pos_i = q / (float)LW1;
