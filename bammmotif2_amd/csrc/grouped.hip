@@ -8,7 +8,7 @@
 namespace bamm {
 
 // length classes the grouped kernel is instantiated for: 2..48 positions per lane (a plan needs M >= G)
-bool grp_supported_class(int M, uint32_t K) { return K <= 3u && M >= 2 && M <= 48; }
+bool grp_supported_class(int M, uint32_t K) { return K <= 3u && M >= 2 && M <= 64; }
 // 4 / 3 / 2 / 1 waves per SIMD: the grouped kernel's register budget runs out one class earlier than k_em_seq's
 uint32_t grp_max_threads(int M) { return M <= 8 ? 1024u : (M <= 16 ? 768u : (M <= 32 ? 512u : 256u)); }
 
@@ -66,6 +66,7 @@ bool grp_geometry(uint32_t K, uint32_t W, uint32_t G, int M, uint32_t waves, boo
     g.T = (W + g.G - 1u) / g.G;
     if (g.T > 64u) return false;
     g.Tq = (g.T + 3u) / 4u;
+    if (M > 48 && g.Tq > 4u) return false;                  // 56 / 64 positions per lane: the straight-line chain only
     g.delta = g.G * g.T - W;
     g.Ts = (layout & 4u) ? (g.T | 1u) : g.T;
     g.Rf = 1u << (2u * (K + g.G));

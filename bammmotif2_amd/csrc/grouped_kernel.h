@@ -127,6 +127,29 @@ __device__ __forceinline__ void grp_step(float (&U)[M], const float (&f)[M]) {
 template <int M, int G, int NQ>
 __device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]) {
     static_assert(NQ >= 1 && NQ <= 4, "quads");
+    // 56 / 64 positions per lane: 4*M registers in flight per quad do not fit the register file (hipcc then parks
+    // destinations it believes ready in AGPRs: round 1's wrong results at these lengths).  One slot at a time
+    // instead: M ds_read_b32 in flight, four times the gathers at a third of the cost each.
+    if constexpr (M > 48) {
+#define BAMM_GRP_SLOT(SL)                                                                       \
+        if constexpr (4 * NQ > (SL)) {                                                          \
+            float f[M];                                                                         \
+            _Pragma("unroll") for (int m = 0; m < M; m++)                                       \
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[m]) : "v"(ra[m]), "n"((SL) * 4));  \
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));                                 \
+            _Pragma("unroll") for (int m = 1; m < M; m++) asm volatile("" : "+v"(f[m]) : "v"(f[0])); \
+            if constexpr ((SL) == 0) {                                                          \
+                _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = f[m];                      \
+            } else {                                                                            \
+                grp_step<M, G>(U, f);                                                           \
+            }                                                                                   \
+        }
+        BAMM_GRP_SLOT(0) BAMM_GRP_SLOT(1) BAMM_GRP_SLOT(2) BAMM_GRP_SLOT(3) BAMM_GRP_SLOT(4) BAMM_GRP_SLOT(5)
+        BAMM_GRP_SLOT(6) BAMM_GRP_SLOT(7) BAMM_GRP_SLOT(8) BAMM_GRP_SLOT(9) BAMM_GRP_SLOT(10) BAMM_GRP_SLOT(11)
+        BAMM_GRP_SLOT(12) BAMM_GRP_SLOT(13) BAMM_GRP_SLOT(14) BAMM_GRP_SLOT(15)
+#undef BAMM_GRP_SLOT
+        return;
+    }
 #define BAMM_GRP_QUAD(JQ)                                                                       \
     if constexpr (NQ > (JQ)) {                                                                  \
         f32x4 sv[M];                                                                            \
@@ -443,7 +466,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 case 2: grp_chain<M, G, 2>(ra, U); break;
                 case 3: grp_chain<M, G, 3>(ra, U); break;
                 case 4: grp_chain<M, G, 4>(ra, U); break;
-                default: {                                   // more than 16 groups: plain loop
+                default: if constexpr (M <= 48) {            // more than 16 groups: plain loop (not planned beyond 48 per lane)
                     grp_chain<M, G, 4>(ra, U);
                     for (uint32_t jq = 4; jq < Tq; jq++) {
                         f32x4 sv[M];

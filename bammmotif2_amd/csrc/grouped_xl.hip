@@ -1,16 +1,15 @@
-// The grouped-column kernel (grouped_kernel.h, grouped.hip) for 40 and 48 positions per lane: sequences of
-// 2049..3072 positions (1024..1535 bp double-stranded), blocks of 256 threads -- one wave per SIMD, which
+// The grouped-column kernel (grouped_kernel.h, grouped.hip) for 40 .. 64 positions per lane: sequences of
+// 2049..4096 positions (1024..2047 bp double-stranded), blocks of 256 threads -- one wave per SIMD, which
 // owns all 512 registers.  A third translation unit: these instantiations are the slowest to compile.
-// 56 and 64 positions per lane are NOT instantiated: there the E-chain's M hand-issued ds_read_b128 (4*M
-// destination registers in flight until lds_wait) no longer fit the register file, the compiler spills
-// destinations it believes ready, and the results are wrong (caught by test_grouped_gpu.py at those
-// lengths during round 1).  Those sequences stay on k_em_seq.
+// At 56 and 64 positions per lane the E-chain reads its table one slot at a time (grp_chain, M > 48): the
+// 4*M destination registers of M hand-issued ds_read_b128 no longer fit the register file there (round 1: the
+// compiler moved destinations it believed ready, wrong results); M ds_read_b32 in flight do.
 
 #include "grouped_kernel.h"
 
 namespace bamm {
 
-#define BAMM_FOR_EACH_GCLASS_XL(X) X(16, 40, 256) X(17, 48, 256)
+#define BAMM_FOR_EACH_GCLASS_XL(X) X(16, 40, 256) X(17, 48, 256) X(18, 56, 256) X(19, 64, 256)
 
 // arguments checked by launch_em_grp
 int launch_em_grp_xl(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads,

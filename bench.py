@@ -360,7 +360,11 @@ def main():
                          "lds": lds,
                          "note": ("E pass + M slices of one iteration, timed together" if sliced else
                                   "the fused kernel is LDS / VALU issue bound (DESIGN.md section 4): "
-                                  "`lds` prices it against a measured LDS ceiling")},
+                                  "`lds` prices it against a measured LDS ceiling" +
+                                  ("; `traffic` = the 2-bit stream and records (~1.5 x the algorithmic bytes) plus the "
+                                   "fix lanes' log of virtual-row sums, written during the pass and read back once per "
+                                   "block (mixed rows and K = 3 have no LDS left for those bins)"
+                                   if (mixed_seqs or K == 3) else ""))},
             "allreduce": allreduce_kind,
             "parity": "learned v within 1e-5 of the reference on its own fixtures up to ~2k sequences; beyond that the "
                       "reference's fp32 CAS accumulation is itself 4e-5 (10k) to 4e-4 (200k) off exact arithmetic, while "

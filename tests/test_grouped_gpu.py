@@ -47,6 +47,10 @@ GROUPED_CASES = [
     dict(name="g_k2_m40_48", N=10, L0=1280, W=20, K=2, n_frac=0.0005, ragged=240),    # L 2081..3041
     dict(name="g_k1_m40_48_ss", N=10, L0=2600, W=14, K=1, ss=True, n_frac=0.0005, ragged=460),
     dict(name="g_k0_m48", N=6, L0=1500, W=8, K=0, ragged=30),                        # L 2941..3061
+    # 56 and 64 positions per lane: 3073..4096 positions (the E-chain reads one slot at a time there)
+    dict(name="g_k2_m56_64", N=8, L0=1600, W=20, K=2, n_frac=0.0003, ragged=440),     # L 3201..4081
+    dict(name="g_k1_m64_ss", N=6, L0=3900, W=14, K=1, ss=True, ragged=190),           # L 3900..4090
+    dict(name="g_k3_m56", N=6, L0=1560, W=12, K=3, n_frac=0.0003, ragged=200),        # L 3121..3521
     # mixed rows (csrc/mixed_kernel.h: K = 2, both strands, W = 3 B + 4 A): one and two wide groups, 4..8 positions per lane
     dict(name="g_mix_a1_m4", N=96, L0=110, W=13, K=2, ragged=10),
     dict(name="g_mix_a2_m5", N=96, L0=140, W=14, K=2, n_frac=0.002, ragged=12),
