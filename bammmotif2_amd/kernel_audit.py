@@ -65,12 +65,14 @@ def audit_disassembly(text: str):
     kernel = None
     queue = []          # outstanding LGKM operations, oldest first: sets of destination VGPRs (empty for writes / SMEM)
     inflight = set()
+    since_valu_exec = 99    # instructions since a VALU instruction wrote EXEC (v_cmpx*): a DPP needs 5 wait states
     for lineno, raw in enumerate(text.splitlines(), 1):
         m = _FUNC.match(raw)
         if m:
             kernel = m.group(1)
             stats[kernel] = {"scratch_instructions": 0, "ds_reads": 0, "instructions": 0}
             queue, inflight = [], set()
+            since_valu_exec = 99
             continue
         if kernel is None or not raw.startswith("\t"):
             continue
@@ -80,6 +82,15 @@ def audit_disassembly(text: str):
         op, _, rest = ins.partition(" ")
         st = stats[kernel]
         st["instructions"] += 1
+        # The hand-written DPP multiply (device_utils.h: mul_wave_shr1) carries its own s_nop 1 for the VGPR-write
+        # hazard; the compiler's hazard recogniser does not see it, so the other DPP hazard -- a VALU write of EXEC
+        # within 5 wait states -- is checked here (hipcc uses v_cmp + s_and_saveexec, never v_cmpx, today)
+        if op.startswith("v_cmpx"):
+            since_valu_exec = 0
+        else:
+            since_valu_exec += (int(rest) + 1) if op == "s_nop" and rest.strip().isdigit() else 1
+        if op == "v_mul_f32_dpp" and since_valu_exec <= 5:
+            violations.append((kernel, lineno, ins + "   <- DPP within 5 wait states of a VALU write of EXEC", []))
         if op.startswith("scratch_"):
             st["scratch_instructions"] += 1
         if op == "s_waitcnt":

@@ -48,19 +48,39 @@ def test_shipped_kernels_pass_the_audit():
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_guard_trips_on_an_oversized_length_class(tmp_path):
-    """64 positions per lane is not instantiated in the product because hipcc moves in-flight destinations
-    there; the audit must see that."""
-    src = tmp_path / "oversized.hip"
+def test_guard_trips_on_a_kernel_that_uses_a_destination_in_flight(tmp_path):
+    """Compile a kernel that multiplies the destination of a hand-issued ds_read_b128 before its s_waitcnt (what
+    hipcc did by itself to the grouped kernel at 56 / 64 positions per lane in round 1, by parking such registers
+    in AGPRs -- those classes read one slot at a time now and pass): the audit of the object must see it."""
+    src = tmp_path / "hazard.hip"
     src.write_text('#include "%s"\n'
                    "namespace bamm {\n"
                    "void set_error(const char*, ...) {}\n"
-                   "int oversized(const GrpKernelArgs& a, hipStream_t st) {\n"
-                   "    return launch_variant<64, 3, 5, 256>(true, false, a, 256, 256, st);\n"
+                   "__global__ void k_hazard(float* out) {\n"
+                   "    extern __shared__ float l[];\n"
+                   "    f32x4 v = lds_read_b128(lds_offset(l) + threadIdx.x * 16u);\n"
+                   "    const float early = v.x * 2.0f;                       // the read has not landed yet\n"
+                   '    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v));\n'
+                   "    out[threadIdx.x] = early + v.y;\n"
                    "}\n}\n" % os.path.join(build.CSRC, "grouped_kernel.h"))
-    obj = tmp_path / "oversized.o"
+    obj = tmp_path / "hazard.o"
     flags = [f for f in build.FLAGS if not f.startswith("-Rpass")]
     subprocess.check_call([HIPCC] + flags + ["-c", str(src), "-o", str(obj)], stderr=subprocess.DEVNULL)
     violations, stats = kernel_audit.audit_object(str(obj), str(tmp_path / "audit"))
-    assert violations, "the audit no longer sees the in-flight hazard of the 64-positions-per-lane class"
-    assert any(s["scratch_instructions"] > 0 for s in stats.values())
+    assert any("k_hazard" in v[0] for v in violations), "the audit no longer sees a destination used in flight"
+
+
+def test_audit_sees_a_dpp_behind_a_valu_write_of_exec():
+    """The hand-written v_mul_f32_dpp (device_utils.h) carries its own s_nop for the VGPR-write hazard; the other
+    DPP hazard, a VALU write of EXEC within 5 wait states, is the audit's to catch."""
+    listing = """
+0000000000001000 <k_dpp>:
+\tv_cmpx_lt_u32_e64 exec, v1, v2                             // 000000001000: D0C9007E
+\ts_nop 1                                                    // 000000001008: BF800001
+\tv_mul_f32_dpp v3, v4, v3 wave_shr:1 row_mask:0xf bank_mask:0xf  // 00000000100C: 0A0606FA
+\ts_endpgm                                                   // 000000001014: BF810000
+"""
+    v, _ = kernel_audit.audit_disassembly(listing)
+    assert len(v) == 1 and "DPP" in v[0][2]
+    v, _ = kernel_audit.audit_disassembly(listing.replace("s_nop 1", "s_nop 4"))
+    assert v == []
