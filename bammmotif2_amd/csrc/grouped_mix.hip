@@ -4,13 +4,14 @@
 
 namespace bamm {
 
+// (the planner keeps the narrow groups within one quad -- mix_geometry: more of them lost to the uniform rows --,
+// so only NQ = 1 is instantiated)
 #define BAMM_MIX_CASE(idx, M, T, A)                                                                       \
-    case idx * 4 + 1: rc = launch_mix_variant<M, A, 1, T>(accum, write_r, a, blocks, st); break;           \
-    case idx * 4 + 2: rc = launch_mix_variant<M, A, 2, T>(accum, write_r, a, blocks, st); break;
+    case idx * 4 + 1: rc = launch_mix_variant<M, A, 1, T>(accum, write_r, a, blocks, st); break;
 
 // arguments checked by launch_em_grp
 int launch_em_mix(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
-    if (threads != grp_max_threads(kMClasses[mclass]) || a.g.mixA != 2u || a.g.Tq < 1u || a.g.Tq > 2u) {
+    if (threads != grp_max_threads(kMClasses[mclass]) || a.g.mixA != 2u || a.g.Tq != 1u) {
         set_error("mixed-row kernel: bad launch (%u threads, A=%u, %u quads)", threads, a.g.mixA, a.g.Tq);
         return BAMM_ERR_ARG;
     }
