@@ -59,6 +59,27 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Entry of the fix lanes' log (kernels with no LDS for the bins of their virtual rows): 12 bytes
+//   word 0 = sum[31:0];  words 1-2 = sum[40:32] | bin0 << 9 | bin1 << 22 | bin2 << 35 | bin3 << 48
+// sum: what ONE window added to a virtual count cell (< 2^41); bins: 13 bits each, kGrpNoBin = none.
+constexpr uint32_t kGrpNoBin = 0x1fffu;
+struct GrpLogEntry { uint32_t w[3]; };
+__device__ __forceinline__ void grp_log_store(GrpLogEntry* log, uint32_t idx, unsigned long long sum, unsigned long long bins52) {
+    const unsigned long long hi = (sum >> 32) | (bins52 << 9);
+    GrpLogEntry e;
+    e.w[0] = (uint32_t)sum; e.w[1] = (uint32_t)hi; e.w[2] = (uint32_t)(hi >> 32);
+    log[idx] = e;
+}
+__device__ __forceinline__ void grp_log_load(const GrpLogEntry* log, uint32_t idx, unsigned long long& sum, unsigned long long& bins52) {
+    const uint32_t* p = log[idx].w;                          // written by this wave earlier in the launch: read from L2
+    const uint32_t w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t w2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = ((unsigned long long)w2 << 32) | w1;
+    sum = ((hi & 0x1ffull) << 32) | w0;
+    bins52 = hi >> 9;
+}
+
 template <int I> struct IntC { static constexpr int value = I; };
 template <int N, int I = 0, class F>
 __device__ __forceinline__ void static_for(F&& f) {           // f(IntC<0>{}), f(IntC<1>{}), ... : compile-time indices
@@ -182,7 +203,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // K = 3 (the only order with two columns per 5-mer row): odds and count tables of 10+ groups leave no LDS
     // for the bins of the virtual rows (41 KB) and often none for the single-column table.  Both serve the few
     // fix lanes only.  The single-column table is read through L2 when the geometry finds no room for it.  What
-    // a fix lane takes out of its virtual count row is LOGGED (the non-zero sums of a sequence, compacted: 16
+    // a fix lane takes out of its virtual count row is LOGGED (the non-zero sums of a sequence, compacted: 12
     // bytes each, plain stores) and folded in the block epilogue, when the odds table's LDS is free for the
     // bins.  Adding those counts
     // straight into the pass's accumulator with global atomics (round 2's first version) cost 0.5-1.6 ms per
@@ -287,10 +308,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
     for (int m = 0; m < (kCachePos ? M : 1); m++) pos_m[m] = 0.0f;
     // K = 3: this wave's log of virtual-row counts (see FIXG above): entries {sum, bins of its G columns}
-    [[maybe_unused]] ulonglong2* my_log = nullptr;
+    [[maybe_unused]] GrpLogEntry* my_log = nullptr;
     [[maybe_unused]] uint32_t nlog = 0;
     if constexpr (FIXG && ACCUM)
-        my_log = reinterpret_cast<ulonglong2*>(ga.fix_log) + (size_t)(blockIdx.x * waves_per_block + wave) * ga.fix_log_cap;
+        my_log = reinterpret_cast<GrpLogEntry*>(ga.fix_log) + (size_t)(blockIdx.x * waves_per_block + wave) * ga.fix_log_cap;
 
     for (; t < a.sv.count; t += total_waves) {
         const RawSeqG<M> cur = nxt;
@@ -614,18 +635,18 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         }
                     }
                 }
-                if constexpr (FIXG) {                            // the non-zero sums, compacted: {sum, bin of column 0 | bin of column 1 << 16}
+                if constexpr (FIXG) {                            // the non-zero sums, compacted (GrpLogEntry)
                     static_assert(!FIXG || G == 2, "two bins per entry");
                     const unsigned long long nzm = __ballot(acc != 0ull);
                     if (acc != 0ull) {
-                        uint32_t bins = 0;
+                        unsigned long long bins = 0ull;
 #pragma unroll
                         for (int c = 0; c < G; c++) {
                             const int col = (int)(G * lane_t + c) - (int)delta;
-                            bins |= ((yfix[c] != Y) ? (uint32_t)col * Y + yfix[c] : 0xffffu) << (16 * c);
+                            bins |= (unsigned long long)((yfix[c] != Y) ? (uint32_t)col * Y + yfix[c] : kGrpNoBin) << (13 * c);
                         }
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
-                        my_log[nlog + rank] = make_ulonglong2(acc, (unsigned long long)bins);
+                        grp_log_store(my_log, nlog + rank, acc, bins);
                     }
                     nlog += (uint32_t)__builtin_popcountll(nzm);
                 }
@@ -654,19 +675,15 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
             unsigned long long acc[NB], bins[NB];
 #pragma unroll
-            for (uint32_t u = 0; u < NB; u++) {
-                const uint32_t e = e0 + u * 64u + (uint32_t)lane;
-                const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(my_log + min(e, nlog - 1u));
-                acc[u] = __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bins[u] = __hip_atomic_load(ent + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (uint32_t u = 0; u < NB; u++)
+                grp_log_load(my_log, min(e0 + u * 64u + (uint32_t)lane, nlog - 1u), acc[u], bins[u]);
 #pragma unroll
             for (uint32_t u = 0; u < NB; u++) {
                 if (e0 + u * 64u + (uint32_t)lane < nlog) {
 #pragma unroll
                     for (int c = 0; c < G; c++) {
-                        const uint32_t bin = ((uint32_t)bins[u] >> (16 * c)) & 0xffffu;
-                        if (bin != 0xffffu) atomicAdd(&n1[bin], acc[u]);
+                        const uint32_t bin = (uint32_t)(bins[u] >> (13 * c)) & kGrpNoBin;
+                        if (bin != kGrpNoBin) atomicAdd(&n1[bin], acc[u]);
                     }
                 }
             }

@@ -120,10 +120,10 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     for (int m = 0; m < M; m++) pos_m[m] = 0.0f;
 #pragma unroll
     for (int m = 0; m < (kCacheSpec ? M : 1); m++) spec[m] = -1;
-    [[maybe_unused]] ulonglong2* my_log = nullptr;           // the fix lanes' non-zero sums: {sum, 4 bins of 16 bits}
+    [[maybe_unused]] GrpLogEntry* my_log = nullptr;          // the fix lanes' non-zero sums (12-byte entries)
     [[maybe_unused]] uint32_t nlog = 0;
     if constexpr (ACCUM)
-        my_log = reinterpret_cast<ulonglong2*>(ga.fix_log) + (size_t)(blockIdx.x * WAVES + wave) * ga.fix_log_cap;
+        my_log = reinterpret_cast<GrpLogEntry*>(ga.fix_log) + (size_t)(blockIdx.x * WAVES + wave) * ga.fix_log_cap;
 
     for (; t < a.sv.count; t += total_waves) {
         const RawSeqG<M> cur = nxt;
@@ -352,16 +352,17 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                 acc = *cell;
                 *cell = 0ull;
             }
+            unsigned long long bins = 0ull;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t bin = ((uint32_t)c < lane_G && yfix[c] != Y) ? (lane_col0 + (uint32_t)c) * Y + yfix[c] : kGrpNoBin;
+                bins |= (unsigned long long)bin << (13 * c);
+            }
+            if (bins == 0xfffffffffffffull) acc = 0ull;      // a group wholly beyond the edge: its sum belongs to no bin
             const unsigned long long nzm = __ballot(acc != 0ull);
             if (acc != 0ull) {
-                unsigned long long bins = 0ull;
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t bin = ((uint32_t)c < lane_G && yfix[c] != Y) ? (lane_col0 + (uint32_t)c) * Y + yfix[c] : 0xffffu;
-                    bins |= (unsigned long long)bin << (16 * c);
-                }
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
-                my_log[nlog + rank] = make_ulonglong2(acc, bins);
+                grp_log_store(my_log, nlog + rank, acc, bins);
             }
             nlog += (uint32_t)__builtin_popcountll(nzm);
             wave_lds_sync();
@@ -385,19 +386,15 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
             unsigned long long acc[NB], bins[NB];
 #pragma unroll
-            for (uint32_t u = 0; u < NB; u++) {
-                const uint32_t e = e0 + u * 64u + (uint32_t)lane;
-                const unsigned long long* ent = reinterpret_cast<const unsigned long long*>(my_log + min(e, nlog - 1u));
-                acc[u] = __hip_atomic_load(ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bins[u] = __hip_atomic_load(ent + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            for (uint32_t u = 0; u < NB; u++)
+                grp_log_load(my_log, min(e0 + u * 64u + (uint32_t)lane, nlog - 1u), acc[u], bins[u]);
 #pragma unroll
             for (uint32_t u = 0; u < NB; u++) {
                 if (e0 + u * 64u + (uint32_t)lane < nlog) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        const uint32_t bin = (uint32_t)(bins[u] >> (16 * c)) & 0xffffu;
-                        if (bin != 0xffffu) atomicAdd(&n1[bin], acc[u]);
+                        const uint32_t bin = (uint32_t)(bins[u] >> (13 * c)) & kGrpNoBin;
+                        if (bin != kGrpNoBin) atomicAdd(&n1[bin], acc[u]);
                     }
                 }
             }
