@@ -213,6 +213,41 @@ def test_optimize_stopping_rule(gpu_ctx, orc):
     em.close(); ss.close()
 
 
+@pytest.mark.parametrize("stop_at", [1, 3, 12])
+def test_optimize_leaves_exactly_the_state_of_its_last_pass(stop_at, gpu_ctx, orc):
+    """optimize() runs one pass ahead of its stop rule; the pass enqueued behind the one that fires the rule must do
+    nothing, on the device (model, q, accumulator, trace) and in the host's bookkeeping (which odds table and q slot
+    are current): the handle is bit-identical to one that ran the same number of passes through iterate(), and
+    stays so through further passes, an E-step and getR()."""
+    c = Case(**SMALL_CASES[0])
+    # a: iterate() stop_at passes; b: optimize() with a rule that fires in pass stop_at (epsilon above every v_diff
+    # from that pass on: taken from a's trace); c: optimize() that runs into max_iterations = stop_at
+    em_a, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, max_iterations=40)
+    em_a.iterate(stop_at)
+    vd = em_a.trace()[1]
+    eps = float(np.nextafter(np.float32(vd[stop_at - 1]), np.float32(np.inf)))
+    if stop_at > 1 and not all(v >= eps for v in vd[:stop_at - 1]):
+        pytest.skip("v_diff is not decreasing on this case: no epsilon stops exactly there")
+    em_b = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, max_iterations=40, epsilon=eps)
+    em_c = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, max_iterations=stop_at, epsilon=0.0)
+    assert em_b.optimize() == stop_at and em_c.optimize() == stop_at
+    for em in (em_b, em_c):
+        assert em.iteration() == stop_at
+        assert np.array_equal(em.getV(), em_a.getV()) and em.getQ() == em_a.getQ()
+        assert np.array_equal(em.getCounts(), em_a.getCounts())
+        assert np.array_equal(em.trace()[0], em_a.trace()[0])
+        assert np.array_equal(em.getR(), em_a.getR())            # the last E pass's odds table and q
+    em_a.iterate(2); em_b.iterate(2)
+    assert np.array_equal(em_b.getV(), em_a.getV())
+    em_a.EStep(); em_b.EStep()
+    assert em_b.getLLH() == em_a.getLLH() and np.array_equal(em_b.getR(), em_a.getR())
+    em_a.MStep(); em_b.MStep()
+    assert np.array_equal(em_b.getV(), em_a.getV())
+    for em in (em_a, em_b, em_c):
+        em.close()
+    ss.close()
+
+
 def test_optimize_q_entry_point(gpu_ctx, orc):
     c = Case(**SMALL_CASES[0])
     em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc)
