@@ -42,14 +42,26 @@ bool mix_geometry(uint32_t K, uint32_t W, int M, uint32_t waves, bool accum, Grp
         uint32_t off = 0;
         g.off_sg6 = off; off = up16(off + R6T * A * 4u);
         g.off_sg = off; off = up16(off + g.Rtot * g.rowstride * 4u);
-        g.off_s1 = off; off = up16(off + W * (Y + 1u) * 4u);
-        g.off_stat = off; off = up16(off + 16u * 3u * 8u);
-        g.off_ng6 = off; if (accum) off = up16(off + A * R6T * 8u);
-        g.off_ng = off; if (accum) off = up16(off + B * g.Rtot * 8u);
-        g.off_n1 = g.off_sg6;                                // epilogue only
-        g.off_wave = off; g.wave_bytes = 0u;
+        g.off_stat = g.off_sg;                               // epilogue only: over the narrow odds
+        g.off_n1 = g.off_sg6;                                // epilogue only: over the wide odds
+        if (16u * 3u * 8u > g.Rtot * g.rowstride * 4u || (accum && W * Y * 8u > R6T * A * 4u)) continue;
+        // the single-column table is staged for the prologue where the counts will be (E-only launches: behind
+        // the odds); the fix lanes read it from global memory
+        g.off_ng6 = off;
+        g.off_s1 = off;
+        const uint32_t counts = accum ? up16(A * R6T * 8u) + up16(B * g.Rtot * 8u) : 0u;
+        g.off_ng = off + (accum ? up16(A * R6T * 8u) : 0u);
+        off += std::max(counts, up16(W * (Y + 1u) * 4u));
+        // resident bins for as many of the motif's leading columns as fit (the fix lanes log the rest)
+        g.off_wave = off;
+        g.wave_bytes = 0u;
+        if (accum && off <= 160u * 1024u) {
+            const uint32_t cols = std::min(W, (160u * 1024u - off) / (Y * 8u));
+            g.wave_bytes = cols * Y * 8u;
+            off += g.wave_bytes;
+        }
+        g.cap = 0u;                                          // the single-column table is not resident
         g.lds_bytes = off;
-        if (accum && W * Y * 8u > R6T * A * 4u) continue;
         if (off <= 160u * 1024u) { *out = g; return true; }
         if (g.Tq & 1u) break;                                // the stride was odd already
     }
