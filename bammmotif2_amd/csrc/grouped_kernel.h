@@ -420,13 +420,14 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const bool fixE = lane_b >= g.Bj && lane_b < g.Bj + nE;
         const bool fix = fixJ || fixE;
         const bool any_fix = (B | nE) != 0u;                 // wave-uniform
-        // the fix lanes' G factors: requested from the LDS table by hand and waited for after the row decode (the
-        // neutral entry y = Y of a column is 1.0f); from the global table (K = 3 without room) as ordinary loads
+        // the fix lanes' G factors come from the single-column table in GLOBAL memory (through L2; the neutral entry
+        // y = Y of a column is 1.0f): the loads are issued here, ahead of the row decode, and land under it -- the
+        // vector-memory path is idle otherwise, the LDS pipe is what the pass is short of (the LDS copy of the table
+        // only serves the prologue's table build): k = 2 0.980 -> 0.954 ms, k = 1 0.881 -> 0.856 ms
         float fs[G];
 #pragma unroll
         for (int c = 0; c < G; c++) fs[c] = 1.0f;
         if (any_fix && fix) {
-            const uint32_t s1_base = lds_offset(s1_lds);
 #pragma unroll
             for (int c = 0; c < G; c++) {
                 const int col = (int)(G * lane_t + c) - (int)delta;
@@ -448,8 +449,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
                 yfix[c] = yc;
                 const uint32_t idx = __umul24((uint32_t)max(col, 0), Ys) + yc;
-                if (s1_global) fs[c] = a.s[idx];
-                else asm volatile("ds_read_b32 %0, %1" : "=v"(fs[c]) : "v"(s1_base + idx * 4u));
+                fs[c] = a.s[idx];
             }
         }
         if constexpr (kOneWindow) decode_rows();
@@ -461,11 +461,6 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 if (k3 < nE) row[m] = vbase + g.Bj + k3;
             }
             if (fix) {
-                if (!s1_global) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0]));
-#pragma unroll
-                    for (int c = 1; c < G; c++) asm volatile("" : "+v"(fs[c]) : "v"(fs[0]));
-                }
                 float f = 1.0f;
 #pragma unroll
                 for (int c = 0; c < G; c++) f *= fs[c];                // column order; a neutral entry is 1.0f
