@@ -73,7 +73,7 @@ struct bamm_ctx {
     bool own_stream = false;
     uint32_t blocks = 0, threads = 0;   // 0 = default
     // bamm_ctx_set_tuning: kernel-selection switches for benchmarks and the cross-kernel parity tests
-    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true;
+    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true, use_fused_update = true;
     uint32_t group_size = 0;            // 0 = planner's choice
     int group_layout = -1;              // -1 = planner's choice
     int num_cus = 0;
@@ -114,6 +114,12 @@ struct bamm_seqs {
     }
 };
 
+struct EmBook {                   // host-side state one model update moves (optimize() rolls back work that did not happen)
+    float *d_s, *d_s_alt, *d_q, *d_v, *d_v_alt; const float *s_last, *q_last;
+    long long* d_acc; uint32_t acc_cur, llh_cur, host_iteration, events_used, pass_no;
+    bool estep_done, acc_dirty, mask_done, ring_prev_dirty;
+};
+
 struct bamm_em {
     bamm_ctx* ctx = nullptr;
     bamm_seqs* seqs = nullptr;
@@ -132,7 +138,20 @@ struct bamm_em {
     uint8_t* d_mask = nullptr;
     // the pass's fused accumulator [cells | llh | sum_r | n_seqs]: 64-bit integers the blocks add into,
     // summed across ranks as int64 (exact, order-free), consumed and zeroed by the update
-    long long* d_acc = nullptr;
+    long long* d_acc = nullptr;                // the slot the current / next pass adds into
+    // ... a ring of three slots when the handle can fuse the model update into the next pass's kernel
+    // (update_kernel.h): pass p adds into slot p mod 3, the next kernel's blocks read it, its writer block clears
+    // the slot after next.  Outside a fused sequence only slot `acc_cur` is ever non-zero.
+    long long* d_acc_ring = nullptr;
+    size_t acc_stride = 0;                      // words per slot
+    uint32_t acc_cur = 0;
+    bool fusable = false;                       // K <= 2-sized tables, first launch of a pass is a grouped kernel with room for the update
+    uint32_t fuse_upd_off = 0;                  // LDS offset of the update's scratch in that kernel
+    float* d_s_block = nullptr;                 // [blocks of the first launch][W * (Y + 1)]
+    float* d_v_alt = nullptr;                   // fused updates read the old v while the writer block stores the new one
+    float* d_llh[2] = {nullptr, nullptr};       // log-likelihood of the last two updates (the stop rule compares them)
+    uint32_t llh_cur = 0;                       // slot the last update wrote
+    bool ring_prev_dirty = false;               // the ring slot behind acc_cur was read by a fused update and awaits clearing
     bool acc_external = false;                 // caller-owned (bamm_em_set_reduce_buffer)
     bool acc_dirty = false;                    // holds sums nobody consumed (accumulate without update, getR replay)
     uint32_t fix_shift = 40;                   // counts travel in units of 2^-fix_shift (40 unless the set is huge)
@@ -184,6 +203,7 @@ struct bamm_em {
     double* d_mask_partial_stat = nullptr;
     uint32_t mask_blocks = 0;
     bool mask_done = false;                     // getR() serves d_mask_r
+    EmBook books[4] = {};                       // snapshot right after update i at [i & 3]
 };
 
 namespace {
@@ -347,7 +367,7 @@ int record_event(bamm_em* em, bool start) {
 
 // one bucket through the fused kernel of its flavour (grouped columns or one column at a time)
 int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKernelArgs& a, uint32_t threads,
-                 hipStream_t st) {
+                 hipStream_t st, const UpdateArgs* fuse = nullptr) {
     if (!eb.grouped) {
         a.logC = eb.logc;
         a.sparse_cap = accum ? eb.sparse_cap : 0u;
@@ -375,19 +395,51 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
         ga.fix_log = em->d_fix_log;
         ga.fix_log_cap = (uint32_t)cap;
     }
+    if (fuse) {                                              // the previous pass's update runs in this launch's prologue
+        ga.fused = 1u; ga.upd = *fuse; ga.upd_off = em->fuse_upd_off; ga.s_block = em->d_s_block;
+    }
     return launch_em_grp(eb.mclass, accum, write_r, ga, eb.blocks, threads, st);
 }
 
-// local E(+M) pass over every length bucket, then the deterministic partial reduction
-int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense_r = false) {
+void prepare_update(bamm_em* em, bool q_window, bool fused, UpdateArgs& u);
+
+EmBook capture_book(const bamm_em* em) {
+    return EmBook{em->d_s, em->d_s_alt, em->d_q, em->d_v, em->d_v_alt, em->s_last, em->q_last, em->d_acc, em->acc_cur, em->llh_cur,
+                  em->host_iteration, em->events_used, em->pass_no, em->estep_done, em->acc_dirty, em->mask_done, em->ring_prev_dirty};
+}
+void restore_book(bamm_em* em, const EmBook& b) {
+    em->d_s = b.d_s; em->d_s_alt = b.d_s_alt; em->d_q = b.d_q; em->d_v = b.d_v; em->d_v_alt = b.d_v_alt;
+    em->s_last = b.s_last; em->q_last = b.q_last; em->d_acc = b.d_acc; em->acc_cur = b.acc_cur; em->llh_cur = b.llh_cur;
+    em->host_iteration = b.host_iteration; em->events_used = b.events_used; em->pass_no = b.pass_no;
+    em->estep_done = b.estep_done; em->acc_dirty = b.acc_dirty; em->mask_done = b.mask_done; em->ring_prev_dirty = b.ring_prev_dirty;
+}
+
+// clear whatever a pass left unconsumed (accumulate without update, getR replay, a fused sequence cut short)
+int clean_accumulator(bamm_em* em) {
+    if (!em->acc_dirty) return BAMM_OK;
+    hipStream_t st = em->ctx->stream;
+    if (em->d_acc_ring) {
+        BAMM_HIP(hipMemsetAsync(em->d_acc_ring, 0, 3 * em->acc_stride * sizeof(long long), st));
+        em->acc_cur = 0; em->d_acc = em->d_acc_ring; em->ring_prev_dirty = false;
+    } else {
+        BAMM_HIP(hipMemsetAsync(em->d_acc, 0, (em->cells + 3) * sizeof(long long), st));
+    }
+    em->acc_dirty = false;
+    return BAMM_OK;
+}
+
+// local E(+M) pass over every length bucket; every block adds its table into the pass's accumulator.
+// fuse_q_window >= 0: the PREVIOUS pass's model update (with that q-window flag) runs in the block prologue of this
+// pass's first launch instead of a k_update launch of its own (em->fusable handles, accumulating passes only).
+int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense_r = false, int fuse_q_window = -1) {
     bamm_seqs* s = em->seqs;
     hipStream_t st = em->ctx->stream;
     int rc = use_device(em->ctx);
     if (rc) return rc;
-    if (em->acc_dirty) {                                      // sums of a pass that was never consumed
-        BAMM_HIP(hipMemsetAsync(em->d_acc, 0, (em->cells + 3) * sizeof(long long), st));
-        em->acc_dirty = false;
-    }
+    UpdateArgs fuse{};
+    const bool fusing = fuse_q_window >= 0;
+    if (fusing) prepare_update(em, fuse_q_window != 0, true, fuse);     // consumes the previous pass's sums on the stream
+    else if ((rc = clean_accumulator(em))) return rc;
     if ((rc = record_event(em, true))) return rc;
     for (size_t b = 0; b < em->ebuckets.size(); b++) {
         const EmBucket& bk = em->ebuckets[b];
@@ -411,7 +463,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
         }
         const uint32_t threads = bucket_threads(em->ctx, bk);
         if (!em->sliced) {
-            rc = launch_fused(em, bk, accum, false, a, threads, st);
+            rc = launch_fused(em, bk, accum, false, a, threads, st, (fusing && b == 0) ? &fuse : nullptr);
         } else {
             uint32_t widest = 0;
             for (auto& sl : em->m_slices) widest = std::max(widest, sl.second - sl.first);
@@ -495,30 +547,56 @@ float* q_write_slot(bamm_em* em) {
     return em->d_q;
 }
 
+// Fill the arguments of one model update and move the host's bookkeeping past it (the launch that carries it --
+// k_update, or the next pass's first sequence kernel when `fused` -- follows on the stream).
 // q_window: this pass is one of the first five of its optimize() / iterate() call, where the reference
 // re-estimates q (`iteration` is local to EM::optimize, EM.cpp:75-99)
-int run_update(bamm_em* em, bool q_window) {
-    UpdateArgs u{};
+void prepare_update(bamm_em* em, bool q_window, bool fused, UpdateArgs& u) {
+    u = UpdateArgs{};
     u.K = em->prm.K; u.W = em->prm.W; u.Kbg = em->Kbg;
-    u.acc = em->d_acc; u.count_unit = ldexp(1.0, -(int)em->fix_shift); u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.v = em->d_v; u.s = em->d_s_alt;
+    u.acc = em->d_acc; u.count_unit = ldexp(1.0, -(int)em->fix_shift); u.vbg = em->d_vbg; u.A = em->d_A; u.n = em->d_n; u.s = em->d_s_alt;
     float* q_out = q_write_slot(em);
+    if (fused)                                               // every block reads d_q while the writer block stores q_out: never the same slot
+        for (float* p : em->d_qbuf)
+            if (p != em->q_last && p != em->d_q) { q_out = p; break; }
     u.q = em->d_q; u.q_out = q_out; u.status = em->d_status; u.trace = em->d_trace; u.trace_cap = em->prm.max_iterations;
     u.iteration = em->d_iteration; u.optimize_q = (em->prm.optimize_q && q_window) ? 1 : 0;
     u.n_seqs_override = (double)em->prm.n_seqs_global;
+    u.llh_in = em->d_llh[em->llh_cur]; u.llh_out = em->d_llh[em->llh_cur ^ 1u];
     if (em->stop_arg) {
         u.stop = em->d_stop; u.epsilon = em->prm.epsilon; u.opt_iteration = em->opt_iteration;
         u.llh_prev = em->opt_llh_prev; u.llh_prev_from_status = em->opt_iteration > 1u ? 1 : 0;
         u.status_mirror = em->d_status_mirror ? em->d_status_mirror + 8 + 8 * (em->opt_iteration & 1u) : nullptr;
     }
-    int rc = use_device(em->ctx);
-    if (!rc) rc = launch_update(u, em->ctx->stream);
-    if (rc) return rc;
-    em->acc_dirty = false;                                    // k_update left the accumulator zeroed
+    if (fused) {
+        // every block of the carrying launch reads slot `acc_cur` and the old v; its writer block stores the new v
+        // elsewhere and clears the slot after next; the launch's own pass adds into the next slot
+        u.v_old = em->d_v; u.v = em->d_v_alt;
+        u.acc_zero = em->d_acc_ring + (size_t)((em->acc_cur + 2u) % 3u) * em->acc_stride;
+        std::swap(em->d_v, em->d_v_alt);
+        em->acc_cur = (em->acc_cur + 1u) % 3u;
+        em->d_acc = em->d_acc_ring + (size_t)em->acc_cur * em->acc_stride;
+        em->ring_prev_dirty = true;                          // the slot just read stays as it is until the next update clears it
+    } else {
+        u.v = em->d_v; u.v_old = nullptr;
+        u.acc_zero = em->ring_prev_dirty ? em->d_acc_ring + (size_t)((em->acc_cur + 2u) % 3u) * em->acc_stride : nullptr;
+        em->ring_prev_dirty = false;
+    }
+    em->acc_dirty = false;                                    // consumed (k_update zeroes it; the ring moves on)
     std::swap(em->d_s, em->d_s_alt);
     em->d_q = q_out;
+    em->llh_cur ^= 1u;
     em->host_iteration++;
     em->estep_done = false;
-    return BAMM_OK;
+    em->books[em->host_iteration & 3u] = capture_book(em);
+}
+
+int run_update(bamm_em* em, bool q_window) {
+    int rc = use_device(em->ctx);
+    if (rc) return rc;
+    UpdateArgs u;
+    prepare_update(em, q_window, false, u);
+    return launch_update(u, em->ctx->stream);
 }
 
 int fetch_status(bamm_em* em) {
@@ -561,6 +639,7 @@ int bamm_ctx_create(int device, void* hip_stream, bamm_ctx** out) {
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     c->name = prop.name;
+    if (c->name.empty()) c->name = prop.gcnArchName;       // some driver stacks leave the marketing name blank
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -573,6 +652,18 @@ int bamm_ctx_create(int device, void* hip_stream, bamm_ctx** out) {
         c->own_stream = true;
     }
     *out = c;
+    return BAMM_OK;
+}
+
+int bamm_device_count(int* n) {
+    if (!n) { set_error("bamm_device_count: null argument"); return BAMM_ERR_ARG; }
+    *n = 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device visible");
+        return BAMM_ERR_NO_DEVICE;
+    }
+    *n = count;
     return BAMM_OK;
 }
 
@@ -609,6 +700,7 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
     else if (k == "sparse") c->use_sparse = value != 0;
     else if (k == "e_fused") c->use_e_fused = value != 0;
     else if (k == "e_list") c->use_e_list = value != 0;
+    else if (k == "fused_update") c->use_fused_update = value != 0;
     else if (k == "group_size") {
         if (value != 0 && (value < 2 || value > 4)) { set_error("group_size must be 0 (auto) or 2..4"); return BAMM_ERR_ARG; }
         c->group_size = (uint32_t)value;
@@ -718,7 +810,8 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipSetDevice(em->ctx->device);
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
-                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)(em->acc_external ? nullptr : em->d_acc),
+                    (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_acc_ring,
+                    (void*)em->d_v_alt, (void*)em->d_llh[0], (void*)em->d_s_block,
                     (void*)em->d_state, (void*)em->d_list_r, (void*)em->d_list_p, (void*)em->d_list_n, (void*)em->d_s_alt, (void*)em->d_fix_log,
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
@@ -814,7 +907,12 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if ((rc = dev_alloc(&em->d_status, 8))) return fail(rc);
     if ((rc = dev_alloc(&em->d_trace, (size_t)em->prm.max_iterations * 3))) return fail(rc);
     if ((rc = dev_alloc(&em->d_iteration, 1))) return fail(rc);
-    if ((rc = dev_alloc(&em->d_acc, em->cells + 3))) return fail(rc);
+    em->acc_stride = (em->cells + 3 + 1) & ~(size_t)1;      // slots start on 16-byte boundaries
+    if ((rc = dev_alloc(&em->d_acc_ring, 3 * em->acc_stride))) return fail(rc);
+    em->d_acc = em->d_acc_ring;
+    if ((rc = dev_alloc(&em->d_v_alt, em->vsz))) return fail(rc);
+    if ((rc = dev_alloc(&em->d_llh[0], 2))) return fail(rc);
+    em->d_llh[1] = em->d_llh[0] + 1;
     {   // counts are sums of r * 2^fix_shift over at most n_seqs_global (else this handle's) sequences, each
         // contributing less than 1 per cell: keep the int64 total below 2^62
         const uint64_t n_hint = std::max<uint64_t>(prm->n_seqs_bound ? prm->n_seqs_bound : (prm->n_seqs_global ? prm->n_seqs_global : seqs->n), 1);
@@ -825,7 +923,8 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if (hipMemsetAsync(em->d_n, 0, em->vsz * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(em->d_status, 0, 8 * sizeof(float), st) != hipSuccess ||
         hipMemsetAsync(em->d_iteration, 0, sizeof(uint32_t), st) != hipSuccess ||
-        hipMemsetAsync(em->d_acc, 0, (em->cells + 3) * sizeof(long long), st) != hipSuccess) {
+        hipMemsetAsync(em->d_llh[0], 0, 2 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(em->d_acc_ring, 0, 3 * em->acc_stride * sizeof(long long), st) != hipSuccess) {
         set_error("hipMemsetAsync failed");
         return fail(BAMM_ERR_HIP);
     }
@@ -942,6 +1041,32 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         b.blocks = nb;
         em->total_blocks += nb;
     }
+    // fused updates (update_kernel.h): inside iterate() / optimize() the model update of pass p runs in the block
+    // prologue of pass p+1's FIRST launch -- a grouped kernel whose count tables leave room for the update's scratch
+    if (!sliced && c->use_fused_update && update_fits_lds(prm->K, prm->W) && prm->K <= 2u) {
+        size_t best = em->ebuckets.size();
+        for (size_t i = 0; i < em->ebuckets.size(); i++)
+            if (em->ebuckets[i].grouped && kMClasses[em->ebuckets[i].mclass] <= 16 &&          // the classes built with the fused prologue
+                (best == em->ebuckets.size() || em->ebuckets[i].count > em->ebuckets[best].count)) best = i;
+        if (best < em->ebuckets.size()) {
+            std::swap(em->ebuckets[0], em->ebuckets[best]);
+            const EmBucket& eb = em->ebuckets[0];
+            GrpGeom g{};
+            const uint32_t threads = bucket_threads(c, eb);
+            if (grp_geometry(prm->K, prm->W, eb.G, kMClasses[eb.mclass], threads / 64u, true, eb.logc, eb.layout, &g)) {
+                const uint32_t need = (uint32_t)update_lds_bytes(prm->K, prm->W);
+                const uint32_t s1_bytes = (prm->W * (Y + 1u) * 4u + 15u) & ~15u;
+                // mixed rows: behind the staged single-column table, inside the count tables; uniform rows: the count table
+                const uint32_t off = (eb.layout & 8u) ? g.off_s1 + s1_bytes : g.off_ng;
+                const uint32_t end = (eb.layout & 8u) ? g.off_wave : g.off_n1;
+                if (off + need <= end) {
+                    em->fusable = true;
+                    em->fuse_upd_off = off;
+                    if ((rc = dev_alloc(&em->d_s_block, (size_t)eb.blocks * prm->W * (Y + 1u)))) return fail(rc);
+                }
+            }
+        }
+    }
     if (sliced && em->e_fused && c->use_e_list) {
         if ((rc = dev_alloc(&em->d_list_r, (size_t)seqs->total_len)) || (rc = dev_alloc(&em->d_list_p, (size_t)seqs->total_len)) ||
             (rc = dev_alloc(&em->d_list_n, (size_t)seqs->n))) return fail(rc);
@@ -1041,7 +1166,8 @@ int bamm_em_set_reduce_buffer(bamm_em* em, void* dev_ptr, uint64_t n_words) {
     }
     BAMM_HIP(hipSetDevice(em->ctx->device));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
-    if (!em->acc_external) (void)hipFree(em->d_acc);
+    (void)hipFree(em->d_acc_ring);                           // a caller-owned accumulator is one slot: no fused updates
+    em->d_acc_ring = nullptr; em->acc_cur = 0; em->ring_prev_dirty = false; em->fusable = false;
     em->d_acc = static_cast<long long*>(dev_ptr);
     em->acc_external = true;
     em->acc_dirty = false;
@@ -1058,11 +1184,14 @@ int bamm_em_update(bamm_em* em) {
 int bamm_em_iterate(bamm_em* em, uint32_t n) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
     em->events_used = 0; em->pass_no = 0;
+    // fusable handles: the update of pass i runs in the prologue of pass i+1's first kernel (one launch and one
+    // collective per iteration); the last pass's update is a k_update launch, so the handle is in the same state
+    // at every API boundary whichever way its updates ran
     for (uint32_t i = 0; i < n; i++) {
-        int rc = run_accumulate(em, true);
+        int rc = run_accumulate(em, true, false, false, (em->fusable && i > 0u) ? (int)(i - 1u < 5u) : -1);
         if (!rc) rc = run_allreduce(em);
-        if (!rc) rc = run_update(em, i < 5u);
-        if (rc) return rc;
+        if (!rc && (!em->fusable || i + 1u == n)) rc = run_update(em, i < 5u);
+        if (rc) { em->acc_dirty = true; return rc; }
     }
     return BAMM_OK;
 }
@@ -1078,50 +1207,60 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
     hipStream_t st = em->ctx->stream;
     // The stop rule (EM.cpp:117-118) needs (llh, v_diff) of a pass on the host: a read-back and a stream
     // synchronisation per pass, 13 us during which the GPU idles (half of a pass at 300 sequences, a sixth at 50k).
-    // So the loop runs ONE pass ahead: pass i+1 is enqueued before pass i's numbers are waited for.  k_update
-    // evaluates the same rule on the device and raises a flag; a pass enqueued behind a raised flag does nothing
-    // (every kernel of it returns at entry), so the model is exactly what pass i left, and the host takes back
-    // the bookkeeping of that one pass.
+    // So the loop runs AHEAD of the numbers it waits for.  The update evaluates the same rule on the device and
+    // raises a flag; whatever was enqueued behind a raised flag does nothing (every kernel returns at entry), so the
+    // model is exactly what the stopping pass left, and the host takes back the bookkeeping of the work that did
+    // not happen (prepare_update keeps a snapshot per update).
+    //
+    // The stream carries UNITS.  Plain handles: unit u = pass u + all-reduce + k_update(u); status(u) is there when
+    // unit u is.  Fusable handles (update_kernel.h): unit u = [update(u-1) in the prologue of] pass u + all-reduce,
+    // and one last unit max_it + 1 = k_update(max_it); status(u) is there when unit u + 1 is (lag 1).  A fused
+    // update that fires the rule ends every block of its kernel before the pass: same model, same trace.
     if (!em->d_stop && (rc = dev_alloc(&em->d_stop, 1))) return rc;
     for (hipEvent_t& e : em->opt_events)
         if (!e) BAMM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     BAMM_HIP(hipMemsetAsync(em->d_stop, 0, sizeof(uint32_t), st));
-    struct Book {                                        // host-side state a pass moves
-        float *d_s, *d_s_alt, *d_q; const float *s_last, *q_last;
-        uint32_t host_iteration; bool estep_done, acc_dirty, mask_done;
-    };
-    auto capture = [&]() { return Book{em->d_s, em->d_s_alt, em->d_q, em->s_last, em->q_last, em->host_iteration, em->estep_done, em->acc_dirty, em->mask_done}; };
-    auto restore = [&](const Book& b) {
-        em->d_s = b.d_s; em->d_s_alt = b.d_s_alt; em->d_q = b.d_q; em->s_last = b.s_last; em->q_last = b.q_last;
-        em->host_iteration = b.host_iteration; em->estep_done = b.estep_done; em->acc_dirty = b.acc_dirty; em->mask_done = b.mask_done;
-    };
+    const uint32_t lag = em->fusable ? 1u : 0u;
+    const uint32_t units = max_it + lag;
+    const uint32_t first_update = em->host_iteration;       // update(i) of this call is the handle's update first_update + i
     em->stop_arg = em->d_stop;
     em->opt_llh_prev = em->llh_prev;
-    auto enqueue = [&](uint32_t it) -> int {              // pass `it` (1-based), its status on the way to slot it & 1
-        em->opt_iteration = it;
-        int r = run_accumulate(em, true);
-        if (!r) r = run_allreduce(em);
-        if (!r) r = run_update(em, it <= 5u);                                   // EM.cpp:99
+    auto enqueue_unit = [&](uint32_t u) -> int {            // 1-based
+        int r = BAMM_OK;
+        if (u <= max_it) {
+            if (lag && u >= 2u) {
+                em->opt_iteration = u - 1u;
+                r = run_accumulate(em, true, false, false, (int)(u - 1u <= 5u));     // EM.cpp:99 for update(u-1)
+            } else {
+                r = run_accumulate(em, true);
+            }
+            if (!r) r = run_allreduce(em);
+            if (!r && !lag) { em->opt_iteration = u; r = run_update(em, u <= 5u); }    // EM.cpp:99
+        } else {
+            em->opt_iteration = max_it;
+            r = run_update(em, max_it <= 5u);
+        }
         if (r) return r;
-        if (!em->d_status_mirror)
-            BAMM_HIP(hipMemcpyAsync(em->h_status + 8 + 8 * (it & 1u), em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
-        BAMM_HIP(hipEventRecord(em->opt_events[it & 1u], st));
+        const uint32_t upd = u - lag;                        // the update this unit carried (0: none)
+        if (upd >= 1u && !em->d_status_mirror)
+            BAMM_HIP(hipMemcpyAsync(em->h_status + 8 + 8 * (upd & 1u), em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+        BAMM_HIP(hipEventRecord(em->opt_events[u & 1u], st));
         return BAMM_OK;
     };
-    auto leave = [&](int r) { em->stop_arg = nullptr; return r; };
-    uint32_t enqueued = 1, done = 0;
+    // every exit: the kernels stop looking at the flag; sums nobody consumed are cleared before the next pass
+    auto leave = [&](int r) { em->stop_arg = nullptr; if (r) em->acc_dirty = true; return r; };
+    uint32_t enqueued = 0, done = 0;
     float llh = em->llh_prev;
-    if ((rc = enqueue(1))) return leave(rc);
     for (;;) {                                                              // EM.cpp:81
-        const Book before_ahead = capture();
-        bool ahead = false;
-        if (enqueued < max_it) {
-            if ((rc = enqueue(enqueued + 1u))) return leave(rc);
-            enqueued++;
-            ahead = true;
-        }
         done++;
-        BAMM_HIP(hipEventSynchronize(em->opt_events[done & 1u]));
+        while (enqueued < std::min(units, done + lag + 1u)) {               // the unit with status(done) and one beyond it
+            if ((rc = enqueue_unit(enqueued + 1u))) return leave(rc);
+            enqueued++;
+        }
+        if (hipEventSynchronize(em->opt_events[(done + lag) & 1u]) != hipSuccess) {
+            set_error("hipEventSynchronize failed in optimize()");
+            return leave(BAMM_ERR_HIP);
+        }
         const float* hs = em->h_status + 8 + 8 * (done & 1u);
         const float llh_prev = llh;
         llh = hs[0];
@@ -1129,12 +1268,16 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
         bool iterate = true;
         if (v_diff < em->prm.epsilon) iterate = false;                      // EM.cpp:117
         if (llh - llh_prev < 0 && done > 10) iterate = false;               // EM.cpp:118
-        if (!iterate) {
-            if (ahead) restore(before_ahead);                               // that pass found the flag raised: it did nothing
+        if (!iterate || done == max_it) {
             memcpy(em->h_status, hs, 8 * sizeof(float));
+            if (!iterate) {
+                // whatever was enqueued behind update(done) found the flag raised and did nothing: back to the snapshot
+                // prepare_update took right after update(done) (buffers, iteration count, kernel-timing samples)
+                restore_book(em, em->books[(first_update + done) & 3u]);
+                if (lag) em->acc_dirty = true;                              // the ring slot the fused update read was never cleared
+            }
             break;
         }
-        if (done == max_it) { memcpy(em->h_status, hs, 8 * sizeof(float)); break; }
     }
     em->stop_arg = nullptr;
     em->llh_prev = llh;

@@ -11,16 +11,40 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <mutex>
 
 #include "common.h"
 
 using namespace bamm;
 
+// bamm_comm_init_local: the ranks of ONE process summed through pinned host memory -- no RCCL, any devices (even
+// one device behind several contexts).  A self-test vehicle (the N > 1 host logic on a 1-GPU box) and the way out
+// when librccl cannot be opened; tens of microseconds per call, never used for reported numbers.
+struct LocalGroup {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint32_t n = 0, arrived = 0, generation = 0, refs = 0;
+    bool aborted = false;
+    std::vector<long long*> inbox;          // [rank] pinned, `cap` words: what the rank contributed
+    size_t cap = 0;
+    // false when the group was aborted while (or before) waiting
+    bool barrier() {
+        std::unique_lock<std::mutex> lock(mu);
+        if (aborted) return false;
+        const uint32_t gen = generation;
+        if (++arrived == n) { arrived = 0; generation++; cv.notify_all(); return true; }
+        cv.wait(lock, [&] { return generation != gen || aborted; });
+        return generation != gen;
+    }
+};
+
 struct bamm_comm {
     ncclComm_t comm = nullptr;
     bamm_ctx* ctx = nullptr;
     uint32_t rank = 0, world = 1;
+    LocalGroup* local = nullptr;            // non-null: host-staged sum inside this process
+    long long* h_sum = nullptr;             // pinned, local kind
 };
 
 namespace {
@@ -31,6 +55,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int*) = nullptr;
@@ -58,6 +83,7 @@ void load_rccl() {
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(sym("ncclCommAbort"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(sym("ncclGetVersion"));
@@ -82,7 +108,25 @@ int fail(const Rccl* r, const char* what, ncclResult_t rc) {
 
 namespace bamm {
 
+static int local_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st) {
+    LocalGroup* g = c->local;
+    if (n_words > g->cap) { set_error("local all-reduce of %zu words (capacity %zu)", n_words, g->cap); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipSetDevice(ctx_device(c->ctx)));
+    BAMM_HIP(hipMemcpyAsync(g->inbox[c->rank], dev_ptr, n_words * sizeof(long long), hipMemcpyDeviceToHost, st));
+    BAMM_HIP(hipStreamSynchronize(st));
+    if (!g->barrier()) { set_error("local all-reduce: the group was aborted"); return BAMM_ERR_COMM; }
+    for (size_t i = 0; i < n_words; i++) {                   // integer sums: the rank order does not matter
+        long long t = 0;
+        for (uint32_t r = 0; r < g->n; r++) t += g->inbox[r][i];
+        c->h_sum[i] = t;
+    }
+    if (!g->barrier()) { set_error("local all-reduce: the group was aborted"); return BAMM_ERR_COMM; }   // inboxes free again
+    BAMM_HIP(hipMemcpyAsync(dev_ptr, c->h_sum, n_words * sizeof(long long), hipMemcpyHostToDevice, st));
+    return BAMM_OK;
+}
+
 int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st) {
+    if (c->local) return local_allreduce_i64(c, dev_ptr, n_words, st);
     const Rccl* r = rccl();
     if (!r) return BAMM_ERR_COMM;
     const ncclResult_t rc = r->AllReduce(dev_ptr, dev_ptr, n_words, ncclInt64, ncclSum, c->comm, st);
@@ -121,6 +165,51 @@ int bamm_comm_init_all(bamm_ctx* const* ctxs, uint32_t n, bamm_comm** out) {
     return BAMM_OK;
 }
 
+int bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, bamm_comm** out) {
+    if (!ctxs || !out || n == 0 || max_words == 0) { set_error("bamm_comm_init_local: bad argument"); return BAMM_ERR_ARG; }
+    for (uint32_t i = 0; i < n; i++) out[i] = nullptr;
+    for (uint32_t i = 0; i < n; i++)
+        if (!ctxs[i]) { set_error("bamm_comm_init_local: null context %u", i); return BAMM_ERR_ARG; }
+    LocalGroup* g = new LocalGroup();
+    g->n = n; g->cap = (size_t)max_words; g->refs = n;
+    g->inbox.assign(n, nullptr);
+    std::vector<bamm_comm*> made;
+    bool ok = true;
+    for (uint32_t i = 0; i < n && ok; i++) {
+        bamm_comm* c = new bamm_comm();
+        c->ctx = ctxs[i]; c->rank = i; c->world = n; c->local = g;
+        made.push_back(c);
+        ok = hipSetDevice(ctx_device(ctxs[i])) == hipSuccess &&
+             hipHostMalloc((void**)&g->inbox[i], g->cap * sizeof(long long), hipHostMallocPortable) == hipSuccess &&
+             hipHostMalloc((void**)&c->h_sum, g->cap * sizeof(long long), hipHostMallocPortable) == hipSuccess;
+    }
+    if (!ok) {
+        for (bamm_comm* c : made) { (void)hipHostFree(c->h_sum); delete c; }
+        for (long long* p : g->inbox) (void)hipHostFree(p);
+        delete g;
+        set_error("bamm_comm_init_local: pinned host buffers could not be allocated");
+        return BAMM_ERR_HIP;
+    }
+    for (uint32_t i = 0; i < n; i++) out[i] = made[i];
+    return BAMM_OK;
+}
+
+int bamm_comm_abort(bamm_comm* c) {
+    if (!c) return BAMM_OK;
+    if (c->local) {
+        { std::lock_guard<std::mutex> lock(c->local->mu); c->local->aborted = true; }
+        c->local->cv.notify_all();
+        return BAMM_OK;
+    }
+    const Rccl* r = rccl();
+    if (r && c->comm) {
+        (void)hipSetDevice(ctx_device(c->ctx));
+        (void)r->CommAbort(c->comm);                         // also frees the communicator
+        c->comm = nullptr;
+    }
+    return BAMM_OK;
+}
+
 int bamm_comm_unique_id(void* id_out, size_t cap) {
     if (!id_out || cap < BAMM_COMM_ID_BYTES) { set_error("bamm_comm_unique_id: buffer of %d bytes needed", BAMM_COMM_ID_BYTES); return BAMM_ERR_ARG; }
     static_assert(sizeof(ncclUniqueId) == BAMM_COMM_ID_BYTES, "ncclUniqueId size");
@@ -155,15 +244,29 @@ int bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rcc
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
     if (rccl_version) {
-        const Rccl* r = rccl();
-        *rccl_version = 0;
-        if (r) (void)r->GetVersion(rccl_version);
+        *rccl_version = 0;                                   // 0: the host-staged group of bamm_comm_init_local
+        if (!c->local) {
+            const Rccl* r = rccl();
+            if (r) (void)r->GetVersion(rccl_version);
+        }
     }
     return BAMM_OK;
 }
 
 int bamm_comm_destroy(bamm_comm* c) {
     if (!c) return BAMM_OK;
+    if (c->local) {
+        LocalGroup* g = c->local;
+        (void)hipHostFree(c->h_sum);
+        bool last;
+        { std::lock_guard<std::mutex> lock(g->mu); last = --g->refs == 0; }
+        if (last) {
+            for (long long* p : g->inbox) (void)hipHostFree(p);
+            delete g;
+        }
+        delete c;
+        return BAMM_OK;
+    }
     const Rccl* r = rccl();
     if (r && c->comm) {
         (void)hipSetDevice(ctx_device(c->ctx));

@@ -114,6 +114,48 @@ struct GrpGeom {
     uint32_t mixA, mixB, off_sg6, off_ng6;
 };
 
+struct UpdateArgs {
+    uint32_t K, W, Kbg;          // Kbg = min(bg_order, K)
+    long long* acc;              // [Y*W + 3]: n_K in [y][j] (units of count_unit), llh, sum_r (fixed point), n_seqs;
+                                 // k_update: consumed AND zeroed; fused into the next pass's kernel: read only
+    long long* acc_zero;         // nullable: another slot of the accumulator ring to clear (the one the pass after next adds
+                                 // into; k_update: the slot the last fused kernel read and could not clear itself)
+    double   count_unit;         // value of one unit of the counts (2^-40 unless the set is huge)
+    const float* vbg;            // flat bg conditionals (orders 0..bg_order)
+    const float* A;              // [K+1][W]
+    float* n;                    // flat counts (all orders)
+    float* v;                    // flat conditionals (all orders): the new model
+    const float* v_old;          // nullable: the model the pass ran with, when it is not `v` itself (fused updates keep the
+                                 // two apart: every block reads the old one while the writer block stores the new one)
+    float* s;                    // [W][Y+1] linear odds for the next E-step
+    float* q;                    // device scalar (input)
+    float* q_out;                // device scalar for the next pass (may alias q)
+    float* status;               // [8]: llh, v_diff, q, iteration, ...
+    float* trace;                // [cap][3]
+    uint32_t trace_cap;
+    uint32_t* iteration;         // device counter
+    int32_t optimize_q;          // re-estimate q in this pass (EM.cpp:99: the first five passes of an optimize() call)
+    double n_seqs_override;      // >0: use instead of red[..+2]
+    // optimize(): the stop rule evaluated where its inputs are (EM.cpp:117-118, same float comparisons as the host's)
+    uint32_t* stop;              // nullable; set to 1 when the rule fires; a non-zero word makes this launch a no-op
+    float epsilon;               // EM.h:62
+    float llh_prev;              // likelihood before this pass when it is the call's first ...
+    int32_t llh_prev_from_status;   // ... else *llh_in, as the previous update left it
+    const float* llh_in;         // the previous update's log-likelihood (a slot the writer does not store into)
+    float* llh_out;              // nullable: where this update leaves its own
+    uint32_t opt_iteration;      // 1-based pass number inside this optimize() call (`iteration > 10`)
+    float* status_mirror;        // nullable: pinned host memory (device address) that receives the 8 status words as
+                                 // well, so that the host needs no copy in the stream to see them
+};
+
+// the update with every order of n staged in LDS (update_kernel.h): scratch bytes, and
+// whether it applies -- at most 2048 cells of the top order (two per thread at 1024 threads), tables within 60 KiB
+inline size_t update_lds_bytes(uint32_t K, uint32_t W) {   // n of all orders, A, vbg (each padded to 8 bytes), 16 + 4 doubles
+    auto even = [](size_t x) { return (x + 1) & ~size_t(1); };
+    return (even(v_size(K, W)) + even((size_t)(K + 1) * W) + even(bg_size(K))) * sizeof(float) + (16 + 4) * sizeof(double);
+}
+inline bool update_fits_lds(uint32_t K, uint32_t W) { return ipow4(K + 1) * W <= 2048u && update_lds_bytes(K, W) <= 60u * 1024u; }
+
 struct GrpKernelArgs {
     EmKernelArgs e;
     GrpGeom g;
@@ -123,6 +165,12 @@ struct GrpKernelArgs {
     // wave (12-byte entries: grouped_kernel.h, GrpLogEntry) and folded into single-column bins in the block epilogue
     unsigned long long* fix_log;
     uint32_t fix_log_cap;        // entries per wave: sequences of the wave x fix lanes (Bv * T)
+    // fused update (update_kernel.h): the previous pass's model update runs in this launch's block prologue instead of
+    // a kernel of its own; e.s / e.q are then what the writer block publishes (later launches of the pass, getR)
+    uint32_t fused;              // 0 = e.s / e.q hold the model as usual
+    uint32_t upd_off;            // LDS byte offset of the update's scratch (update_lds_bytes), inside the count tables
+    float*   s_block;            // [blocks][W * (Y + 1)]: every block's copy of the odds table for its fix lanes
+    UpdateArgs upd;
 };
 
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply
@@ -168,33 +216,6 @@ struct ScoreKernelArgs {
     uint32_t* z;                 // [N]
 };
 
-struct UpdateArgs {
-    uint32_t K, W, Kbg;          // Kbg = min(bg_order, K)
-    long long* acc;              // [Y*W + 3]: n_K in [y][j] (units of count_unit), llh, sum_r (fixed point), n_seqs;
-                                 // consumed AND zeroed for the next pass
-    double   count_unit;         // value of one unit of the counts (2^-40 unless the set is huge)
-    const float* vbg;            // flat bg conditionals (orders 0..bg_order)
-    const float* A;              // [K+1][W]
-    float* n;                    // flat counts (all orders)
-    float* v;                    // flat conditionals (all orders), updated in place
-    float* s;                    // [W][Y+1] linear odds for the next E-step
-    float* q;                    // device scalar (input)
-    float* q_out;                // device scalar for the next pass (may alias q)
-    float* status;               // [8]: llh, v_diff, q, iteration, ...
-    float* trace;                // [cap][3]
-    uint32_t trace_cap;
-    uint32_t* iteration;         // device counter
-    int32_t optimize_q;          // re-estimate q in this pass (EM.cpp:99: the first five passes of an optimize() call)
-    double n_seqs_override;      // >0: use instead of red[..+2]
-    // optimize(): the stop rule evaluated where its inputs are (EM.cpp:117-118, same float comparisons as the host's)
-    uint32_t* stop;              // nullable; set to 1 when the rule fires; a non-zero word makes this launch a no-op
-    float epsilon;               // EM.h:62
-    float llh_prev;              // likelihood before this pass when it is the call's first ...
-    int32_t llh_prev_from_status;   // ... else status[0] as the previous update left it
-    uint32_t opt_iteration;      // 1-based pass number inside this optimize() call (`iteration > 10`)
-    float* status_mirror;        // nullable: pinned host memory (device address) that receives the 8 status words as
-                                 // well, so that the host needs no copy in the stream to see them
-};
 
 struct MaskSelect {              // device state of the radix select (EM.cpp:329-343)
     double   pos_count;          // number of windows (all ranks)

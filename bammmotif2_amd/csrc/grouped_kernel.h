@@ -45,6 +45,7 @@
 
 #pragma once
 #include "device_utils.h"
+#include "update_kernel.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -242,7 +243,27 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // ---- block prologue: single-column table, grouped table, zeroed counts.  The loads of `s` are issued
     // first and everything that does not need them (zeroed counts, neutral slots) runs under their latency.
     const bool s1_to_lds = !FIXG || g.cap != 0u;
-    const bool s1_in_regs = s1_to_lds && W * Ys <= 2u * blockDim.x;      // at most two cells per thread: K <= 2 at usual widths
+    // fused update (update_kernel.h; planned for K <= 2 and up to 16 positions per lane only): the previous pass's model update runs here, in every
+    // block, its scratch where the count table will be; the odds table lands in the single-column table's place and
+    // in this block's global copy for the fix lanes.  Inside optimize() a fired stop rule ends the block here.
+    [[maybe_unused]] float q_fused = 0.0f;
+    bool fused_now = false;
+    if constexpr (ACCUM && !FIXG && M <= 16) {               // up to 1024 positions: beyond that a launch dwarfs the update's 6 us
+        if (ga.fused) {
+            const UpdateOut uo = model_update_lds<false>(ga.upd, lds_raw + ga.upd_off, reinterpret_cast<float*>(lds_raw + g.off_s1),
+                                                         blockIdx.x == 0);
+            if (uo.fired) {                                  // block-uniform: the model is final, no pass follows
+                if (blockIdx.x == 0) { __syncthreads(); publish_odds(ga.upd, reinterpret_cast<const float*>(lds_raw + g.off_s1), nullptr, true); }
+                return;
+            }
+            q_fused = uo.q;
+            fused_now = true;
+            __syncthreads();                                 // the scratch becomes the count table below
+            publish_odds(ga.upd, reinterpret_cast<const float*>(lds_raw + g.off_s1), ga.s_block + (size_t)blockIdx.x * (W * Ys), blockIdx.x == 0);
+        }
+    }
+    const float* const sfix = fused_now ? ga.s_block + (size_t)blockIdx.x * (W * Ys) : a.s;
+    const bool s1_in_regs = !fused_now && s1_to_lds && W * Ys <= 2u * blockDim.x;      // at most two cells per thread: K <= 2 at usual widths
     float s1_r0 = 1.0f, s1_r1 = 1.0f;
     if (s1_in_regs) {
         if (threadIdx.x < W * Ys) s1_r0 = a.s[threadIdx.x];
@@ -258,7 +279,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const uint32_t row = Rn + i / (4u * Tq), slot = i % (4u * Tq);
         sg[row * g.rowstride + slot] = 1.0f;
     }
-    if (s1_to_lds) {
+    if (s1_to_lds && !fused_now) {
         float* s1w = reinterpret_cast<float*>(lds_raw + g.off_s1);
         if (s1_in_regs) {
             if (threadIdx.x < W * Ys) s1w[threadIdx.x] = s1_r0;
@@ -293,7 +314,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     }
     __syncthreads();
 
-    const float q = *a.q;
+    const float q = fused_now ? q_fused : *a.q;
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
     const uint32_t vbase = g.R0 + wave * g.Bv;
@@ -449,7 +470,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
                 yfix[c] = yc;
                 const uint32_t idx = __umul24((uint32_t)max(col, 0), Ys) + yc;
-                fs[c] = a.s[idx];
+                fs[c] = sfix[idx];
             }
         }
         if constexpr (kOneWindow) decode_rows();

@@ -28,6 +28,7 @@
 // table is written.  No MFMA: this is gather/scatter, not a contraction.
 
 #include "device_utils.h"
+#include "update_kernel.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -754,30 +755,34 @@ template <bool IN_LDS>
 __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
     if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
 
-    extern __shared__ float upd_lds[];
+    extern __shared__ __align__(16) unsigned char upd_lds[];
+    if constexpr (IN_LDS) {
+        // the same device function the sequence kernels run in their prologue when the update is fused into the
+        // next pass (update_kernel.h): here one block, the accumulator consumed and zeroed
+        (void)model_update_lds<true>(a, upd_lds, nullptr, true);
+    } else {
     __shared__ double shd[16];
     __shared__ double stat3[3];
     const uint32_t K = a.K, W = a.W;
     const uint32_t YK = 1u << (2 * (K + 1));
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     auto voff = [W](uint32_t k) { return (size_t)W * (((size_t(1) << (2 * (k + 1))) - 4) / 3); };
-    const size_t vsz = voff(K + 1);
-    float* const n = IN_LDS ? upd_lds : a.n;               // all orders, flat [k][y][j]
-    float* const v = IN_LDS ? upd_lds + vsz : a.v;
+    float* const n = a.n;                                  // all orders, flat [k][y][j]
+    float* const v = a.v;
 
     // order-K counts from the (all-reduced) integer accumulator, which is left zeroed for the next pass
     float* nK = n + voff(K);
-    float old0 = 0.0f, old1 = 0.0f;                        // IN_LDS: this thread's (at most two) cells of the old v[K], for v_diff
-    for (uint32_t i = tid, u = 0; i < YK * W; i += nt, u++) {
+    for (uint32_t i = tid; i < YK * W; i += nt) {
         nK[i] = (float)((double)a.acc[i] * a.count_unit);
         a.acc[i] = 0ll;
-        if (IN_LDS) { const float x = a.v[voff(K) + i]; old0 = u == 0u ? x : old0; old1 = u == 1u ? x : old1; }
     }
     if (tid < 3) {
         const long long x = a.acc[(size_t)YK * W + tid];
         a.acc[(size_t)YK * W + tid] = 0ll;
         stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : (double)x);
     }
+    if (a.acc_zero != nullptr)
+        for (uint32_t i = tid; i < YK * W + 3u; i += nt) a.acc_zero[i] = 0ll;
     __syncthreads();
     // EM.cpp:247-254: n[k-1][y mod 4^k][j] += n[k][y][j], y ascending (same float order)
     for (uint32_t k = K; k > 0; k--) {
@@ -813,13 +818,13 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         const float* vk1 = v + voff(k - 1);
         const float* Ak = a.A + (size_t)k * W;
         const uint32_t Yk1 = 1u << (2 * (k + 1)), Yk = 1u << (2 * k);
-        for (uint32_t i = tid, u = 0; i < Yk1 * W; i += nt, u++) {
+        for (uint32_t i = tid; i < Yk1 * W; i += nt) {
             const uint32_t y = i / W, j = i % W;
             const uint32_t y2 = y % Yk, yk = y / 4;
             float nv;
             if (j < k) nv = vk1[(size_t)y2 * W + j];
             else nv = (nk[i] + Ak[j] * vk1[(size_t)y2 * W + j]) / (nk1[(size_t)yk * W + j - 1] + Ak[j]);
-            if (k == K) diff += (double)fabsf(nv - (IN_LDS ? (u == 0u ? old0 : old1) : a.v[voff(K) + i]));
+            if (k == K) diff += (double)fabsf(nv - a.v[voff(K) + i]);
             vk[i] = nv;
         }
         __syncthreads();
@@ -839,8 +844,6 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         __syncthreads();
     }
     const double v_diff = shd[0];
-    if (IN_LDS)                                            // results out: one coalesced sweep, nobody waits for it
-        for (uint32_t i = tid; i < vsz; i += nt) { a.n[i] = n[i]; a.v[i] = v[i]; }
     // next E-step's odds table (Motif.cpp:485-494)
     {
         const uint32_t Ys = YK + 1u, Yb = 1u << (2 * (a.Kbg + 1));
@@ -861,9 +864,10 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
             q = (float)((nseq - sum_r + 1.0) / (nseq + 2.0));
         *a.q_out = q;
         if (a.stop != nullptr) {                           // EM.cpp:117-118
-            const float llh_prev = a.llh_prev_from_status ? a.status[0] : a.llh_prev;
+            const float llh_prev = a.llh_prev_from_status ? *a.llh_in : a.llh_prev;
             if ((float)v_diff < a.epsilon || ((float)llh - llh_prev < 0 && a.opt_iteration > 10u)) *a.stop = 1u;
         }
+        if (a.llh_out != nullptr) *a.llh_out = (float)llh;
         a.status[0] = (float)llh;
         a.status[1] = (float)v_diff;
         a.status[2] = q;
@@ -880,6 +884,7 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
             a.trace[(size_t)(it - 1u) * 3 + 2] = q;
         }
     }
+    }
 }
 
 // EStep() alone: publish the statistics and clear them (the counts part was not touched)
@@ -891,8 +896,6 @@ __global__ void k_stat_only(long long* acc, uint32_t cells, float* status) {
         acc[cells + 0] = 0ll; acc[cells + 1] = 0ll; acc[cells + 2] = 0ll;
     }
 }
-
-inline size_t W_cells(uint32_t K, uint32_t W) { return ((size_t)1 << (2 * (K + 1))) * W; }
 
 template <int M, int THREADS>
 int launch_em_variant(bool accum, bool write_r, const EmKernelArgs& a, uint32_t blocks, uint32_t threads,
@@ -1075,11 +1078,10 @@ int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint
 }
 
 int launch_update(const UpdateArgs& a, hipStream_t st) {
-    const size_t vsz = v_size(a.K, a.W);
     // n and v of all orders staged in LDS when at most two cells per thread of the top order are in flight
     // (the old v[K] is kept in two registers) and the tables fit the default 64 KiB
-    if ((size_t)W_cells(a.K, a.W) <= 2048u && 2 * vsz * sizeof(float) <= 60 * 1024) {
-        hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(1024), 2 * vsz * sizeof(float), st, a);
+    if (update_fits_lds(a.K, a.W)) {
+        hipLaunchKernelGGL(k_update<true>, dim3(1), dim3(1024), update_lds_bytes(a.K, a.W), st, a);
     } else {
         hipLaunchKernelGGL(k_update<false>, dim3(1), dim3(1024), 0, st, a);
     }

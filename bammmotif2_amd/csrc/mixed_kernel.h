@@ -75,13 +75,33 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     if (t < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t, lane);
 
     // ---- block prologue
+    // fused update (update_kernel.h): the previous pass's model update runs here, in every block, from the all-reduced
+    // accumulator -- its odds table lands where the prologue stages it anyway, and in this block's global copy for
+    // the fix lanes; block 0 publishes the model.  Inside optimize() a fired stop rule ends the block here.
+    [[maybe_unused]] float q_fused = 0.0f;
+    const float* const sfix = (ACCUM && ga.fused) ? ga.s_block + (size_t)blockIdx.x * (W * Ys) : a.s;
     {
         float* s1w = reinterpret_cast<float*>(lds_raw + g.off_s1);
         const float* s1 = s1_stage;
-        for (uint32_t i = threadIdx.x; i < W * Ys; i += THREADS) s1w[i] = a.s[i];
+        bool staged = false;
+        if constexpr (ACCUM) {
+            if (ga.fused) {
+                const UpdateOut uo = model_update_lds<false>(ga.upd, lds_raw + ga.upd_off, s1w, blockIdx.x == 0);
+                if (uo.fired) {                              // block-uniform: the model is final, no pass follows
+                    if (blockIdx.x == 0) { __syncthreads(); publish_odds(ga.upd, s1w, nullptr, true); }
+                    return;
+                }
+                q_fused = uo.q;
+                staged = true;
+            }
+        }
+        if (!staged)
+            for (uint32_t i = threadIdx.x; i < W * Ys; i += THREADS) s1w[i] = a.s[i];
         for (uint32_t i = threadIdx.x; i < (R5T - R5N) * rs5; i += THREADS) sg5[R5N * rs5 + i] = 1.0f;
         for (uint32_t i = threadIdx.x; i < (R6T - R6N) * A; i += THREADS) sg6[R6N * A + i] = 1.0f;
         __syncthreads();
+        if constexpr (ACCUM)
+            if (staged) publish_odds(ga.upd, s1w, ga.s_block + (size_t)blockIdx.x * (W * Ys), blockIdx.x == 0);
         for (uint32_t row = threadIdx.x; row < R5N; row += THREADS) {      // a group's 3 column odds in column order
             float* out = sg5 + row * rs5;
             for (uint32_t slot = 0; slot < pad; slot++) out[slot] = 1.0f;
@@ -111,7 +131,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         }
     }
 
-    const float q = *a.q;
+    const float q = (ACCUM && ga.fused) ? q_fused : *a.q;
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles: (row, group)
     const bool lane_wide = lane_t >= B;
@@ -196,7 +216,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                     if (pos >= LW1) yc = Y;                                            // EM.cpp:167 (also pos < 0)
                 }
                 yfix[c] = yc;
-                fs[c] = a.s[__umul24(colc, Ys) + yc];                                  // global, through L2
+                fs[c] = sfix[__umul24(colc, Ys) + yc];                                 // global, through L1 / L2
             }
         }
         // Which slots do not take their row from the stream -- beyond the EM.cpp:167 edge (neutral row), a

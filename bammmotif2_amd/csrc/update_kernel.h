@@ -1,0 +1,216 @@
+// The model update of one EM pass with every order of n and v staged in LDS, as a device function:
+//   EM.cpp:247-254 (marginalise), Motif::updateV init/Motif.h:95-136, EM::optimize_q EM.cpp:515,
+//   v_diff EM.cpp:102-108, the stop rule EM.cpp:117-118, Motif::calculateLinearS init/Motif.cpp:485-494
+// (file:line relative to /root/reference/src).
+//
+// Two callers run the SAME code (same float formulas in the same order: bit-identical models):
+//   * k_update<true> (kernels.hip): one block after the pass's all-reduce, the accumulator consumed and zeroed;
+//   * the block prologue of the NEXT pass's first sequence kernel (k_em_mix / k_em_grp, "fused update"): every
+//     block recomputes the <= 2048-cell update from the all-reduced accumulator of the previous pass into its own
+//     LDS -- 10 KB read through L2 and a few hundred cycles of LDS arithmetic instead of a kernel launch between
+//     two passes -- and block 0 of the launch (the "writer") alone publishes n, v, s, q, status and trace.  An
+//     iteration is then ONE kernel + ONE collective.  The accumulator is a ring of three: pass p adds into slot
+//     p mod 3, the next kernel's blocks read it, its writer clears the slot pass p + 2 will add into (every reader
+//     of that slot finished with the kernel before: stream order).
+#pragma once
+#include "device_utils.h"
+
+namespace bamm {
+namespace {
+
+struct UpdateOut {
+    float q;        // q of the next pass (every thread of the block)
+    bool fired;     // the stop rule fired (every thread; false when a.stop == nullptr)
+};
+
+// CONSUME: the standalone kernel's semantics -- the accumulator is zeroed as it is read.  Fused callers leave it
+//          (other blocks are still reading) and the writer clears a.acc_zero instead.
+// s_lds:   nullable; receives the next pass's odds table [W][Y+1] INSTEAD of a.s: the caller's prologue builds its grouped
+//          tables from it and, after its next barrier, copies it out coalesced (its block's global copy for the fix
+//          lanes; the writer block: a.s) -- publish_odds() below
+// Every thread of the block must call this (it synchronises the block).
+//
+// Two barriers instead of one per order: the reference's chain n_K -> n_(K-1) -> ... -> n_0, v_0 -> v_1 -> ... -> v_K
+// is recomputed per cell from what the previous phase left in LDS -- the SAME float expressions on the same operands
+// in the same order (sums of four ascending, one division per order), so every value has the bits the phased form
+// gave it; only the waiting is gone (7 block barriers and 4 exposed global-load latencies cost 4.3 us per launch).
+//   phase A  global -> LDS: n_K from the integer accumulator, A, vbg (every load of the update issued up front)
+//   phase B  n_k for k < K, each cell summed straight from n_K (EM.cpp:247-254: four rows of order k+1 per cell, ascending)
+//   phase C  per cell of every order: the v chain from order 0 up (Motif.h:100-135), v_diff, the odds table
+template <bool CONSUME>
+__device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsigned char* upd, float* s_lds, bool writer) {
+    const uint32_t K = a.K, W = a.W;
+    const uint32_t YK = 1u << (2 * (K + 1));
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    auto voff = [W](uint32_t k) { return (size_t)W * (((size_t(1) << (2 * (k + 1))) - 4) / 3); };
+    const size_t vsz = voff(K + 1);
+    const uint32_t nA = (K + 1u) * W, nB = ((1u << (2 * (a.Kbg + 2))) - 4u) / 3u;   // A[k][j]; vbg orders 0..Kbg
+    float* const n = reinterpret_cast<float*>(upd);                  // all orders, flat [k][y][j]
+    float* const Al = n + vsz;                                       // [(K+1) * W]
+    float* const bl = Al + ((nA + 1u) & ~1u);                        // vbg, orders 0..Kbg
+    double* const shd = reinterpret_cast<double*>(n + ((vsz + 1) & ~size_t(1)) + ((nA + 1u) & ~1u) + ((nB + 1u) & ~1u));   // [16] v_diff partials, [3] statistics
+    double* const stat3 = shd + 16;
+    const float* const v_old = a.v_old ? a.v_old : a.v;             // the model the pass ran with (v_diff)
+    long long* const acc = a.acc;
+    const bool want_diff = writer || a.stop != nullptr;              // block-uniform
+
+    // ---- phase A
+    const float q_in = *a.q;                                         // issued with the other loads of the update, used last
+    const float llh_before = (a.stop != nullptr && a.llh_prev_from_status) ? *a.llh_in : a.llh_prev;
+    float* nK = n + voff(K);
+    for (uint32_t i = tid; i < YK * W; i += nt) {
+        nK[i] = (float)((double)acc[i] * a.count_unit);
+        if (CONSUME) acc[i] = 0ll;
+    }
+    for (uint32_t i = tid; i < nA; i += nt) Al[i] = a.A[i];
+    for (uint32_t i = tid; i < nB; i += nt) bl[i] = a.vbg[i];
+    if (tid < 3) {
+        const long long x = acc[(size_t)YK * W + tid];
+        if (CONSUME) acc[(size_t)YK * W + tid] = 0ll;
+        stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : (double)x);
+    }
+    if (writer && a.acc_zero != nullptr)                             // the ring slot two passes ahead
+        for (uint32_t i = tid; i < YK * W + 3u; i += nt) a.acc_zero[i] = 0ll;
+    __syncthreads();
+    // ---- phase B: n[k][y][j] = (((0 + c_0) + c_1) + c_2) + c_3 over the four rows c_d = n[k+1][d * 4^(k+1) + y][j] of the
+    // next order, themselves sums of four, down to n_K: nested loops over the K - k levels (at most four: the
+    // tables fit LDS for K <= 4 only), each level summed from 0.0f upwards as the reference's += does
+    for (uint32_t k = 0; k < K; k++) {
+        const uint32_t Yk = 1u << (2 * (k + 1)), depth = K - k;
+        float* nk = n + voff(k);
+        for (uint32_t i = tid; i < Yk * W; i += nt) {
+            const uint32_t y = i / W, j = i % W;
+            float s0 = 0.0f;
+            for (uint32_t d1 = 0; d1 < 4; d1++) {
+                const uint32_t r1 = y + d1 * Yk;
+                float s1;
+                if (depth == 1u) s1 = nK[(size_t)r1 * W + j];
+                else {
+                    s1 = 0.0f;
+                    for (uint32_t d2 = 0; d2 < 4; d2++) {
+                        const uint32_t r2 = r1 + d2 * Yk * 4u;
+                        float s2;
+                        if (depth == 2u) s2 = nK[(size_t)r2 * W + j];
+                        else {
+                            s2 = 0.0f;
+                            for (uint32_t d3 = 0; d3 < 4; d3++) {
+                                const uint32_t r3 = r2 + d3 * Yk * 16u;
+                                float s3;
+                                if (depth == 3u) s3 = nK[(size_t)r3 * W + j];
+                                else {
+                                    s3 = 0.0f;
+                                    for (uint32_t d4 = 0; d4 < 4; d4++) s3 += nK[(size_t)(r3 + d4 * Yk * 64u) * W + j];
+                                }
+                                s2 += s3;
+                            }
+                        }
+                        s1 += s2;
+                    }
+                }
+                s0 += s1;
+            }
+            nk[i] = s0;
+        }
+    }
+    __syncthreads();
+    // ---- phase C: the v chain of a cell (y, j) of order k, from order 0 up (Motif.h:100-135)
+    //   v[0][y0][j] = (n[0][y0][j] + A[0][j] * vbg[0][y0]) / (sum_y' n[0][y'][j] + A[0][j])
+    //   v[kk][ykk][j] = j < kk ? v[kk-1][ykk mod 4^kk][j]
+    //                          : (n[kk][ykk][j] + A[kk][j] * v[kk-1][ykk mod 4^kk][j]) / (n[kk-1][ykk / 4][j-1] + A[kk][j])
+    auto v_cell = [&](uint32_t k, uint32_t y, uint32_t j) -> float {
+        float sumN = 0.0f;
+        for (uint32_t yy = 0; yy < 4; yy++) sumN += n[yy * W + j];
+        const uint32_t y0 = y & 3u;
+        float val = (n[y0 * W + j] + Al[j] * bl[y0]) / (sumN + Al[j]);
+        for (uint32_t kk = 1; kk <= k; kk++) {
+            if (j < kk) continue;                                    // the copy of the lower order's value
+            const uint32_t ykk = y & ((1u << (2 * (kk + 1))) - 1u);
+            const float* nkk = n + voff(kk);
+            const float* nk1 = n + voff(kk - 1);
+            const float Akj = Al[kk * W + j];
+            val = (nkk[(size_t)ykk * W + j] + Akj * val) / (nk1[(size_t)(ykk >> 2) * W + j - 1u] + Akj);
+        }
+        return val;
+    };
+    double diff = 0.0;
+    const uint32_t Ys = YK + 1u, Yb = 1u << (2 * (a.Kbg + 1));
+    const float* const b = bl + (((size_t)Yb - 4) / 3);
+    for (uint32_t k = 0; k <= K; k++) {
+        const uint32_t Yk1 = 1u << (2 * (k + 1));
+        if (k < K && !writer) continue;                              // the lower orders only leave the block through the writer
+        for (uint32_t i = tid; i < Yk1 * W; i += nt) {
+            const uint32_t y = i / W, j = i % W;
+            const float nv = v_cell(k, y, j);
+            if (k == K && want_diff) diff += (double)fabsf(nv - v_old[voff(K) + i]);   // before the store: k_update updates v in place
+            if (writer) { a.v[voff(k) + i] = nv; a.n[voff(k) + i] = n[voff(k) + i]; }
+            if (k == K) {
+                const float sv = nv / b[y % Yb];                     // Motif.cpp:485-494
+                if (s_lds != nullptr) s_lds[(size_t)j * Ys + y] = sv;
+                else if (writer) a.s[(size_t)j * Ys + y] = sv;
+            }
+        }
+    }
+    for (uint32_t j = tid; j < W; j += nt) {                         // the neutral row
+        if (s_lds != nullptr) s_lds[(size_t)j * Ys + YK] = 1.0f;
+        else if (writer) a.s[(size_t)j * Ys + YK] = 1.0f;
+    }
+    // v_diff (EM.cpp:102-108): wave sums, then the wave results.  Only who needs it: the writer (status, trace)
+    // and, inside optimize(), every block (the stop rule decides whether the block runs its pass)
+    double v_diff = 0.0;
+    if (want_diff) {
+        double d = diff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+        if ((tid & 63u) == 0u) shd[tid >> 6] = d;
+        __syncthreads();
+        for (uint32_t w = 0; w < (nt + 63u) / 64u; w++) v_diff += shd[w];      // same order in every thread
+    }
+    UpdateOut out;
+    const double llh = stat3[0], sum_r = stat3[1];
+    const double nseq = a.n_seqs_override > 0.0 ? a.n_seqs_override : stat3[2];
+    float q = q_in;
+    if (a.optimize_q)                                                // EM.cpp:515; the host applies EM.cpp:99's `iteration <= 5`
+        q = (float)((nseq - sum_r + 1.0) / (nseq + 2.0));
+    out.q = q;
+    out.fired = false;
+    if (a.stop != nullptr) {                                         // EM.cpp:117-118
+        out.fired = (float)v_diff < a.epsilon || ((float)llh - llh_before < 0 && a.opt_iteration > 10u);
+    }
+    if (writer && tid == 0) {
+        const uint32_t it = *a.iteration + 1u;
+        *a.iteration = it;
+        *a.q_out = q;
+        if (a.llh_out != nullptr) *a.llh_out = (float)llh;
+        if (out.fired) *a.stop = 1u;
+        a.status[0] = (float)llh;
+        a.status[1] = (float)v_diff;
+        a.status[2] = q;
+        a.status[3] = (float)it;
+        a.status[4] = (float)sum_r;
+        a.status[5] = (float)nseq;
+        if (a.status_mirror != nullptr) {
+            a.status_mirror[0] = (float)llh; a.status_mirror[1] = (float)v_diff; a.status_mirror[2] = q; a.status_mirror[3] = (float)it;
+            a.status_mirror[4] = (float)sum_r; a.status_mirror[5] = (float)nseq;
+        }
+        if (a.trace && it - 1u < a.trace_cap) {
+            a.trace[(size_t)(it - 1u) * 3 + 0] = (float)llh;
+            a.trace[(size_t)(it - 1u) * 3 + 1] = (float)v_diff;
+            a.trace[(size_t)(it - 1u) * 3 + 2] = q;
+        }
+    }
+    return out;
+}
+
+// after the barrier that follows model_update_lds(..., s_lds, ...): the odds table leaves the block, coalesced
+// (s_block nullable: a block that stops here -- the rule fired -- only publishes when it is the writer)
+__device__ __forceinline__ void publish_odds(const UpdateArgs& a, const float* s_lds, float* s_block, bool writer) {
+    const uint32_t cells = a.W * ((1u << (2 * (a.K + 1))) + 1u);
+    for (uint32_t i = threadIdx.x; i < cells; i += blockDim.x) {
+        const float x = s_lds[i];
+        if (s_block != nullptr) s_block[i] = x;
+        if (writer) a.s[i] = x;
+    }
+}
+
+}  // namespace
+}  // namespace bamm

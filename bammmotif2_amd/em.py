@@ -130,6 +130,13 @@ class PackedSeqs:
             pass
 
 
+def device_count() -> int:
+    """HIP devices visible to this process (raises without one: there is no CPU fallback)."""
+    n = C.c_int()
+    check(abi.load().bamm_device_count(C.byref(n)))
+    return int(n.value)
+
+
 class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self.lib = abi.load()
@@ -178,6 +185,20 @@ class Comm:
         out = (C.c_void_p * len(ctxs))()
         check(lib.bamm_comm_init_all(arr, len(ctxs), out))
         return [cls(c, C.c_void_p(h)) for c, h in zip(ctxs, out)]
+
+    @classmethod
+    def init_local(cls, ctxs, max_words: int):
+        """One process, len(ctxs) contexts on any devices (even one): host-staged sum, no RCCL (self-tests)."""
+        lib = ctxs[0].lib
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        out = (C.c_void_p * len(ctxs))()
+        check(lib.bamm_comm_init_local(arr, len(ctxs), max_words, out))
+        return [cls(c, C.c_void_p(h)) for c, h in zip(ctxs, out)]
+
+    def abort(self):
+        """Wake the peers blocked in a collective with this rank (they get BAMM_ERR_COMM)."""
+        if self.h:
+            self.lib.bamm_comm_abort(self.h)
 
     @staticmethod
     def unique_id() -> bytes:

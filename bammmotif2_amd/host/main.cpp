@@ -6,6 +6,7 @@
 // sequences (--EM) and spreads the cross-validation folds (--FDR) over N GPUs.  Not ported (exit
 // with a clear message): --CGS, non-STANDARD alphabets.
 #include <omp.h>
+#include <thread>
 #include <sys/stat.h>
 
 #include <chrono>
@@ -492,16 +493,35 @@ int main(int nargs, char* args[]) {
                 if (bamm_em_create(devs[d].ctx, devs[d].shard, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &ems[d])) die_abi("EM");
                 if (devs[d].comm && bamm_em_set_comm(ems[d], devs[d].comm)) die_abi("EM communicator");
             }
-            const int nthreads = sharded ? (int)ndev : 1;
-#pragma omp parallel num_threads(nthreads)
-            {
-                const size_t d = (size_t)omp_get_thread_num();
-                if (d < ndev && ems[d]) {
-                    int rc;
-                    if (!o.advanceEM) rc = bamm_em_optimize(ems[d], &its[d]);                    // mainBaMM.cpp:133-137
-                    else rc = bamm_em_mask(ems[d], o.f, &its[d], nullptr, nullptr);
-                    if (rc) thread_err[d] = bamm_last_error();                                    // thread-local message
+            // every refusal that depends on the data is decided from GLOBAL quantities before any collective starts
+            // (a rank that refused alone would leave its peers in ncclAllReduce): EM::mask's per-wave LDS plan
+            if (o.advanceEM && sharded) {
+                uint32_t longest = 0;
+                for (uint64_t n = 0; n < (uint64_t)kept_len.size(); n++) longest = std::max(longest, kept_len[n]);
+                // the plan of bamm_em_mask (csrc/abi.cpp, mask.hip): per wave two f32 and one u16 per position + a bit mask,
+                // next to one count column of 4^(K+1) u64 cells, within 160 KiB
+                auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+                const size_t wave_bytes = 2 * up16((size_t)longest * 4) + up16((size_t)longest * 2) + up16(((size_t)longest / 32 + 2) * 4);
+                if (longest > 65535u || wave_bytes + up16((size_t(1) << (2 * (motif.K + 1))) * 8) > 160u * 1024u) die("Error: --advanceEM keeps a sequence's windows in the LDS of one wavefront (about 16 000 positions at most); "
+                                          "the longest sequence here has " + std::to_string(longest) + ".");
+            }
+            // one std::thread per rank, not an OpenMP team (which may come back smaller than asked for and leave ranks
+            // out of the collective); a rank that still fails aborts every communicator so that its peers return
+            auto run_rank = [&](size_t d) {
+                int rc;
+                if (!o.advanceEM) rc = bamm_em_optimize(ems[d], &its[d]);                    // mainBaMM.cpp:133-137
+                else rc = bamm_em_mask(ems[d], o.f, &its[d], nullptr, nullptr);
+                if (rc) {
+                    thread_err[d] = bamm_last_error();                                        // thread-local message
+                    for (auto& dv : devs) if (dv.comm) bamm_comm_abort(dv.comm);
                 }
+            };
+            if (sharded) {
+                std::vector<std::thread> team;
+                for (size_t d = 0; d < ndev; d++) if (ems[d]) team.emplace_back(run_rank, d);
+                for (auto& t : team) t.join();
+            } else if (ems[0]) {
+                run_rank(0);
             }
             for (size_t d = 0; d < ndev; d++)
                 if (!thread_err[d].empty()) die("Error: EM on GPU " + std::to_string(devs[d].device) + ": " + thread_err[d]);

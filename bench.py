@@ -6,9 +6,15 @@
 A "step" is one EM iteration (EStep + MStep + updateV, /root/reference/src/refinement/EM.cpp:
 81-128) over the whole synthetic set: 1M x 200 bp, W = 20, k = 2, K_bg = 2, double-stranded
 (L = 401), seeded from the planted PWM.  The set is resident in HBM
-(2-bit packed) before the timed region.  With N > 1 (launched by torch.distributed.run, one
-rank per GPU) the SAME 1M sequences are sharded over the ranks ("strong" scaling, the shape
-BASELINE.json names) and the fused count buffer is all-reduced over RCCL once per iteration.
+(2-bit packed) before the timed region.  With N > 1 the SAME 1M sequences are sharded over the
+ranks ("strong" scaling, the shape BASELINE.json names) and the fused count buffer is all-reduced
+over RCCL once per iteration.  Two launch forms, same library path (csrc/comm.cpp):
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (WORLD_SIZE in the
+    environment): one process per GPU, ncclCommInitRank, torch.distributed only carries the id and
+    the barriers;
+  * plain `python bench.py --gpus N`: ONE process, one context + host thread per GPU,
+    ncclCommInitAll (what `BaMMmotif --gpus N` and integration/sharded_em.cpp do).  Fewer visible
+    devices than N is an error, never a silent single-GPU run.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     algorithmic HBM bytes of the sequence kernel / its HIP-event duration vs 8 TB/s
@@ -62,6 +68,12 @@ def parse():
                     help="all-reduce through torch.distributed.all_reduce from a Python callback instead of the "
                          "library's own RCCL call (bamm_em_set_comm), which is the default with the nccl backend")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-start / optimize()-mode figures")
+    ap.add_argument("--local-ranks", action="store_true",
+                    help="in-process form only: --gpus N ranks as N contexts on device 0 with the host-staged sum of "
+                         "bamm_comm_init_local instead of RCCL (self-test of the N>1 logic on a 1-GPU box; never "
+                         "used for reported numbers)")
+    ap.add_argument("--no-fused-update", action="store_true",
+                    help="a k_update launch after every pass instead of the update fused into the next pass's kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the fused buffer through the host: lets 2 ranks share ONE GPU (self-test of "
                          "the N>1 logic on a 1-GPU box; never used for reported numbers)")
@@ -155,6 +167,265 @@ def lds_roofline(tj, avg_kernel_s):
     return out
 
 
+def workload(args):
+    """The synthetic set of SURVEY.md 8(d) (seed 1234) and the seed model, packed once on the host."""
+    import bammmotif2_amd as bm
+    from bammmotif2_amd import synth
+    W, K, L0 = args.width, args.order, args.L0
+    pwm = synth.make_pwm(W, 1234)
+    codes, in_off = synth.make_sequences(args.nseq, L0, pwm, 1234, plant_frac=0.5)
+    packed = bm.PackedSeqs.from_codes(codes, in_off, args.ss, seed=42)
+    alpha = synth.default_alpha(K)
+    return dict(W=W, K=K, L0=L0, pwm=pwm, codes=codes, in_off=in_off, packed=packed, alpha=alpha,
+                A=synth.alpha_matrix(alpha, W), vbg=packed.bg_model(2, np.array([1.0, 10.0, 10.0], np.float32)),
+                v0=synth.bamm_from_pwm((0.7 * pwm + 0.3 * 0.25).astype(np.float32), K), q=0.3)
+
+
+def kernel_label(em, K):
+    g_seqs, o_seqs, _ = em.plan()
+    mixed_seqs = em.plan_mixed()
+    name = ("k_em_seq (E pass, compacted lists of the non-zero windows) + k_m_list x slices (column-sliced M pass)" if K >= 4 else
+            "k_em_mix (fused E+M, grouped columns: 5-mer rows, the last groups on 6-mer rows)" if o_seqs == 0 and mixed_seqs == g_seqs else
+            "k_em_grp (fused E+M, grouped columns)" if o_seqs == 0 else
+            "k_em_seq (fused E+M)" if g_seqs == 0 else "k_em_grp + k_em_seq (fused E+M)")
+    return name, bool(mixed_seqs)
+
+
+def git_head():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def pmc_summary(local_positions, K, avg_kernel_s):
+    """PMC figures of the same command from an EARLIER run (tools/pmc_run.sh -> tools/summarize_pmc.py: FETCH_SIZE / WRITE_SIZE
+    and the LDS counters need rocprofv3 passes of their own, they cannot be taken inside this process), matched by
+    workload.  The result says which committed file they come from."""
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):   # newest round first
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("positions_per_launch") == local_positions and tj.get("order", 2) == K:
+                src = {"file": os.path.relpath(tpath, ROOT), "measured_at_commit": tj.get("commit"),
+                       "how": "rocprofv3 --pmc passes of `python bench.py` (tools/pmc_run.sh), not this run"}
+                return tj.get("hbm_bytes_per_launch"), lds_roofline(tj, avg_kernel_s), src
+        except Exception:
+            pass
+    return None, None, None
+
+
+def report(args, wl, world, dt, kernel_ms, launches, local_positions, local_windows, kernel_name, mixed, llh_last,
+           allreduce_kind, extras, ranks=None, launcher="single process"):
+    packed, W, K, L0 = wl["packed"], wl["W"], wl["K"], wl["L0"]
+    total_positions = packed.total_len
+    total_windows = int((packed.lengths.astype(np.int64) - W + 1).sum())
+    its = args.steps / dt
+    avg_kernel_s = kernel_ms / launches * 1e-3 if launches else float('nan')
+    sliced = K >= 4
+    alg_bytes = algorithmic_bytes(local_positions, local_windows, sliced)
+    achieved = alg_bytes / avg_kernel_s / 1e9
+    traffic, lds, pmc_src = pmc_summary(local_positions, K, avg_kernel_s)
+    L = int(packed.lengths[0]) if packed.n_seqs else 0
+    shape = f"{args.nseq // 1000000}M" if args.nseq % 1000000 == 0 else (f"{args.nseq // 1000}k" if args.nseq % 1000 == 0 else str(args.nseq))
+    out = {
+        "metric": f"EM seq-positions/sec (and iterations/sec), {shape}x{L0}bp k={K} W={W}",
+        "value": total_positions * its,
+        "unit": "positions/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "iterations_per_s": its,
+        "windows_per_s": total_windows * its,
+        "timed_region": f"passes {args.warmup + 1}-{args.warmup + args.steps} of one handle through iterate() (fixed budget, SURVEY H5); "
+                        "`from_seed` beside it: the first passes from the seed model, as iterate() and as optimize()",
+        "config": {"workload": f"{args.nseq}x{L0}bp {'single' if args.ss else 'double'}-strand "
+                               f"(L={L}), W={W}, k={K}, K_bg=2, --EM, fixed iteration budget",
+                   "n_seqs": args.nseq, "seq_len": L0, "W": W, "k": K,
+                   "parallelism": f"sequences sharded over {world} GPU(s), 1 all-reduce of "
+                                  f"{4 ** (K + 1) * W + 3} int64 words per iteration" if world > 1 else "1 GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
+                     "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     "algorithmic_bytes_rule": ("0.5 B/position + 8 B/window (sequence read by the E and the M pass, "
+                                                "r written and read once as f32)" if sliced else
+                                                "0.25 B/position (2-bit base, read once)"),
+                     "moved_bytes_frac": (traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "lds": lds, "lds_source": pmc_src if lds else None,
+                     "note": ("E pass + M slices of one iteration, timed together; `moved_bytes_frac` = PMC traffic / time / peak "
+                              "(the lists between E and M move fewer bytes than SURVEY's dense round trip of r)" if sliced else
+                              "the fused kernel is LDS / VALU issue bound (DESIGN.md section 4): "
+                              "`lds` prices it against a measured LDS ceiling" +
+                              ("; `traffic` = the 2-bit stream and records (~1.5 x the algorithmic bytes) plus the "
+                               "fix lanes' log of virtual-row sums, written during the pass and read back once per "
+                               "block (mixed rows and K = 3 have no LDS left for all of those bins)"
+                               if (mixed or K == 3) else ""))},
+        "allreduce": allreduce_kind,
+        "launcher": launcher,
+        "ranks": ranks,
+        "commit": git_head(),
+        "parity": "learned v within 1e-5 of the reference on its own fixtures up to ~2k sequences; beyond that the "
+                  "reference's fp32 CAS accumulation is itself 4e-5 (10k) to 4e-4 (200k) off exact arithmetic, while "
+                  "this path stays within 3e-7 of the fp64 restatement at every size (integer accumulation; "
+                  "profiles/r02_deviation_vs_fp64.txt, tests/test_golden_gpu.py, tests/golden_tolerance_report.py)",
+        "llh_last": llh_last,
+        **extras,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(wl["codes"], wl["in_off"], W, K, wl["v0"], wl["alpha"], wl["q"], args.cpu_sample,
+                                               args.cpu_iters, args.ss)
+            # a ratio of the GPU's whole-set rate to the CPU's rate on the SAMPLE (positions/s does not depend
+            # on the set size for the reference's loops): a stated baseline, not a kernel-quality figure
+            out["cpu_baseline"]["gpu_over_cpu_sample_rate"] = out["value"] / out["cpu_baseline"]["value"]
+        except Exception as e:  # the baseline is a reported number, never a reason to lose the line
+            out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": usable_cpus(),
+                                   "kind": "unavailable", "sample": repr(e)}
+    return out
+
+
+def from_seed_extras(bm, ctx, seqs, wl, args, sync):
+    """Beside the steady-state figure: what a run from the seed pays (the first passes are slower: few
+    responsibilities are exactly zero yet), as iterate() and as optimize() (EM.cpp:81-128: the stopping rule looks
+    at (llh, v_diff) of every pass); single rank only, outside the timed region."""
+    n_cold = 20
+    W, K = wl["W"], wl["K"]
+    out = {}
+    e2 = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=n_cold, n_seqs_bound=args.nseq)
+    sync()
+    t1 = time.perf_counter(); e2.iterate(n_cold); sync()
+    out["ms_per_step_cold"] = (time.perf_counter() - t1) / n_cold * 1e3
+    e2.close()
+    e3 = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=n_cold, epsilon=0.0, n_seqs_bound=args.nseq)
+    sync()
+    t1 = time.perf_counter(); it3 = e3.optimize(); sync()
+    out["ms_per_step_optimize_mode"] = (time.perf_counter() - t1) / max(it3, 1) * 1e3
+    out["cold_passes"] = n_cold
+    e3.close()
+    out["from_seed"] = {"passes": n_cold, "ms_per_step_iterate": out["ms_per_step_cold"], "ms_per_step_optimize": out["ms_per_step_optimize_mode"],
+                        "positions_per_s_iterate": wl["packed"].total_len / (out["ms_per_step_cold"] * 1e-3)}
+    return out
+
+
+def main_inprocess(args, result_fd):
+    """`python bench.py --gpus N` without a launcher: ONE process, a context + host thread per GPU, the library's
+    own RCCL communicator (ncclCommInitAll).  ctypes releases the GIL during the calls, so the N iterate() calls
+    run side by side.  Nothing here touches torch."""
+    import threading
+    import bammmotif2_amd as bm
+    from bammmotif2_amd import build
+
+    build.build_library()
+    N = max(args.gpus, 1)
+    ndev = bm.device_count()                  # raises without a GPU
+    if args.local_ranks:
+        devices = [0] * N
+    else:
+        if ndev < N:
+            raise SystemExit(f"bench.py --gpus {N}: only {ndev} HIP device(s) visible -- refusing to report a {N}-GPU number "
+                             f"(use --local-ranks for a self-test of the {N}-rank logic on one device)")
+        devices = list(range(N))
+    wl = workload(args)
+    packed, W, K = wl["packed"], wl["W"], wl["K"]
+    ctxs, seqs, ems = [], [], []
+    for r in range(N):
+        ctx = bm.Context(devices[r])
+        if args.blocks or args.threads:
+            ctx.set_launch(args.blocks, args.threads)
+        elif args.local_ranks and N > 1:
+            ctx.set_launch(max(1, 240 // N), 0)              # the ranks share one device's CUs
+        if args.group_layout >= 0:
+            ctx.set_tuning(group_layout=args.group_layout)
+        if args.no_fused_update:
+            ctx.set_tuning(fused_update=0)
+        b, e = packed.shard_range(W, r, N)
+        ss = bm.SeqSet(ctx, packed, b, e)
+        em = bm.EM(ctx, ss, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=args.steps + args.warmup + 8,
+                   n_seqs_bound=args.nseq)
+        em.set_kernel_timing(max(2, min(8, args.steps // 16)))
+        ctxs.append(ctx); seqs.append(ss); ems.append(em)
+    comms = []
+    allreduce_kind = "none"
+    if N > 1 or args.force_dist:
+        if args.local_ranks:
+            comms = bm.Comm.init_local(ctxs, 4 ** (K + 1) * W + 3)
+            allreduce_kind = "host-staged sum inside the process (bamm_comm_init_local; self-test, not a reported configuration)"
+        else:
+            comms = bm.Comm.init_all(ctxs)
+            allreduce_kind = "rccl (libbamm_em, ncclCommInitAll + ncclAllReduce int64 on the kernels' stream, one host thread per GPU)"
+        for em, c in zip(ems, comms):
+            em.set_comm(c)
+    ranks = []
+    for r in range(N):
+        info = comms[r].info() if comms else dict(rank=0, world=1, rccl_version=None)
+        if info["world"] != N or info["rank"] != r:
+            raise SystemExit(f"rank {r}: communicator reports rank {info['rank']} of {info['world']}")
+        ranks.append({**info, "device": devices[r], "device_name": ctxs[r].device_name(), "n_seqs": seqs[r].n_seqs})
+
+    gate = threading.Barrier(N)
+    dts, errors = [0.0] * N, [None] * N
+
+    def worker(r):
+        try:
+            ems[r].iterate(args.warmup)
+            ctxs[r].sync()
+            gate.wait()                                      # barrier + synchronize on both sides of the timed region
+            t0 = time.perf_counter()
+            ems[r].iterate(args.steps)
+            ctxs[r].sync()
+            dts[r] = time.perf_counter() - t0
+            gate.wait()
+        except BaseException as e:                           # a rank that fails alone would leave the others in the collective
+            errors[r] = e
+            gate.abort()
+            for c in comms:
+                c.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,), name=f"rank{r}") for r in range(N)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    failed = [(r, e) for r, e in enumerate(errors) if e is not None and not isinstance(e, threading.BrokenBarrierError)]
+    if failed or any(errors):
+        raise SystemExit("bench.py: " + "; ".join(f"rank {r}: {e!r}" for r, e in (failed or list(enumerate(errors)))))
+    dt = max(dts)                                            # MAX over ranks
+    # every rank holds the same model, bit for bit (integer all-reduce, redundant update)
+    v0_ = ems[0].getV()
+    agree = all(np.array_equal(v0_, em.getV()) for em in ems[1:])
+    if not agree:
+        raise SystemExit("bench.py: the ranks' models differ after the run")
+    kernel = [em.kernel_time() for em in ems]
+    kernel_ms, launches = max(kernel)                        # the slowest rank's sequence kernel
+    llh, _, _ = ems[0].trace()
+    name, mixed = kernel_label(ems[0], K)
+    extras = {"ranks_agree_bitwise": agree, "ms_per_step_per_rank": [d / args.steps * 1e3 for d in dts]}
+    if N == 1 and not comms and not args.no_extras:
+        extras.update(from_seed_extras(bm, ctxs[0], seqs[0], wl, args, ctxs[0].sync))
+    lp = int(seqs[0].off[-1])
+    lw = int((seqs[0].lengths.astype(np.int64) - W + 1).sum())
+    out = report(args, wl, N, dt, kernel_ms, launches, lp, lw, name, mixed, float(llh[-1]) if len(llh) else None,
+                 allreduce_kind, extras, ranks, "one process, one host thread per GPU")
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
+    for em in ems:
+        em.close()
+    for ss in seqs:
+        ss.close()
+    for c in comms:
+        c.close()
+    for ctx in ctxs:
+        ctx.close()
+
+
 def main():
     args = parse()
     # stdout carries ONE JSON line (rank 0).  RCCL prints a version banner on stdout when a communicator
@@ -162,20 +433,25 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.local_ranks):
+        return main_inprocess(args, result_fd)               # no launcher: N ranks inside this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != max(args.gpus, 1) and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}) or drop the launcher and let bench.py run them in-process")
 
     import torch
     import torch.distributed as dist
     import bammmotif2_amd as bm
-    from bammmotif2_amd import synth, build
+    from bammmotif2_amd import build
 
     build.build_library()
     if args.dist_backend == "gloo":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} device(s) visible")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
@@ -186,15 +462,8 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    W, K, L0 = args.width, args.order, args.L0
-    pwm = synth.make_pwm(W, 1234)
-    codes, in_off = synth.make_sequences(args.nseq, L0, pwm, 1234, plant_frac=0.5)
-    packed = bm.PackedSeqs.from_codes(codes, in_off, args.ss, seed=42)
-    alpha = synth.default_alpha(K)
-    A = synth.alpha_matrix(alpha, W)
-    vbg = packed.bg_model(2, np.array([1.0, 10.0, 10.0], np.float32))
-    v0 = synth.bamm_from_pwm((0.7 * pwm + 0.3 * 0.25).astype(np.float32), K)
-    q = 0.3
+    wl = workload(args)
+    packed, W, K, A, vbg, v0, q = wl["packed"], wl["W"], wl["K"], wl["A"], wl["vbg"], wl["v0"], wl["q"]
 
     # one explicit HIP stream shared by the kernels and (through torch) the RCCL all-reduce:
     # torch's default stream has handle 0, which the C ABI would read as "create your own"
@@ -204,6 +473,8 @@ def main():
         ctx.set_launch(args.blocks, args.threads)
     if args.group_layout >= 0:
         ctx.set_tuning(group_layout=args.group_layout)
+    if args.no_fused_update:
+        ctx.set_tuning(fused_update=0)
     begin, end = packed.shard_range(W, rank, world)
     seqs = bm.SeqSet(ctx, packed, begin, end)
     em = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=args.steps + args.warmup + 8,
@@ -211,6 +482,7 @@ def main():
 
     keep = []
     allreduce_kind = "none"
+    rank_info = dict(rank=rank, world=world, rccl_version=None)
     if use_dist and args.dist_backend == "nccl" and not args.torch_allreduce:
         # the library's own collective: ncclAllReduce(int64, sum) on the context's stream, no Python in the
         # loop.  Rank 0's unique id travels over the torch process group that also serves the barriers.
@@ -233,7 +505,8 @@ def main():
         if int(agreed.item()) == 1:
             em.set_comm(comm)
             keep.append(comm)
-            allreduce_kind = "rccl (libbamm_em, ncclAllReduce int64 on the kernels' stream)"
+            rank_info = comm.info()
+            allreduce_kind = "rccl (libbamm_em, ncclCommInitRank + ncclAllReduce int64 on the kernels' stream)"
         else:
             if comm is not None:
                 comm.close()
@@ -282,107 +555,27 @@ def main():
         dt = float(t.item())
 
     kernel_ms, launches = em.kernel_time()
-    # beside the steady-state figure: what a run from the seed pays (the first passes are slower: few
-    # responsibilities are exactly zero yet), as iterate() and as optimize() (EM.cpp:81-128: one host
-    # read-back of (llh, v_diff) per pass for the stopping rule); single rank only, outside the timed region
     extras = {}
     if world == 1 and not use_dist and not args.no_extras:
-        n_cold = 20
         with torch.cuda.stream(tstream):
-            e2 = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=n_cold, n_seqs_bound=args.nseq)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter(); e2.iterate(n_cold); torch.cuda.synchronize()
-            extras["ms_per_step_cold"] = (time.perf_counter() - t1) / n_cold * 1e3
-            e2.close()
-            e3 = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=n_cold, epsilon=0.0, n_seqs_bound=args.nseq)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter(); it3 = e3.optimize(); torch.cuda.synchronize()
-            extras["ms_per_step_optimize_mode"] = (time.perf_counter() - t1) / max(it3, 1) * 1e3
-            extras["cold_passes"] = n_cold
-            e3.close()
+            extras = from_seed_extras(bm, ctx, seqs, wl, args, torch.cuda.synchronize)
     local_positions = int(seqs.off[-1])
     local_windows = int((seqs.lengths.astype(np.int64) - W + 1).sum())
-    total_positions = packed.total_len
-    total_windows = int((packed.lengths.astype(np.int64) - W + 1).sum())
     llh, vdiff, _ = em.trace()
-
-    g_seqs, o_seqs, _ = em.plan()
-    mixed_seqs = em.plan_mixed()
-    kernel_name = ("k_em_seq (E pass, compacted lists of the non-zero windows) + k_m_list x slices (column-sliced M pass)" if K >= 4 else
-                   "k_em_mix (fused E+M, grouped columns: 5-mer rows, the last groups on 6-mer rows)" if o_seqs == 0 and mixed_seqs == g_seqs else
-                   "k_em_grp (fused E+M, grouped columns)" if o_seqs == 0 else
-                   "k_em_seq (fused E+M)" if g_seqs == 0 else "k_em_grp + k_em_seq (fused E+M)")
+    kernel_name, mixed = kernel_label(em, K)
+    # what proves the N ranks: every rank's communicator view, gathered on rank 0
+    me = {**rank_info, "device": local_rank, "device_name": ctx.device_name(), "n_seqs": seqs.n_seqs}
+    ranks = [me]
+    if use_dist and world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks = gathered
+        if sorted(g["rank"] for g in ranks) != list(range(world)) or any(g["world"] != world for g in ranks):
+            raise SystemExit(f"bench.py: the ranks do not form a world of {world}: {ranks}")
     if rank == 0:
-        its = args.steps / dt
-        avg_kernel_s = kernel_ms / launches * 1e-3 if launches else float('nan')
-        sliced = K >= 4
-        alg_bytes = algorithmic_bytes(local_positions, local_windows, sliced)
-        achieved = alg_bytes / avg_kernel_s / 1e9
-        # PMC summaries of the same command (tools/pmc_run.sh -> tools/summarize_pmc.py), matched by workload
-        traffic, lds = None, None
-        import glob
-        for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")), reverse=True):   # newest round first
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("positions_per_launch") == local_positions and tj.get("order", 2) == K:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    lds = lds_roofline(tj, avg_kernel_s)
-                    break
-            except Exception:
-                pass
-        out = {
-            "metric": "EM seq-positions/sec (and iterations/sec), 1Mx200bp k=2 W=20",
-            "value": total_positions * its,
-            "unit": "positions/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "iterations_per_s": its,
-            "windows_per_s": total_windows * its,
-            "config": {"workload": f"{args.nseq}x{L0}bp {'single' if args.ss else 'double'}-strand "
-                                   f"(L={int(packed.lengths[0])}), W={W}, k={K}, K_bg=2, --EM, fixed iteration budget",
-                       "n_seqs": args.nseq, "seq_len": L0, "W": W, "k": K,
-                       "parallelism": f"sequences sharded over {world} GPU(s), 1 all-reduce of "
-                                      f"{4 ** (K + 1) * W + 3} int64 words per iteration" if world > 1 else "1 GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_rule": ("0.5 B/position + 8 B/window (sequence read by the E and the M pass, "
-                                                    "r written and read once as f32)" if sliced else
-                                                    "0.25 B/position (2-bit base, read once)"),
-                         "lds": lds,
-                         "note": ("E pass + M slices of one iteration, timed together" if sliced else
-                                  "the fused kernel is LDS / VALU issue bound (DESIGN.md section 4): "
-                                  "`lds` prices it against a measured LDS ceiling" +
-                                  ("; `traffic` = the 2-bit stream and records (~1.5 x the algorithmic bytes) plus the "
-                                   "fix lanes' log of virtual-row sums, written during the pass and read back once per "
-                                   "block (mixed rows and K = 3 have no LDS left for those bins)"
-                                   if (mixed_seqs or K == 3) else ""))},
-            "allreduce": allreduce_kind,
-            "parity": "learned v within 1e-5 of the reference on its own fixtures up to ~2k sequences; beyond that the "
-                      "reference's fp32 CAS accumulation is itself 4e-5 (10k) to 4e-4 (200k) off exact arithmetic, while "
-                      "this path stays within 3e-7 of the fp64 restatement at every size (integer accumulation; "
-                      "profiles/r01_deviation_vs_fp64.txt, tests/test_golden_gpu.py)",
-            "llh_last": float(llh[-1]) if len(llh) else None,
-            **extras,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                out["cpu_baseline"] = cpu_baseline(codes, in_off, W, K, v0, alpha, q, args.cpu_sample,
-                                                   args.cpu_iters, args.ss)
-                # a ratio of the GPU's whole-set rate to the CPU's rate on the SAMPLE (positions/s does not depend
-                # on the set size for the reference's loops): a stated baseline, not a kernel-quality figure
-                out["cpu_baseline"]["gpu_over_cpu_sample_rate"] = out["value"] / out["cpu_baseline"]["value"]
-            except Exception as e:  # the baseline is a reported number, never a reason to lose the line
-                out["cpu_baseline"] = {"value": None, "unit": "positions/s", "cores": usable_cpus(),
-                                       "kind": "unavailable", "sample": repr(e)}
+        out = report(args, wl, world, dt, kernel_ms, launches, local_positions, local_windows, kernel_name, mixed,
+                     float(llh[-1]) if len(llh) else None, allreduce_kind, extras, ranks,
+                     "torch.distributed.run, one process per GPU" if "WORLD_SIZE" in os.environ else "single process")
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
 

@@ -122,6 +122,8 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
  *   "e_fused"      1/0  sliced path: whole-table E pass when the odds table fits LDS (default 1)
  *   "e_list"       1/0  sliced path: the E pass hands the M slices compacted lists of the non-zero
  *                       windows instead of all responsibilities (default 1)
+ *   "fused_update" 1/0 inside iterate() / optimize() the model update of pass p runs in the block prologue of
+ *                       pass p+1's first kernel instead of a launch of its own (default 1; K <= 2-sized tables)
  * There are no environment variables that change what the library computes or launches.          */
 int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
 
@@ -225,8 +227,18 @@ int  bamm_comm_init_all(bamm_ctx* const* ctxs, uint32_t n, bamm_comm** out /* [n
  * to the other ranks (MPI, a file, torch.distributed ...), every rank calls init_rank.        */
 int  bamm_comm_unique_id(void* id_out, size_t cap);
 int  bamm_comm_init_rank(bamm_ctx* ctx, const void* id, uint32_t rank, uint32_t world, bamm_comm** out);
+/* one process, n contexts on ANY devices (the same one included): the sum is staged through pinned host memory
+ * between the ranks' host threads, no RCCL.  max_words >= the largest buffer summed (4^(K+1)*W + 3; EM::mask: 2049).
+ * For self-tests of the N > 1 logic on a 1-GPU box and for hosts without librccl; *rccl_version reports 0.       */
+int  bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, bamm_comm** out /* [n] */);
 int  bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rccl_version);
+/* a rank that fails calls this on its communicator (any thread): the collectives its peers are blocked in return
+ * BAMM_ERR_COMM instead of waiting for it for ever (ncclCommAbort; the local kind wakes its waiters).  The handle
+ * stays valid for bamm_comm_destroy only.                                                                        */
+int  bamm_comm_abort(bamm_comm* c);
 int  bamm_comm_destroy(bamm_comm* c);
+/* HIP devices visible to the process (0 and BAMM_ERR_NO_DEVICE when there is none)                               */
+int  bamm_device_count(int* n);
 
 /* results (each synchronises the stream)                                                     */
 int  bamm_em_get_v(bamm_em* em, float* v_flat);        /* Motif::getV()                       */

@@ -4,15 +4,14 @@
 // every GPU holds the identical model.  This is what `BaMMmotif --gpus N --EM` does
 // (bammmotif2_amd/host/main.cpp); tests/test_host_cpu.py compiles this file against include/bamm_em.h.
 //
-//   g++ -std=c++17 -fopenmp -I include integration/sharded_em.cpp -L bammmotif2_amd -lbamm_em
+//   g++ -std=c++17 -pthread -I include integration/sharded_em.cpp -L bammmotif2_amd -lbamm_em
 //
 // Reference reduction points this replaces: the OpenMP `reduction(+:llikelihood)` of EM::EStep
 // (src/refinement/EM.cpp:148), the CAS float adds into n_[K] of EM::MStep (EM.cpp:203-215,240) and the
 // serial sum over r_ of EM::optimize_q (EM.cpp:509-513).
-#include <omp.h>
-
 #include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bamm_em.h"
@@ -43,14 +42,21 @@ int sharded_em(const bamm_packed* packed, const std::vector<int>& devices, const
         if (bamm_em_create(ctx[r], shard[r], &p, vbg.data(), A.data(), v.data(), nullptr, &em[r])) return fail("EM");
         if (bamm_em_set_comm(em[r], comm[r])) return fail("EM communicator");
     }
-#pragma omp parallel num_threads((int)R)
-    {
-        const uint32_t r = (uint32_t)omp_get_thread_num();
-        // EM::optimize (EM.cpp:62-137): every pass = local E+M over the shard, ncclAllReduce(int64, sum) of
-        // [n_K | llh | sum_r | N] on this GPU's stream, the update.  The stopping rule reads the same numbers
-        // on every rank, so all of them leave the loop in the same pass.
-        if (bamm_em_optimize(em[r], &iterations[r])) err[r] = bamm_last_error();
-    }
+    // One std::thread per rank (an OpenMP team may come back smaller than asked for -- OMP_THREAD_LIMIT, dynamic
+    // teams -- and the missing ranks would leave the others waiting in the collective for ever).
+    // EM::optimize (EM.cpp:62-137): every pass = local E+M over the shard, ncclAllReduce(int64, sum) of
+    // [n_K | llh | sum_r | N] on this GPU's stream, the update.  The stopping rule reads the same numbers
+    // on every rank, so all of them leave the loop in the same pass.  A rank that fails alone aborts every
+    // communicator: its peers' collectives return BAMM_ERR_COMM instead of blocking.
+    std::vector<std::thread> team;
+    for (uint32_t r = 0; r < R; r++)
+        team.emplace_back([&, r] {
+            if (bamm_em_optimize(em[r], &iterations[r])) {
+                err[r] = bamm_last_error();
+                for (uint32_t o = 0; o < R; o++) bamm_comm_abort(comm[o]);
+            }
+        });
+    for (auto& t : team) t.join();
     int rc = (int)iterations[0];
     for (uint32_t r = 0; r < R; r++)
         if (!err[r].empty()) { fprintf(stderr, "GPU %d: %s\n", devices[r], err[r].c_str()); rc = -1; }

@@ -30,3 +30,40 @@ def test_two_ranks_one_gpu_match_single_rank():
     # same total work, same model trajectory: the log-likelihood after the last pass agrees
     assert j2["llh_last"] == pytest.approx(j1["llh_last"], rel=1e-6)
     assert j2["config"]["n_seqs"] == j1["config"]["n_seqs"]
+
+
+def _run_bench(*extra):
+    common = ["--nseq", "20000", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + list(extra), capture_output=True, text=True, cwd=ROOT)
+
+
+@pytest.mark.timeout(600)
+def test_inprocess_ranks_without_a_launcher():
+    """`python bench.py --gpus N` with no launcher runs N ranks inside the process (one context + host thread each,
+    the library's communicator).  On this 1-GPU box: (a) asking for 2 GPUs FAILS LOUDLY instead of printing a
+    1-GPU line, (b) the same code path with --local-ranks (2 contexts on device 0, host-staged sum) reproduces the
+    single-rank trajectory, (c) a 1-rank RCCL communicator through ncclCommInitAll does too."""
+    refused = _run_bench("--gpus", "2")
+    assert refused.returncode != 0
+    assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+    assert "only 1 HIP device" in refused.stderr
+
+    one = _run_bench()
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j1["metric"].endswith("20kx200bp k=2 W=20")
+
+    two = _run_bench("--gpus", "2", "--local-ranks")
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j2 = json.loads(lines[0])
+    assert j2["n_gpus"] == 2 and [r["rank"] for r in j2["ranks"]] == [0, 1] and all(r["world"] == 2 for r in j2["ranks"])
+    assert sum(r["n_seqs"] for r in j2["ranks"]) == 20000
+    assert j2["ranks_agree_bitwise"] is True
+    assert j2["llh_last"] == j1["llh_last"]                  # integer sums: the same bits whatever the number of ranks
+
+    rccl1 = _run_bench("--gpus", "1", "--local-ranks", "--force-dist")      # N = 1 through the in-process path, host-staged
+    assert rccl1.returncode == 0, rccl1.stderr[-3000:]
+    j3 = json.loads([l for l in rccl1.stdout.splitlines() if l.startswith("{")][-1])
+    assert j3["llh_last"] == j1["llh_last"]

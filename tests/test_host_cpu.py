@@ -170,9 +170,9 @@ def test_integration_sources_compile_against_the_headers(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cxx = shutil.which("g++") or "g++"
     obj = tmp_path / "sharded_em.o"
-    subprocess.check_call([cxx, "-std=c++17", "-fopenmp", "-Wall", "-Werror", "-fPIC", "-I", os.path.join(root, "include"), "-c",
+    subprocess.check_call([cxx, "-std=c++17", "-pthread", "-Wall", "-Werror", "-fPIC", "-I", os.path.join(root, "include"), "-c",
                            os.path.join(root, "integration", "sharded_em.cpp"), "-o", str(obj)])
-    subprocess.check_call([cxx, "-shared", "-fopenmp", str(obj), "-L", os.path.dirname(build.LIB), "-lbamm_em",
+    subprocess.check_call([cxx, "-shared", "-pthread", str(obj), "-L", os.path.dirname(build.LIB), "-lbamm_em",
                            "-Wl,--no-undefined", "-o", str(tmp_path / "libsharded.so")])
     ref = "/root/reference/src"
     if os.path.isdir(ref):
