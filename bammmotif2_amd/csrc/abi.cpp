@@ -386,7 +386,7 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
     if ((em->prm.K == 3u || (eb.layout & 8u)) && accum) {      // kernels whose fix lanes log their sums
         const size_t waves = (size_t)eb.blocks * (threads / 64u);
         const size_t cap = ((eb.count + waves - 1) / waves) * std::min<size_t>(64, (size_t)ga.g.Bv * ga.g.T);   // entries per wave
-        const size_t need = (waves * cap * 12 + 7) / 8;       // 12-byte entries, in 8-byte words
+        const size_t need = waves * cap;                      // 8-byte entries
         if (need > em->fix_log_words) {
             if (em->d_fix_log) { BAMM_HIP(hipStreamSynchronize(st)); BAMM_HIP(hipFree(em->d_fix_log)); em->d_fix_log = nullptr; em->fix_log_words = 0; }
             if (int rc = dev_alloc(&em->d_fix_log, need)) return rc;

@@ -162,7 +162,7 @@ struct GrpKernelArgs {
     const uint4* xrec;           // per sequence: x = lo | B<<12 (group ends lo..lo+B-1 need a virtual row), y/z/w = exact y of
                                  // the positions lo-G+1.., 7 bits each, 4 per word (the value Y = position before the sequence)
     // K = 3, accumulating pass: the non-zero sums the fix lanes took out of their virtual count rows, logged per
-    // wave (12-byte entries: grouped_kernel.h, GrpLogEntry) and folded into single-column bins in the block epilogue
+    // wave (8-byte entries: grouped_kernel.h, GrpLogEntry) and folded into single-column bins in the block epilogue
     unsigned long long* fix_log;
     uint32_t fix_log_cap;        // entries per wave: sequences of the wave x fix lanes (Bv * T)
     // fused update (update_kernel.h): the previous pass's model update runs in this launch's block prologue instead of

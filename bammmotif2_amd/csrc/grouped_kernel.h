@@ -60,25 +60,23 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Entry of the fix lanes' log (kernels with no LDS for the bins of their virtual rows): 12 bytes
-//   word 0 = sum[31:0];  words 1-2 = sum[40:32] | bin0 << 9 | bin1 << 22 | bin2 << 35 | bin3 << 48
-// sum: what ONE window added to a virtual count cell (< 2^41); bins: 13 bits each, kGrpNoBin = none.
-constexpr uint32_t kGrpNoBin = 0x1fffu;
-struct GrpLogEntry { uint32_t w[3]; };
-__device__ __forceinline__ void grp_log_store(GrpLogEntry* log, uint32_t idx, unsigned long long sum, unsigned long long bins52) {
-    const unsigned long long hi = (sum >> 32) | (bins52 << 9);
-    GrpLogEntry e;
-    e.w[0] = (uint32_t)sum; e.w[1] = (uint32_t)hi; e.w[2] = (uint32_t)(hi >> 32);
-    log[idx] = e;
+// Entry of the fix lanes' log (kernels with no LDS for the bins of their virtual rows): 8 bytes
+//   low word  = the sum as a float.  It is what ONE window added to a virtual count cell: to_fixed40_pre() of an
+//               fp32 responsibility, i.e. an integer of at most 24 significant bits -- the conversion to float and
+//               back is exact, so the epilogue folds the very integers the kernel without a log would have added
+//   high word = which single-column bins [j][y] it belongs to, as the kernel encodes them (group + the y of each of
+//               the group's columns; a y field >= Y means "no bin": neutral column, beyond the EM.cpp:167 edge, resident)
+// One 8-byte store per logging lane and sequence in the loop, one 8-byte load per entry in the block epilogue
+// (12-byte entries with explicit 13-bit bins until round 3: a third more bytes both ways).
+typedef unsigned long long GrpLogEntry;
+__device__ __forceinline__ void grp_log_store(GrpLogEntry* log, uint32_t idx, unsigned long long sum, uint32_t code) {
+    log[idx] = ((unsigned long long)code << 32) | (unsigned long long)__float_as_uint(__ull2float_rn(sum));
 }
-__device__ __forceinline__ void grp_log_load(const GrpLogEntry* log, uint32_t idx, unsigned long long& sum, unsigned long long& bins52) {
-    const uint32_t* p = log[idx].w;                          // written by this wave earlier in the launch: read from L2
-    const uint32_t w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t w2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long hi = ((unsigned long long)w2 << 32) | w1;
-    sum = ((hi & 0x1ffull) << 32) | w0;
-    bins52 = hi >> 9;
+__device__ __forceinline__ void grp_log_load(const GrpLogEntry* log, uint32_t idx, unsigned long long& sum, uint32_t& code) {
+    // written by this wave earlier in the launch: read from L2
+    const unsigned long long e = __hip_atomic_load(log + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sum = (unsigned long long)__uint_as_float((uint32_t)e);
+    code = (uint32_t)(e >> 32);
 }
 
 template <int I> struct IntC { static constexpr int value = I; };
@@ -655,14 +653,10 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     static_assert(!FIXG || G == 2, "two bins per entry");
                     const unsigned long long nzm = __ballot(acc != 0ull);
                     if (acc != 0ull) {
-                        unsigned long long bins = 0ull;
-#pragma unroll
-                        for (int c = 0; c < G; c++) {
-                            const int col = (int)(G * lane_t + c) - (int)delta;
-                            bins |= (unsigned long long)((yfix[c] != Y) ? (uint32_t)col * Y + yfix[c] : kGrpNoBin) << (13 * c);
-                        }
+                        // code: group (4 bits), then the y of its two columns (9 bits each, Y = 256 = no bin)
+                        const uint32_t code = lane_t | (yfix[0] << 4) | (yfix[G - 1] << 13);
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
-                        grp_log_store(my_log, nlog + rank, acc, bins);
+                        grp_log_store(my_log, nlog + rank, acc, code);
                     }
                     nlog += (uint32_t)__builtin_popcountll(nzm);
                 }
@@ -689,17 +683,20 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         // every lane takes entries of the wave's log, NB loads in flight
         constexpr uint32_t NB = 8;
         for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
-            unsigned long long acc[NB], bins[NB];
+            unsigned long long acc[NB];
+            uint32_t code[NB];
 #pragma unroll
             for (uint32_t u = 0; u < NB; u++)
-                grp_log_load(my_log, min(e0 + u * 64u + (uint32_t)lane, nlog - 1u), acc[u], bins[u]);
+                grp_log_load(my_log, min(e0 + u * 64u + (uint32_t)lane, nlog - 1u), acc[u], code[u]);
 #pragma unroll
             for (uint32_t u = 0; u < NB; u++) {
                 if (e0 + u * 64u + (uint32_t)lane < nlog) {
+                    const uint32_t tt = code[u] & 15u;
 #pragma unroll
                     for (int c = 0; c < G; c++) {
-                        const uint32_t bin = (uint32_t)(bins[u] >> (13 * c)) & kGrpNoBin;
-                        if (bin != kGrpNoBin) atomicAdd(&n1[bin], acc[u]);
+                        const uint32_t yc = (code[u] >> (4 + 9 * c)) & 511u;
+                        const int col = (int)(G * tt + c) - (int)delta;
+                        if (yc < Y) atomicAdd(&n1[(uint32_t)col * Y + yc], acc[u]);
                     }
                 }
             }

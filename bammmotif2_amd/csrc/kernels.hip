@@ -595,10 +595,23 @@ __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0,
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
         const uint64_t base = a.sv.pos_off[seq];
-        // the first entries are on their way while the sequence is decoded
-        const uint32_t e0 = (uint32_t)lane;
-        float r_nxt = e0 < nnz ? a.list_r[base + e0] : 0.0f;
-        uint32_t p_nxt = e0 < nnz ? (uint32_t)a.list_p[base + e0] : 0u;
+        // NP batches of 64 entries are requested at once and the next NP while those are walked: with one batch in
+        // flight the walk waited a full HBM round trip per 64 windows -- nothing to hide behind while the model is
+        // uninformative and a list holds every window (11.6 ms per slice at 1M x 1001 positions against 1.5 ms in
+        // steady state, profiles/r02_c4_kernel_stats.csv).  The first ones are on their way while the sequence is decoded.
+        constexpr uint32_t NP = 4;
+        float r_nxt[NP];
+        uint32_t p_nxt[NP];
+        auto request = [&](uint32_t e) {
+#pragma unroll
+            for (uint32_t u = 0; u < NP; u++) {
+                const uint32_t idx = e + u * 64u;
+                const bool ok = idx < nnz;
+                r_nxt[u] = ok ? a.list_r[base + idx] : 0.0f;
+                p_nxt[u] = ok ? (uint32_t)a.list_p[base + idx] : 0u;
+            }
+        };
+        request((uint32_t)lane);
         uint32_t y[M];
         decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);          // EM.cpp:236: positions >= LW1 take no part (row Y)
 #pragma unroll
@@ -606,21 +619,27 @@ __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t e = e0; e < nnz; e += 64u) {
-            const float r = r_nxt;
-            const uint32_t p = p_nxt;
-            if (e + 64u < nnz) { r_nxt = a.list_r[base + e + 64u]; p_nxt = (uint32_t)a.list_p[base + e + 64u]; }
-            const unsigned long long Fe = to_fixed40(r * a.fix_scale);
-            uint32_t q = p + 1u - W + j0;                             // position of the window's column j0
-            unsigned long long* ncol = n_lds + copy;
-            // eight columns' y first, then their adds: one LDS round trip per batch (row Y is a dump: no check)
-            for (uint32_t jb = j0; jb < j1; jb += 8u, q += 8u, ncol += 8u * cstride) {
-                uint32_t yy[8];
+        for (uint32_t e = (uint32_t)lane; e < nnz; e += 64u * NP) {
+            float r[NP];
+            uint32_t p[NP];
 #pragma unroll
-                for (int u = 0; u < 8; u++) yy[u] = (jb + u < j1) ? (uint32_t)ybuf[q + u] : Y;
+            for (uint32_t u = 0; u < NP; u++) { r[u] = r_nxt[u]; p[u] = p_nxt[u]; }
+            if (e - (uint32_t)lane + 64u * NP < nnz) request(e + 64u * NP);      // wave-uniform
 #pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (jb + u < j1) atomicAdd(&ncol[(size_t)u * cstride + (yy[u] << logC)], Fe);
+            for (uint32_t u = 0; u < NP; u++) {
+                if (e + u * 64u >= nnz) continue;
+                const unsigned long long Fe = to_fixed40(r[u] * a.fix_scale);
+                uint32_t q = p[u] + 1u - W + j0;                          // position of the window's column j0
+                unsigned long long* ncol = n_lds + copy;
+                // eight columns' y first, then their adds: one LDS round trip per batch (row Y is a dump: no check)
+                for (uint32_t jb = j0; jb < j1; jb += 8u, q += 8u, ncol += 8u * cstride) {
+                    uint32_t yy[8];
+#pragma unroll
+                    for (int c = 0; c < 8; c++) yy[c] = (jb + c < j1) ? (uint32_t)ybuf[q + c] : Y;
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+                        if (jb + c < j1) atomicAdd(&ncol[(size_t)c * cstride + (yy[c] << logC)], Fe);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();                              // ybuf is rewritten for the next sequence

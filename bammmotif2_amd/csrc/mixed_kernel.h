@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     for (int m = 0; m < M; m++) pos_m[m] = 0.0f;
 #pragma unroll
     for (int m = 0; m < (kCacheSpec ? M : 1); m++) spec[m] = -1;
-    [[maybe_unused]] GrpLogEntry* my_log = nullptr;          // the fix lanes' non-zero sums (12-byte entries)
+    [[maybe_unused]] GrpLogEntry* my_log = nullptr;          // the fix lanes' non-zero sums (8-byte entries)
     [[maybe_unused]] uint32_t nlog = 0;
     if constexpr (ACCUM)
         my_log = reinterpret_cast<GrpLogEntry*>(ga.fix_log) + (size_t)(blockIdx.x * WAVES + wave) * ga.fix_log_cap;
@@ -381,21 +381,25 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                 acc = *cell;
                 *cell = 0ull;
             }
-            unsigned long long bins = 0ull;
+            // code: group (3 bits), then the y of its up to four columns (7 bits each, >= Y = nothing to log: neutral,
+            // beyond the edge, or a resident bin, which takes the sum here)
+            uint32_t code = lane_t;
+            bool any = false;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t bin = ((uint32_t)c < lane_G && yfix[c] != Y) ? (lane_col0 + (uint32_t)c) * Y + yfix[c] : kGrpNoBin;
-                if (bin != kGrpNoBin && lane_col0 + (uint32_t)c < n1c) {      // a resident bin: added here, not logged
-                    if (acc != 0ull) atomicAdd(&n1p[bin], acc);
-                    bin = kGrpNoBin;
+                uint32_t yc = ((uint32_t)c < lane_G) ? yfix[c] : Y;
+                if (yc != Y && lane_col0 + (uint32_t)c < n1c) {               // a resident bin: added here, not logged
+                    if (acc != 0ull) atomicAdd(&n1p[(lane_col0 + (uint32_t)c) * Y + yc], acc);
+                    yc = Y;
                 }
-                bins |= (unsigned long long)bin << (13 * c);
+                any = any || yc != Y;
+                code |= yc << (3 + 7 * c);
             }
-            if (bins == 0xfffffffffffffull) acc = 0ull;      // nothing left to log (also: a group wholly beyond the edge)
+            if (!any) acc = 0ull;                                // nothing left to log (also: a group wholly beyond the edge)
             const unsigned long long nzm = __ballot(acc != 0ull);
             if (acc != 0ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
-                grp_log_store(my_log, nlog + rank, acc, bins);
+                grp_log_store(my_log, nlog + rank, acc, code);
             }
             nlog += (uint32_t)__builtin_popcountll(nzm);
             wave_lds_sync();
@@ -418,17 +422,20 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         __syncthreads();
         constexpr uint32_t NB = 8;
         for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
-            unsigned long long acc[NB], bins[NB];
+            unsigned long long acc[NB];
+            uint32_t code[NB];
 #pragma unroll
             for (uint32_t u = 0; u < NB; u++)
-                grp_log_load(my_log, min(e0 + u * 64u + (uint32_t)lane, nlog - 1u), acc[u], bins[u]);
+                grp_log_load(my_log, min(e0 + u * 64u + (uint32_t)lane, nlog - 1u), acc[u], code[u]);
 #pragma unroll
             for (uint32_t u = 0; u < NB; u++) {
                 if (e0 + u * 64u + (uint32_t)lane < nlog) {
+                    const uint32_t tt = code[u] & 7u;
+                    const uint32_t col0 = tt >= B ? 3u * B + 4u * (tt - B) : 3u * tt;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        const uint32_t bin = (uint32_t)(bins[u] >> (13 * c)) & kGrpNoBin;
-                        if (bin != kGrpNoBin) atomicAdd(&n1[bin], acc[u]);
+                        const uint32_t yc = (code[u] >> (3 + 7 * c)) & 127u;
+                        if (yc < Y) atomicAdd(&n1[(col0 + (uint32_t)c) * Y + yc], acc[u]);
                     }
                 }
             }

@@ -88,3 +88,73 @@ def test_full_size_invariants(gpu_ctx):
     # (Sequence.cpp:34-41 / EM.cpp:232), so a context can be rarer at column j-1 than its continuations at j.
     assert np.all(v > 0) and np.all(np.isfinite(v))
     em.close(); whole.close()
+
+
+@pytest.mark.timeout(1200)
+def test_full_size_invariants_c4(gpu_ctx):
+    """BASELINE config 4 at full size (1M x 500 bp both strands, W = 30, k = 4: the column-sliced path, E pass with
+    compacted lists + k_m_list slices), from the seed (pass 1: every window is listed, the longest lists) and after 12
+    passes: mass conservation, two half shards == the whole set in int64, bitwise repeat, marginals.  EM.cpp:139-259."""
+    N, L0, W, K = 1_000_000, 500, 30, 4
+    pwm = synth.make_pwm(W, 1234)
+    codes, off = synth.make_sequences(N, L0, pwm, 1234)
+    pk = bm.PackedSeqs.from_codes(codes, off, False, seed=42)
+    del codes
+    vbg = pk.bg_model(2, np.array([1, 10, 10], np.float32))
+    A = synth.alpha_matrix(synth.default_alpha(K), W)
+    v0 = synth.bamm_from_pwm((0.7 * pwm + 0.075).astype(np.float32), K)
+    cells = 4 ** (K + 1) * W
+
+    whole = bm.SeqSet(gpu_ctx, pk)
+    em = bm.EM(gpu_ctx, whole, K, W, vbg, A, v0, 0.3, max_iterations=40)
+    g, o, launches = em.plan()
+    assert g == 0 and o == N                                  # the sliced path, one length class
+
+    def check(em, v_in, q_in, label):
+        em.accumulate()
+        buf = read_buffer(em, gpu_ctx)
+        nK, llh, sum_r, n_seq = decode(buf, cells)
+        nK = nK.reshape(4 ** (K + 1), W)
+        assert n_seq == N, label
+        assert nK[:, 0].sum() == pytest.approx(sum_r, rel=2e-6), label          # mass conservation
+        assert 0.05 * N < sum_r < 0.95 * N and np.isfinite(llh), label
+        col = nK.sum(axis=0)
+        assert np.all(np.diff(col) <= 1e-6 * col[0]), label                    # later columns lose truncated windows only
+        em.accumulate()
+        assert np.array_equal(read_buffer(em, gpu_ctx), buf), label            # bitwise reproducible
+        parts = []
+        for r in range(2):
+            b, e = pk.shard_range(W, r, 2)
+            ss = bm.SeqSet(gpu_ctx, pk, b, e)
+            h = bm.EM(gpu_ctx, ss, K, W, vbg, A, v_in, q_in, n_seqs_bound=N)
+            h.accumulate()
+            parts.append(read_buffer(h, gpu_ctx))
+            h.close(); ss.close()
+        assert np.array_equal((parts[0] + parts[1])[:cells], buf[:cells]), label   # integer sums of the same addends
+        assert (parts[0] + parts[1])[cells + 2] == buf[cells + 2], label
+        np.testing.assert_allclose((parts[0] + parts[1])[cells:cells + 2], buf[cells:cells + 2], rtol=1e-9)
+        return buf
+
+    check(em, v0, 0.3, "from the seed")                       # pass 1: the longest lists
+    # the dense walk (round-1 path: all responsibilities through HBM, no lists) adds the same integers
+    gpu_ctx.set_tuning(e_list=0)
+    try:
+        dense = bm.EM(gpu_ctx, whole, K, W, vbg, A, v0, 0.3, max_iterations=4)
+    finally:
+        gpu_ctx.set_tuning(e_list=1)
+    dense.accumulate(); em.accumulate()
+    assert np.array_equal(read_buffer(dense, gpu_ctx)[:cells], read_buffer(em, gpu_ctx)[:cells])
+    dense.close()
+    em.update()
+    em.iterate(11)
+    v12, q12 = em.getV(), em.getQ()
+    check(em, v12, q12, "after 12 passes")
+    em.update()
+    v, n = em.getV(), em.getCounts()
+    np.testing.assert_allclose(v[:4 * W].reshape(4, W).sum(axis=0), 1.0, atol=3e-7)   # Motif.h:110-118
+    for k in range(K, 0, -1):                                                          # EM.cpp:247-254
+        hi = n[bm.v_offset(k, W):bm.v_offset(k + 1, W)].reshape(4, 4 ** k, W).astype(np.float64).sum(axis=0)
+        lo = n[bm.v_offset(k - 1, W):bm.v_offset(k, W)].reshape(4 ** k, W)
+        np.testing.assert_allclose(lo, hi, rtol=3e-7)
+    assert np.all(v > 0) and np.all(np.isfinite(v))
+    em.close(); whole.close()
