@@ -42,7 +42,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void
 
 # every symbol include/bamm_em.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "bamm_last_error", "bamm_version", "bamm_pack_kmers", "bamm_pack_kmer_ptrs", "bamm_pack_codes",
+    "bamm_last_error", "bamm_version", "bamm_pack_kmers", "bamm_pack_kmer_ptrs", "bamm_pack_codes", "bamm_pack_codes_seeded",
     "bamm_unpack_y", "bamm_packed_free", "bamm_shard_range", "bamm_ctx_create", "bamm_ctx_destroy",
     "bamm_ctx_sync", "bamm_ctx_device_name", "bamm_ctx_set_launch", "bamm_ctx_set_tuning", "bamm_seqs_upload",
     "bamm_seqs_destroy", "bamm_seqs_info", "bamm_em_default_params", "bamm_em_create",
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
     L.bamm_pack_kmers.argtypes = [u64p, u64p, u64, P(P(Packed))]
     L.bamm_pack_kmer_ptrs.argtypes = [P(C.c_void_p), u64p, u64, P(P(Packed))]
     L.bamm_pack_codes.argtypes = [u8p, u64p, u64, i, P(P(Packed))]
+    L.bamm_pack_codes_seeded.argtypes = [u8p, u64p, u64, i, u32, P(P(Packed))]
     L.bamm_unpack_y.argtypes = [P(Packed), u32, u32p]
     L.bamm_packed_free.argtypes = [P(Packed)]
     L.bamm_packed_free.restype = None

@@ -16,6 +16,7 @@
 #include <new>
 
 #include "common.h"
+#include "glibc_rand.h"
 
 namespace bamm {
 
@@ -199,8 +200,21 @@ int bamm_pack_kmer_ptrs(const uint64_t* const* kmer_ptrs, const uint64_t* L, uin
 // (78), so an N of the forward strand is NOT randomised on the reverse strand but enters the
 // k-mer arithmetic as the digit 77; kept as is.  Only the 10 positions behind such a byte need
 // the term-by-term path, everything else is a rolling 22-bit window.
+static int pack_codes_impl(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand, bool seeded,
+                           uint32_t seed, bamm_packed** out);
+
 int bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
                     bamm_packed** out) {
+    return pack_codes_impl(codes, off, n_seqs, single_strand, false, 0u, out);
+}
+
+int bamm_pack_codes_seeded(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand, uint32_t seed,
+                           bamm_packed** out) {
+    return pack_codes_impl(codes, off, n_seqs, single_strand, true, seed, out);
+}
+
+static int pack_codes_impl(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand, bool seeded,
+                           uint32_t seed, bamm_packed** out) {
     if (!out || (n_seqs && (!codes || !off))) {
         set_error("bamm_pack_codes: null argument");
         return BAMM_ERR_ARG;
@@ -234,7 +248,23 @@ int bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, 
     });
     for (uint64_t n = 0; n < n_seqs; n++) doff[n + 1] += doff[n];
     std::vector<uint8_t> draws(doff[n_seqs] ? doff[n_seqs] : 1);
-    for (uint64_t d = 0; d < doff[n_seqs]; d++) draws[d] = (uint8_t)(rand() % 4);
+    // ... unless the caller names the seed the stream starts from (bamm_pack_codes_seeded: the reference seeds once,
+    // mainBaMM.cpp:22, and reads its positives first): glibc's generator is restated (glibc_rand.h), checked against
+    // the running libc, and every host thread jumps to its share of the draws -- 11 M draws at 1 M double-stranded
+    // sequences were a tenth of a second in one thread.  libc's own stream is left freshly seeded.
+    GlibcRandStream gen;
+    if (seeded) gen.start(seed);
+    if (seeded && gen.fast) {
+        const uint64_t D = doff[n_seqs];
+        parallel_ranges(D, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(T, D / 65536 + 1)), [&](uint32_t, uint64_t d0, uint64_t d1) {
+            GlibcRandStream mine = gen;
+            mine.jump(d0);
+            for (uint64_t d = d0; d < d1; d++) draws[d] = (uint8_t)(mine.next_fast() % 4);
+        });
+    } else {
+        if (seeded) srand(seed);
+        for (uint64_t d = 0; d < doff[n_seqs]; d++) draws[d] = (uint8_t)(rand() % 4);
+    }
 
     struct Local { std::vector<uint32_t> epos, ekmer, eclean; uint64_t n0 = 0, n1 = 0; };
     std::vector<Local> loc(T);

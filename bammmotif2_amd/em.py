@@ -63,11 +63,13 @@ class PackedSeqs:
     def from_codes(cls, codes, off, single_strand: bool = False, seed: Optional[int] = 42) -> "PackedSeqs":
         lib = abi.load()
         off = _u64(off)
-        if seed is not None:
-            libc_srand(seed)
         out = C.POINTER(abi.Packed)()
-        check(lib.bamm_pack_codes(np.ascontiguousarray(codes, np.uint8), off, len(off) - 1,
-                                  int(single_strand), C.byref(out)))
+        if seed is not None:      # the libc stream starts at srand(seed): the draws may be taken on all host threads
+            check(lib.bamm_pack_codes_seeded(np.ascontiguousarray(codes, np.uint8), off, len(off) - 1,
+                                             int(single_strand), seed, C.byref(out)))
+        else:                     # wherever the caller's libc stream stands
+            check(lib.bamm_pack_codes(np.ascontiguousarray(codes, np.uint8), off, len(off) - 1,
+                                      int(single_strand), C.byref(out)))
         return cls(out)
 
     @property

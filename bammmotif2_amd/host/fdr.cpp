@@ -1,17 +1,21 @@
 // Evaluation side of the BaMMmotif drop-in: negative-set sampler, FDR / PR statistics and window
 // p-values.  Restated from the reference lines cited in bamm_host.h; fp32 expression order kept.
 #include <omp.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <charconv>
 #include <cassert>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <iomanip>
+#include <thread>
 
 #include "bamm_host.h"
+#include "../csrc/glibc_rand.h"
 
 namespace bammhost {
 
@@ -35,12 +39,19 @@ struct NegSampler {
 
     void kmer_frequency(const uint32_t* y_s, const uint64_t* off, size_t n_seqs) {   // :63-110
         std::fill(n.begin(), n.end(), 0);
-        for (size_t i = 0; i < n_seqs; i++) {
+        // integer counts: a histogram per host thread, summed -- the same numbers however the sequences are cut
+        const int T = std::max(1, std::min<int>(host_parallelism(), (int)(n_seqs / 4096 + 1)));
+        std::vector<std::vector<size_t>> part((size_t)T, std::vector<size_t>(n.size(), 0));
+#pragma omp parallel for schedule(static) num_threads(T)
+        for (long i = 0; i < (long)n_seqs; i++) {
+            std::vector<size_t>& mine = part[(size_t)omp_get_thread_num()];
             const size_t L = off[i + 1] - off[i];
             const uint32_t* km = y_s + off[i];
             for (uint32_t k = 0; k <= s; k++)
-                for (size_t j = k; j < L; j++) n[bgoff(k) + km[j] % ipow4(k + 1)]++;
+                for (size_t j = k; j < L; j++) mine[bgoff(k) + km[j] % ipow4(k + 1)]++;
         }
+        for (auto& pt : part)
+            for (size_t c = 0; c < n.size(); c++) n[c] += pt[c];
         size_t norm = 0;
         for (size_t y = 0; y < 4; y++) norm += n[y];
         float sum = 0.0f;
@@ -104,49 +115,11 @@ struct NegSampler {
         }
     }
 
-    // libc's rand() behind a per-call lock costs more than the sampling itself (400 M draws for
-    // 2 M negatives).  glibc's default generator (TYPE_3 additive feedback, x[i] = x[i-3] + x[i-31],
-    // seeded by the Park-Miller LCG, 310 outputs discarded) is restated here and used only after
-    // its first draws have been checked against srand(42)/rand() of the running libc; otherwise
-    // the sampler stays on rand().  Every later rand() consumer reseeds (FDR.cpp:153).
-    struct Stream {
-        uint32_t r[34];
-        int i = 0;
-        bool fast = false;
-        void seed(uint32_t sd) {
-            int32_t x[344 + 34];
-            x[0] = (int32_t)sd;
-            for (int k = 1; k < 31; k++) {
-                int64_t w = (16807LL * x[k - 1]) % 2147483647LL;
-                if (w < 0) w += 2147483647LL;
-                x[k] = (int32_t)w;
-            }
-            for (int k = 31; k < 34; k++) x[k] = x[k - 31];
-            for (int k = 34; k < 344; k++) x[k] = (int32_t)((uint32_t)x[k - 31] + (uint32_t)x[k - 3]);
-            for (int k = 0; k < 34; k++) r[k] = (uint32_t)x[344 - 34 + k];   // the last 34 words are the state
-            i = 0;
-        }
-        inline int next_fast() {                   // o[k] = o[k-31] + o[k-3] over a ring of 34
-            int a = i + 3, b = i + 31;
-            a -= a >= 34 ? 34 : 0;
-            b -= b >= 34 ? 34 : 0;
-            const uint32_t v = r[a] + r[b];
-            r[i] = v;
-            i = i + 1 == 34 ? 0 : i + 1;
-            return (int)(v >> 1);
-        }
-        inline int next() { return fast ? next_fast() : rand(); }
-        void start() {                             // srand(42) happened just before
-            seed(42u);
-            fast = true;
-            int mine[8];
-            for (int k = 0; k < 8; k++) mine[k] = next_fast();
-            srand(42);
-            for (int k = 0; k < 8; k++) if (rand() != mine[k]) fast = false;
-            srand(42);
-            seed(42u);
-        }
-    } stream;
+    // glibc's rand() restated (csrc/glibc_rand.h): used only after its first draws have been checked against
+    // srand(42)/rand() of the running libc, otherwise the sampler stays on rand(); jump(n) lets every host thread
+    // start in the middle of the one stream.  Every later rand() consumer reseeds (FDR.cpp:153).
+    bamm::GlibcRandStream stream;
+
 
     // F sequences of the same length from the same tables, drawn one after the other from the
     // stream (sequence f consumes draws [f*L, (f+1)*L)) but advanced position by position together:
@@ -217,8 +190,25 @@ struct NegSampler {
 
 }  // namespace
 
+// Host threads for work whose result does not depend on how it is cut (this sampler, packing, sorts): every core
+// the process may use -- the affinity mask capped by the cgroup CPU quota -- whatever --threads says (the
+// reference's flag sized its OpenMP EM loops, Global.cpp:331-333; a container may show 256 CPUs and grant 16).
+int host_parallelism() {
+    static const int n = [] {
+        int c = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) c = CPU_COUNT(&set);
+        std::ifstream f("/sys/fs/cgroup/cpu.max");
+        std::string quota;
+        double period = 0;
+        if (f >> quota >> period && quota != "max" && period > 0) c = std::min(c, std::max(1, (int)(std::stod(quota) / period + 0.5)));
+        return std::max(1, std::min(c, 64));
+    }();
+    return n;
+}
+
 int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, uint32_t s_order, size_t m_fold,
-                     bool generic, std::vector<uint8_t>& codes_out, std::vector<uint64_t>& off_out, std::string& err) {
+                     bool generic, ByteVec& codes_out, std::vector<uint64_t>& off_out, std::string& err) {
     if (!generic && s_order != 2) {
         err = "Error: the sequence-specific negative sampler is written for -s 2 (SeqGenerator.cpp:112-186); use --genericNeg";
         return 1;
@@ -243,7 +233,7 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
     // every range start, then the ranges are sampled on separate threads -- same draws, same negatives.
     std::vector<uint64_t> d0(n_seqs + 1, 0);
     for (size_t i = 0; i < n_seqs; i++) d0[i + 1] = d0[i] + (uint64_t)(off[i + 1] - off[i]) * m_fold;
-    const int threads = omp_get_max_threads();
+    const int threads = host_parallelism();
     if (g.stream.fast && threads > 1 && n_seqs >= 256) {
         const size_t P = (size_t)threads;
         std::vector<size_t> first(P + 1, n_seqs);
@@ -253,15 +243,13 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
         for (size_t p = 1; p <= P; p++) first[p] = std::max(first[p], first[p - 1]);
         first[P] = n_seqs;
         std::vector<decltype(g.stream)> start(P, g.stream);
-        for (size_t p = 0; p < P; p++) {
-            start[p] = g.stream;
-            for (uint64_t k = d0[first[p + 1]] - d0[first[p]]; k > 0; k--) (void)g.stream.next_fast();
-        }
-        codes_out.assign((size_t)d0[n_seqs], 0);
+        for (size_t p = 0; p < P; p++) start[p].jump(d0[first[p]]);     // nobody steps through the stream: Stream::jump
+        codes_out.resize((size_t)d0[n_seqs]);                 // every byte is written by the range that owns it
         off_out.resize(n_seqs * m_fold + 1);
-        for (size_t i = 0; i < n_seqs; i++)
-            for (size_t f = 0; f < m_fold; f++) off_out[i * m_fold + f + 1] = d0[i] + (off[i + 1] - off[i]) * (f + 1);
-#pragma omp parallel for schedule(static, 1)
+#pragma omp parallel for schedule(static) num_threads((int)P)
+        for (long i = 0; i < (long)n_seqs; i++)
+            for (size_t f = 0; f < m_fold; f++) off_out[(size_t)i * m_fold + f + 1] = d0[i] + (off[i + 1] - off[i]) * (f + 1);
+#pragma omp parallel for schedule(static, 1) num_threads((int)P)
         for (long p = 0; p < (long)P; p++) {
             NegSampler w = g;                                  // own tables (rescale writes them), own stream position
             w.stream = start[(size_t)p];
@@ -281,11 +269,33 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
         // only depend on the positive sequence, so once per sequence gives the same tables
         if (!generic) g.rescale(y_s + off[i], L);
         const size_t o = codes_out.size();
-        codes_out.resize(o + L * m_fold, 0);
+        codes_out.resize(o + L * m_fold);
         g.draw_many(L, m_fold, codes_out.data() + o, rnd, ctx);
         for (size_t f = 0; f < m_fold; f++) off_out.push_back(o + L * (f + 1));
     }
     return 0;
+}
+
+// Scores in the reference's order (std::sort with greater / less, FDR.cpp:158-159,203-204,288-289) on every granted core:
+// sorted runs per thread, merged pairwise.  A sorted sequence of floats is the same whatever produced it (equal
+// scores are indistinguishable -- the rare +0 / -0 pair aside, which no statistic tells apart).
+void sort_scores(std::vector<float>& v, bool descending) {
+    const size_t n = v.size();
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)host_parallelism(), n / 100000 + 1));
+    auto less = [descending](float a, float b) { return descending ? a > b : a < b; };
+    if (T == 1) { std::sort(v.begin(), v.end(), less); return; }
+    std::vector<size_t> cut(T + 1);
+    for (size_t t = 0; t <= T; t++) cut[t] = n * t / T;
+#pragma omp parallel for schedule(static, 1) num_threads((int)T)
+    for (long t = 0; t < (long)T; t++) std::sort(v.begin() + cut[t], v.begin() + cut[t + 1], less);
+    for (size_t w = 1; w < T; w *= 2) {                   // runs of w ranges -> runs of 2w
+        const long pairs = (long)((T + 2 * w - 1) / (2 * w));
+#pragma omp parallel for schedule(static, 1) num_threads((int)T)
+        for (long p = 0; p < pairs; p++) {
+            const size_t a = (size_t)p * 2 * w, m = std::min(T, a + w), b = std::min(T, a + 2 * w);
+            if (m < b) std::inplace_merge(v.begin() + cut[a], v.begin() + cut[m], v.begin() + cut[b], less);
+        }
+    }
 }
 
 void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::vector<float> posAll,
@@ -295,8 +305,8 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
     const float mFold = (float)negN / (float)posN;
     srand(42);                                         // FDR.cpp:153
     if (mops) {                                        // FDR.cpp:156-196
-        std::sort(posAll.begin(), posAll.end(), std::greater<float>());
-        std::sort(negAll.begin(), negAll.end(), std::greater<float>());
+        sort_scores(posAll, true);
+        sort_scores(negAll, true);
         size_t ip = 0, in = 0;
         float E_TP = 0.0f;
         size_t idx_max = posN + negN;
@@ -318,8 +328,8 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
         r.occ_mult = E_TP / (float)posN;
     }
     if (zoops) {                                       // FDR.cpp:199-275
-        std::sort(posMax.begin(), posMax.end(), std::greater<float>());
-        std::sort(negMax.begin(), negMax.end(), std::greater<float>());
+        sort_scores(posMax, true);
+        sort_scores(negMax, true);
         size_t ip = 0, in = 0, min_idx_pos = 0;
         const size_t posN_est = static_cast<size_t>(q * (float)posN);
         // The strided CV split (FDR.cpp:49-60) drops the last posN % cvFold positives and keeps
@@ -335,7 +345,14 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
         float Sl = 0.f;
         auto P = [&](size_t i) { return i < nP ? posMax[i] : -INFINITY; };
         auto N = [&](size_t i) { return i < nN ? negMax[i] : -INFINITY; };
-        for (size_t i = 0; i < nP + nN; i++) {
+        // the walk itself is a serial chain (which list the next score comes from, one rand() per tie): it only
+        // records, per step, the score and the two counts; everything computed FROM those -- the p-value with its two
+        // binary searches, FDR, recall: most of the time at 2.2 M steps -- is then filled in on every granted core by
+        // the same expressions
+        const size_t steps = nP + nN;
+        std::vector<float> step_score(steps);
+        std::vector<uint32_t> step_ip(steps), step_in(steps);
+        for (size_t i = 0; i < steps; i++) {
             if ((P(ip) > N(in) || ip == 0 || in >= nN) && ip < nP) {
                 Sl = posMax[ip];
                 ip++;
@@ -346,9 +363,18 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
                 Sl = negMax[in];                                             // in < nN: both lists cannot be exhausted inside the walk
                 in++;
             }
-            const float TP = (float)ip, FP = (float)in / mFold;
-            r.zoops_tp.push_back(TP);
-            r.zoops_fp.push_back(FP);
+            step_score[i] = Sl; step_ip[i] = (uint32_t)ip; step_in[i] = (uint32_t)in;
+            if (ip == posN_est) min_idx_pos = i;
+        }
+        r.zoops_tp.resize(steps); r.zoops_fp.resize(steps); r.pn_pvalue.resize(steps);
+        r.zoops_fdr.resize(steps); r.zoops_rec.resize(steps);
+#pragma omp parallel for schedule(static) num_threads(host_parallelism())
+        for (long ii = 0; ii < (long)steps; ii++) {
+            const size_t i = (size_t)ii, in = step_in[i];
+            const float Sl = step_score[i];
+            const float TP = (float)step_ip[i], FP = (float)in / mFold;
+            r.zoops_tp[i] = TP;
+            r.zoops_fp[i] = FP;
             float p_value;
             if (nN && Sl <= negMax[n_top]) {
                 auto lo = std::lower_bound(negMax.begin(), negMax.end(), Sl, std::greater<float>());
@@ -363,17 +389,16 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
             } else {
                 p_value = 1.0f;                                              // no negative score at all
             }
-            r.pn_pvalue.push_back(p_value);
-            if (ip == posN_est) min_idx_pos = i;
-            r.zoops_fdr.push_back(FP / (TP + FP));
-            r.zoops_rec.push_back(TP / (float)posN);
+            r.pn_pvalue[i] = p_value;
+            r.zoops_fdr[i] = FP / (TP + FP);
+            r.zoops_rec[i] = TP / (float)posN;
         }
         r.occ_frac = r.zoops_fp.empty() ? 1.0f : 1.0f - r.zoops_fp[min_idx_pos] / (float)posN;
     }
     if (with_pvalues) {                                // FDR.cpp:278-333
         auto pv = [](std::vector<float>& pos, std::vector<float>& neg, std::vector<float>& out) {
-            std::sort(neg.begin(), neg.end(), std::less<float>());
-            std::sort(pos.begin(), pos.end(), std::less<float>());
+            sort_scores(neg, false);
+            sort_scores(pos, false);
             for (size_t i = 0; i < pos.size(); i++) {
                 const size_t low = std::lower_bound(neg.begin(), neg.end(), pos[i]) - neg.begin();
                 const size_t up = std::upper_bound(neg.begin(), neg.end(), pos[i]) - neg.begin();
@@ -408,6 +433,25 @@ struct RowWriter {
     void maybe_flush(std::ofstream& f) { if (buf.size() > (1 << 20) - 256) flush_to(f); }
 };
 
+// rows [0, n) formatted by row(w, i) on every granted core -- rounds of one chunk per thread, the chunks written in
+// order: the same bytes as one writer walking all rows (formatting 11 M numbers is most of what the files cost), and
+// the threads' buffers are reused from round to round (fresh pages are slow to come by in a container)
+template <class Row>
+void write_rows(std::ofstream& f, size_t n, int precision, Row&& row) {
+    constexpr size_t kChunk = 16384;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_parallelism(), n / kChunk + 1));
+    std::vector<RowWriter> part((size_t)T, RowWriter(precision));
+    for (size_t base = 0; base < n; base += kChunk * (size_t)T) {
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int t = 0; t < T; t++) {
+            RowWriter& w = part[(size_t)t];
+            const size_t a = std::min(n, base + kChunk * (size_t)t), b = std::min(n, a + kChunk);
+            for (size_t i = a; i < b; i++) row(w, i);
+        }
+        for (auto& w : part) w.flush_to(f);
+    }
+}
+
 }  // namespace
 
 int fdr_write(const std::string& dir, const std::string& basename, const FdrResult& r, size_t posN, size_t negN,
@@ -419,38 +463,28 @@ int fdr_write(const std::string& dir, const std::string& basename, const FdrResu
             if (!f.is_open()) { err = "Error: Cannot write into output directory: " + dir; return 1; }
             f << "TP" << '\t' << "FP" << '\t' << "FDR" << '\t' << "Recall" << '\t' << "p-value" << '\t'
               << (float)negN / (float)posN << '\t' << r.occ_frac << std::endl;
-            RowWriter w;
-            for (size_t i = 0; i < r.zoops_fdr.size(); i++) {
+            write_rows(f, r.zoops_fdr.size(), 6, [&](RowWriter& w, size_t i) {
                 w.num(r.zoops_tp[i]); w.tab(); w.num(r.zoops_fp[i]); w.tab(); w.num(r.zoops_fdr[i]); w.tab();
                 w.num(r.zoops_rec[i]); w.tab(); w.num(r.pn_pvalue[i]); w.tab(); w.nl();
-                w.maybe_flush(f);
-            }
-            w.flush_to(f);
+            });
         }
         if (mops) {                                    // FDR.cpp:409-425
             std::ofstream f(opath + ".mops.stats");
             f << "TP" << '\t' << "FP" << '\t' << "FDR" << '\t' << "Recall" << '\t' << r.occ_mult << std::endl;
-            RowWriter w;
-            for (size_t i = 0; i < r.mops_fdr.size(); i++) {
+            write_rows(f, r.mops_fdr.size(), 6, [&](RowWriter& w, size_t i) {
                 w.num(r.mops_tp[i]); w.tab(); w.num(r.mops_fp[i]); w.tab(); w.num(r.mops_fdr[i]); w.tab();
                 w.num(r.mops_rec[i]); w.tab(); w.nl();
-                w.maybe_flush(f);
-            }
-            w.flush_to(f);
+            });
         }
     }
     if (save_pvalues) {                                // FDR.cpp:428-449, setprecision(3)
         if (zoops) {
             std::ofstream f(opath + ".zoops.pvalues");
-            RowWriter w(3);
-            for (float p : r.zoops_pvalue) { w.num(p); w.nl(); w.maybe_flush(f); }
-            w.flush_to(f);
+            write_rows(f, r.zoops_pvalue.size(), 3, [&](RowWriter& w, size_t i) { w.num(r.zoops_pvalue[i]); w.nl(); });
         }
         if (mops) {
             std::ofstream f(opath + ".mops.pvalues");
-            RowWriter w(3);
-            for (float p : r.mops_pvalue) { w.num(p); w.nl(); w.maybe_flush(f); }
-            w.flush_to(f);
+            write_rows(f, r.mops_pvalue.size(), 3, [&](RowWriter& w, size_t i) { w.num(r.mops_pvalue[i]); w.nl(); });
         }
     }
     return 0;
@@ -465,8 +499,7 @@ int fdr_logodds_write(const std::string& dir, const std::string& basename, std::
                       std::vector<float> posAll, std::vector<float> negAll, size_t posN, size_t negN, bool mops, bool zoops,
                       bool ascending, std::string& err) {
     auto order = [&](std::vector<float>& v) {
-        if (ascending) std::sort(v.begin(), v.end(), std::less<float>());
-        else std::sort(v.begin(), v.end(), std::greater<float>());
+        sort_scores(v, !ascending);
     };
     auto emit = [&](const std::string& path, std::vector<float>& pos, std::vector<float>& neg) {
         order(pos); order(neg);

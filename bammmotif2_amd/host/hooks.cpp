@@ -139,7 +139,7 @@ extern "C" {
 // negatives for a packed (positive) set; two-call protocol (codes == NULL -> sizes only)
 int bh_sample_negatives(const bamm_packed* packed, uint32_t s_order, uint64_t m_fold, int generic, uint64_t* n_out,
                         uint64_t* n_codes, uint8_t* codes, uint64_t* off) {
-    static thread_local std::vector<uint8_t> c;
+    static thread_local ByteVec c;
     static thread_local std::vector<uint64_t> o;
     if (!codes) {
         std::vector<uint32_t> ys(packed->total_len ? packed->total_len : 1);

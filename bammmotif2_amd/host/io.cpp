@@ -1,6 +1,8 @@
 // FASTA reader and model-file I/O of the BaMMmotif drop-in path.  See bamm_host.h.
+#include <omp.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,67 +60,115 @@ int read_fasta(const std::string& path, FastaSet& out, std::string& err) {
     }
     uint8_t lut[256];
     for (int c = 0; c < 256; c++) lut[c] = base_code((char)c);
+    // The records are independent: the buffer is cut at header lines into one range per granted core, every range is
+    // parsed by the same rules into its own set, and the sets are joined in file order -- the same FastaSet as one
+    // pass over the file (1 M records: 0.26 s of a 0.9 s command when parsed by one thread).
+    struct Part {
+        FastaSet set;
+        size_t counts[5] = {0, 0, 0, 0, 0};                  // [0] = unknown bases
+        size_t max_len = 0, min_len = SIZE_MAX, empty_entries = 0;
+        std::string err;
+    };
+    auto parse = [&](const char* p, const char* const endp, Part& part) {
+        FastaSet& o = part.set;
+        o.off.push_back(0);
+        o.codes.reserve((size_t)(endp - p));
+        std::string header;
+        bool have_header = false;
+        size_t rec_start = 0;                                // codes of the record being read start here
+        auto flush = [&]() {
+            if (!have_header) return;
+            have_header = false;
+            const size_t L = o.codes.size() - rec_start;
+            if (L == 0) { part.empty_entries++; return; }
+            part.max_len = std::max(part.max_len, L);
+            part.min_len = std::min(part.min_len, L);
+            o.off.push_back(o.codes.size());
+            o.headers.push_back(header);
+        };
+        while (p < endp) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(endp - p));
+            const char* le = nl ? nl : endp;                 // line = [p, le)
+            const size_t n = (size_t)(le - p);
+            if (n != 0) {                                    // blank lines are skipped
+                if (p[0] == '>') {
+                    flush();
+                    have_header = true;
+                    rec_start = o.codes.size();
+                    if (n == 1) {
+                        header = ">";
+                    } else {                                 // up to the first TAB, then up to the first CR
+                        const char* tab = (const char*)memchr(p, '\t', n);
+                        const size_t h1 = tab ? (size_t)(tab - p) : n;
+                        const char* cr = (const char*)memchr(p, '\r', h1);
+                        header.assign(p, cr ? (size_t)(cr - p) : h1);
+                    }
+                } else if (have_header) {
+                    if (memchr(p, ' ', n)) { part.err = "Error: FASTA sequence contains space character: " + path; return; }
+                    const size_t at = o.codes.size();
+                    o.codes.resize(at + n);
+                    uint8_t* dst = o.codes.data() + at;
+                    for (size_t i = 0; i < n; i++) {
+                        const uint8_t code = lut[(unsigned char)p[i]];
+                        dst[i] = code;
+                        part.counts[code]++;
+                    }
+                } else {
+                    part.err = "Error: Wrong FASTA format: " + path;
+                    return;
+                }
+            }
+            p = nl ? nl + 1 : endp;
+        }
+        flush();
+    };
+    const size_t T = std::max<size_t>(1, std::min<size_t>((size_t)host_parallelism(), buf.size() / (size_t(4) << 20) + 1));
+    std::vector<const char*> cut(T + 1, buf.data() + buf.size());
+    cut[0] = buf.data();
+    for (size_t t = 1; t < T; t++) {                         // the first header line at or behind the t-th share of the bytes
+        const char* q = buf.data() + buf.size() * t / T;
+        const char* const endq = buf.data() + buf.size();
+        while (q < endq) {
+            const char* nl = (const char*)memchr(q, '\n', (size_t)(endq - q));
+            if (!nl || nl + 1 >= endq) { q = endq; break; }
+            if (nl[1] == '>') { q = nl + 1; break; }
+            q = nl + 1;
+        }
+        cut[t] = std::max(q, cut[t - 1]);
+    }
+    std::vector<Part> parts(T);
+#pragma omp parallel for schedule(static, 1) num_threads((int)T)
+    for (long t = 0; t < (long)T; t++) parse(cut[(size_t)t], cut[(size_t)t + 1], parts[(size_t)t]);
     out = FastaSet();
     out.off.push_back(0);
-    out.codes.reserve(buf.size());
-    size_t max_len = 0, min_len = SIZE_MAX;
-    size_t counts[5] = {0, 0, 0, 0, 0};                      // [0] = unknown bases
-    std::string header;
-    bool have_header = false;
-    size_t rec_start = 0;                                    // codes of the record being read start here
-    auto flush = [&]() {
-        if (!have_header) return;
-        have_header = false;
-        const size_t L = out.codes.size() - rec_start;
-        if (L == 0) {
-            fprintf(stderr, "Warning: Ignore FASTA entry without sequence: %s\n", path.c_str());
-            return;
-        }
-        max_len = std::max(max_len, L);
-        min_len = std::min(min_len, L);
-        out.off.push_back(out.codes.size());
-        out.headers.push_back(header);
-    };
-    const char* p = buf.data();
-    const char* const endp = p + buf.size();
-    while (p < endp) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(endp - p));
-        const char* le = nl ? nl : endp;                     // line = [p, le)
-        const size_t n = (size_t)(le - p);
-        if (n != 0) {                                        // blank lines are skipped
-            if (p[0] == '>') {
-                flush();
-                have_header = true;
-                rec_start = out.codes.size();
-                if (n == 1) {
-                    header = ">";
-                } else {                                     // up to the first TAB, then up to the first CR
-                    const char* tab = (const char*)memchr(p, '\t', n);
-                    const size_t h1 = tab ? (size_t)(tab - p) : n;
-                    const char* cr = (const char*)memchr(p, '\r', h1);
-                    header.assign(p, cr ? (size_t)(cr - p) : h1);
-                }
-            } else if (have_header) {
-                if (memchr(p, ' ', n)) {
-                    err = "Error: FASTA sequence contains space character: " + path;
-                    return 1;
-                }
-                const size_t o = out.codes.size();
-                out.codes.resize(o + n);
-                uint8_t* dst = out.codes.data() + o;
-                for (size_t i = 0; i < n; i++) {
-                    const uint8_t code = lut[(unsigned char)p[i]];
-                    dst[i] = code;
-                    counts[code]++;
-                }
-            } else {
-                err = "Error: Wrong FASTA format: " + path;
-                return 1;
-            }
-        }
-        p = nl ? nl + 1 : endp;
+    size_t max_len = 0, min_len = SIZE_MAX, total = 0, records = 0;
+    size_t counts[5] = {0, 0, 0, 0, 0};
+    for (auto& part : parts) {                               // the first error in file order is the one a single pass stops at
+        for (size_t e = 0; e < part.empty_entries; e++) fprintf(stderr, "Warning: Ignore FASTA entry without sequence: %s\n", path.c_str());
+        if (!part.err.empty()) { err = part.err; return 1; }
+        total += part.set.codes.size();
+        records += part.set.headers.size();
     }
-    flush();
+    out.codes.resize(total);
+    out.off.resize(records + 1);
+    out.headers.resize(records);
+    std::vector<size_t> code_at(T + 1, 0), rec_at(T + 1, 0);
+    for (size_t t = 0; t < T; t++) { code_at[t + 1] = code_at[t] + parts[t].set.codes.size(); rec_at[t + 1] = rec_at[t] + parts[t].set.headers.size(); }
+#pragma omp parallel for schedule(static, 1) num_threads((int)T)
+    for (long tt = 0; tt < (long)T; tt++) {
+        const size_t t = (size_t)tt;
+        Part& part = parts[t];
+        if (!part.set.codes.empty()) memcpy(out.codes.data() + code_at[t], part.set.codes.data(), part.set.codes.size());
+        for (size_t r = 0; r < part.set.headers.size(); r++) {
+            out.off[rec_at[t] + r + 1] = code_at[t] + part.set.off[r + 1];
+            out.headers[rec_at[t] + r] = std::move(part.set.headers[r]);
+        }
+    }
+    for (auto& part : parts) {
+        max_len = std::max(max_len, part.max_len);
+        min_len = std::min(min_len, part.min_len);
+        for (int c = 0; c < 5; c++) counts[c] += part.counts[c];
+    }
     out.max_len = max_len;
     out.min_len = out.size() ? min_len : 0;
     const size_t sum = counts[1] + counts[2] + counts[3] + counts[4];

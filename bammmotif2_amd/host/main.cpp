@@ -239,7 +239,8 @@ Options parse(int nargs, char** args) {
     o.advanceEM = a.present(0, "advanceEM");
     a.get(0, "threads", o.threads);
     omp_set_num_threads((int)std::max<size_t>(1, o.threads));   // Global.cpp:331-333 (default 4)
-    bamm_set_host_threads((uint32_t)std::max<size_t>(1, o.threads));
+    // packing, the negative sampler and the sorts give the same bytes however they are cut: all granted cores
+    bamm_set_host_threads((uint32_t)std::max<size_t>(o.threads, (size_t)host_parallelism()));
     // extensions of this build (the reference advertises but never parses the first two, Global.cpp:479-491)
     a.get(0, "maxEMIterations", o.max_iter);
     a.get('e', "epsilon", o.epsilon);
@@ -301,7 +302,8 @@ int main(int nargs, char* args[]) {
     if (pos.size() < o.cvFold) die("Error: Input sequences are too few for training! \n");
     stage("read FASTA");
     bamm_packed* packed = nullptr;
-    if (bamm_pack_codes(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, &packed)) die_abi("packing sequences");
+    // the stream stands at srand(42) (above; nothing between draws from it): the N draws are taken on all host threads
+    if (bamm_pack_codes_seeded(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, 42u, &packed)) die_abi("packing sequences");
     stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
     // records beyond 8192 positions leave the register-resident kernels for the window-by-window path
     // (csrc/long_seq.hip); initFromPWM's pass over such a record runs on the host
@@ -363,7 +365,7 @@ int main(int nargs, char* args[]) {
     if (posN < o.cvFold) { std::cerr << "There are " << posN << " sequences longer than input motif. Exit!\n"; exit(1); }
 
     if (o.verbose) std::cout << std::endl << "*********************" << std::endl << "*   BaMM Training   *" << std::endl << "*********************" << std::endl;
-    std::vector<uint8_t> neg_codes;
+    ByteVec neg_codes;
     std::vector<uint64_t> neg_off{0};
     std::vector<uint32_t> kept_len;
     // sequences sharded over the GPUs for the main EM run: one RCCL rank per GPU, so only over distinct devices

@@ -90,6 +90,13 @@ int  bamm_pack_kmer_ptrs(const uint64_t* const* kmer_ptrs, const uint64_t* L, ui
  * the caller's srand(42) (mainBaMM.cpp:22) the result equals packing the reference's kmer_.   */
 int  bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
                      bamm_packed** out);
+/* the same when the libc stream starts at srand(seed) (the reference seeds once, mainBaMM.cpp:22, and its positives
+ * are read first): glibc's generator is restated and checked against the running libc, so the draws are taken on all
+ * host threads (each jumps to its share of the one stream) instead of one after the other; falls back to
+ * srand(seed) + rand() where the check fails.  Same result as srand(seed); bamm_pack_codes(...).  libc's stream is
+ * left freshly seeded, not advanced.                                                                          */
+int  bamm_pack_codes_seeded(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
+                            uint32_t seed, bamm_packed** out);
 /* host threads the packing helpers may use (0 = a default of at most 8); the result never depends
  * on it: the rand() draws are taken serially, in the reference's order                        */
 void bamm_set_host_threads(uint32_t n);

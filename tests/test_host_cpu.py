@@ -179,3 +179,30 @@ def test_integration_sources_compile_against_the_headers(tmp_path):
         for f in ("EM_hip.cpp", "ScoreSeqSet_hip.cpp"):
             subprocess.check_call([cxx, "-std=c++11", "-fopenmp", "-w", "-fPIC", "-I", ref, "-I", os.path.join(root, "include"),
                                    "-c", os.path.join(root, "integration", f), "-o", str(tmp_path / (f + ".o"))])
+
+
+def test_seeded_packing_equals_the_libc_stream():
+    """bamm_pack_codes_seeded (glibc's rand() restated, every host thread jumping to its share of the draws) against
+    srand(seed) + bamm_pack_codes (one thread stepping through libc's rand()): the same packed set, N-rich sequences,
+    both strand modes, several seeds (Sequence.cpp:35-41)."""
+    import ctypes as C
+    from bammmotif2_amd import abi
+    lib = abi.load()
+    rng = np.random.default_rng(17)
+    N = 40000
+    lens = rng.integers(12, 90, N)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    codes = rng.integers(1, 5, int(off[-1])).astype(np.uint8)
+    codes[rng.random(len(codes)) < 0.03] = 0
+    for ss in (0, 1):
+        for seed in (42, 7):
+            bm.libc_srand(seed)
+            a = C.POINTER(abi.Packed)()
+            abi.check(lib.bamm_pack_codes(codes, off, N, ss, C.byref(a)))
+            b = C.POINTER(abi.Packed)()
+            abi.check(lib.bamm_pack_codes_seeded(codes, off, N, ss, seed, C.byref(b)))
+            pa, pb = bm.PackedSeqs(a), bm.PackedSeqs(b)
+            assert pa.n_exceptions == pb.n_exceptions and pa.n_exceptions > 1000
+            assert np.array_equal(pa.words, pb.words)
+            assert np.array_equal(pa.unpack_y(10), pb.unpack_y(10))
+            pa.free(); pb.free()

@@ -75,6 +75,33 @@ def test_fasta_reader(host, tmp_path):
     assert host.bh_base_name(b"/a/b/JunD.fasta") == b"JunD"
 
 
+def test_fasta_reader_cut_over_threads(host, tmp_path):
+    """Files beyond a few MB are cut at header lines and parsed on every granted core (host/io.cpp): the joined set
+    equals a single pass -- multi-line records, blank lines, CR / TAB in headers, records without a sequence, and an
+    error in the middle of the file is still THE error (SequenceSet.cpp:67-225)."""
+    rng = np.random.default_rng(3)
+    recs = []
+    for n in range(60000):
+        L = int(rng.integers(30, 400))
+        seq = "".join(rng.choice(list("ACGTacgtNR"), L))
+        if n % 7 == 0:
+            seq = seq[:L // 2] + "\n" + seq[L // 2:]            # two lines
+        head = f">s{n}" + ("\tdescr" if n % 5 == 0 else "") + ("\r" if n % 11 == 0 else "")
+        recs.append(head + "\n" + seq + "\n" + ("\n" if n % 13 == 0 else "") + (">nothing\n" if n % 1001 == 0 else ""))
+    p = tmp_path / "big.fa"
+    p.write_text("".join(recs))
+    assert p.stat().st_size > 12 << 20                           # several ranges
+    codes, off, bf = host_fasta(host, str(p))
+    c2, o2 = read_fasta_py(str(p))
+    assert np.array_equal(off, o2) and np.array_equal(codes, c2) and len(off) == 60001
+    np.testing.assert_allclose(bf, np.bincount(codes, minlength=5)[1:] / (codes > 0).sum(), rtol=1e-6)
+    recs[41234] = ">bad\nAC GT\n"
+    p.write_text("".join(recs))
+    n, m = C.c_uint64(), C.c_uint64()
+    assert host.bh_read_fasta(str(p).encode(), C.byref(n), C.byref(m), None, None, None) == 1
+    assert b"space character" in host.bh_last_error()
+
+
 @pytest.mark.parametrize("name", ["small_k2_ds_N", "small_k0_ss", "small_k3_ds"])
 def test_model_writers_match_reference_bytes(name, host, tmp_path):
     c, g = gu.load(name)
