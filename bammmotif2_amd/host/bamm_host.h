@@ -94,8 +94,9 @@ using ByteVec = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;
 // every core the process may use (affinity mask capped by the cgroup quota): for host work whose result does not
 // depend on how it is cut -- the negative sampler, packing, sorts
 int host_parallelism();
+void set_host_parallelism(int n);           // tests: force a thread count (0 = every granted core again)
 int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, uint32_t s_order, size_t m_fold,
-                     bool generic, ByteVec& codes_out, std::vector<uint64_t>& off_out, std::string& err);
+                     bool generic, ByteVec& codes_out, std::vector<uint64_t>& off_out, std::string& err, size_t keep_stride = 0);
 
 struct FdrResult {                      // what FDR::calculatePR / calculatePvalues leave behind (FDR.h:54-84)
     std::vector<float> zoops_tp, zoops_fp, zoops_fdr, zoops_rec, pn_pvalue, zoops_pvalue;

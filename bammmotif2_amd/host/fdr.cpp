@@ -4,6 +4,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cassert>
 #include <cmath>
@@ -125,13 +126,29 @@ struct NegSampler {
     // stream (sequence f consumes draws [f*L, (f+1)*L)) but advanced position by position together:
     // the per-base dependency chain (context -> bars -> base -> context) of one sequence overlaps
     // with those of the others.
-    void draw_many(size_t L, size_t F, uint8_t* seqs, std::vector<float>& rnd, std::vector<size_t>& ctx) {
-        if (s >= L || F == 1) { for (size_t f = 0; f < F; f++) draw(L, seqs + f * L); return; }
+    // keep (nullable): keep[f] == 0 -> sequence f still consumes its L draws of the stream but is not generated; the
+    // kept ones are written one after the other (FDR.cpp:58-60 only ever scores every cvFold-th negative)
+    void draw_many(size_t L, size_t F, uint8_t* seqs, std::vector<float>& rnd, std::vector<size_t>& ctx, const uint8_t* keep = nullptr) {
+        if (s >= L || F == 1) {
+            for (size_t f = 0; f < F; f++) {
+                if (keep && !keep[f]) { for (size_t k = 0; k < L; k++) (void)stream.next(); continue; }
+                draw(L, seqs);
+                seqs += L;
+            }
+            return;
+        }
         rnd.resize(F * L);
         for (size_t k = 0; k < F * L; k++) rnd[k] = (float)stream.next() / (float)RAND_MAX;
         ctx.assign(F, 0);
+        std::vector<uint8_t*>& dst = dst_scratch;
+        dst.assign(F, nullptr);
+        {
+            uint8_t* at = seqs;
+            for (size_t f = 0; f < F; f++) if (!keep || keep[f]) { dst[f] = at; at += L; }
+        }
         for (size_t f = 0; f < F; f++) {               // the first s bases: lower-order bars (as in draw())
-            uint8_t* seq = seqs + f * L;
+            if (!dst[f]) continue;
+            uint8_t* seq = dst[f];
             const float* r = rnd.data() + f * L;
             for (uint8_t y = 0; y < 4; y++)
                 if (r[0] <= range_bar[y]) { seq[0] = y + 1; break; }
@@ -149,13 +166,15 @@ struct NegSampler {
         const float* bar = range_bar.data() + bgoff(s);
         for (size_t i = s; i < L; i++)
             for (size_t f = 0; f < F; f++) {
+                if (!dst[f]) continue;
                 const float* b4 = bar + ctx[f] * 4;
                 const float random = rnd[f * L + i];
                 const uint8_t a = (uint8_t)(1 + (random > b4[0]) + (random > b4[1]) + (random > b4[2]));
-                seqs[f * L + i] = a;
+                dst[f][i] = a;
                 ctx[f] = (ctx[f] * 4 + (size_t)(a - 1)) & ctx_mask;
             }
     }
+    std::vector<uint8_t*> dst_scratch;
 
     void draw(size_t L, uint8_t* seq) {             // :222-283 == :296-341 (same sampling loop)
         float random = (float)stream.next() / (float)RAND_MAX;
@@ -193,7 +212,10 @@ struct NegSampler {
 // Host threads for work whose result does not depend on how it is cut (this sampler, packing, sorts): every core
 // the process may use -- the affinity mask capped by the cgroup CPU quota -- whatever --threads says (the
 // reference's flag sized its OpenMP EM loops, Global.cpp:331-333; a container may show 256 CPUs and grant 16).
+static std::atomic<int> g_parallelism_override{0};
+void set_host_parallelism(int n) { g_parallelism_override.store(n > 0 ? n : 0); }
 int host_parallelism() {
+    if (const int forced = g_parallelism_override.load()) return forced;
     static const int n = [] {
         int c = (int)std::thread::hardware_concurrency();
         cpu_set_t set;
@@ -208,7 +230,7 @@ int host_parallelism() {
 }
 
 int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, uint32_t s_order, size_t m_fold,
-                     bool generic, ByteVec& codes_out, std::vector<uint64_t>& off_out, std::string& err) {
+                     bool generic, ByteVec& codes_out, std::vector<uint64_t>& off_out, std::string& err, size_t keep_stride) {
     if (!generic && s_order != 2) {
         err = "Error: the sequence-specific negative sampler is written for -s 2 (SeqGenerator.cpp:112-186); use --genericNeg";
         return 1;
@@ -217,61 +239,56 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
     NegSampler g(s_order);
     g.stream.start();
     g.kmer_frequency(y_s, off, n_seqs);
-    codes_out.clear();
-    off_out.assign(1, 0);
-    std::vector<float> rnd;
-    std::vector<size_t> ctx;
-    {
-        size_t total = 0;
-        for (size_t i = 0; i < n_seqs; i++) total += (off[i + 1] - off[i]) * m_fold;
-        codes_out.reserve(total);
-        off_out.reserve(n_seqs * m_fold + 1);
-    }
     // Every negative consumes exactly L draws of the one rand() stream, in order, so where each positive
     // sequence's draws start is known up front.  With the restated generator (stream.fast) the stream
-    // is cut into contiguous ranges: a serial pass only advances the generator to record the state at
-    // every range start, then the ranges are sampled on separate threads -- same draws, same negatives.
-    std::vector<uint64_t> d0(n_seqs + 1, 0);
-    for (size_t i = 0; i < n_seqs; i++) d0[i + 1] = d0[i] + (uint64_t)(off[i + 1] - off[i]) * m_fold;
-    const int threads = host_parallelism();
-    if (g.stream.fast && threads > 1 && n_seqs >= 256) {
-        const size_t P = (size_t)threads;
-        std::vector<size_t> first(P + 1, n_seqs);
-        first[0] = 0;
-        for (size_t p = 1; p < P; p++)                        // ranges of about equal numbers of draws
-            first[p] = (size_t)(std::lower_bound(d0.begin(), d0.end(), d0[n_seqs] * p / P) - d0.begin());
-        for (size_t p = 1; p <= P; p++) first[p] = std::max(first[p], first[p - 1]);
-        first[P] = n_seqs;
-        std::vector<decltype(g.stream)> start(P, g.stream);
-        for (size_t p = 0; p < P; p++) start[p].jump(d0[first[p]]);     // nobody steps through the stream: Stream::jump
-        codes_out.resize((size_t)d0[n_seqs]);                 // every byte is written by the range that owns it
-        off_out.resize(n_seqs * m_fold + 1);
-#pragma omp parallel for schedule(static) num_threads((int)P)
-        for (long i = 0; i < (long)n_seqs; i++)
-            for (size_t f = 0; f < m_fold; f++) off_out[(size_t)i * m_fold + f + 1] = d0[i] + (off[i + 1] - off[i]) * (f + 1);
-#pragma omp parallel for schedule(static, 1) num_threads((int)P)
-        for (long p = 0; p < (long)P; p++) {
-            NegSampler w = g;                                  // own tables (rescale writes them), own stream position
-            w.stream = start[(size_t)p];
-            std::vector<float> rnd2;
-            std::vector<size_t> ctx2;
-            for (size_t i = first[(size_t)p]; i < first[(size_t)p + 1]; i++) {
-                const size_t L = off[i + 1] - off[i];
-                if (!generic) w.rescale(y_s + off[i], L);
-                w.draw_many(L, m_fold, codes_out.data() + d0[i], rnd2, ctx2);
-            }
-        }
-        return 0;
-    }
+    // is cut into contiguous ranges, every range jumps to its first draw (GlibcRandStream::jump) and the ranges
+    // are sampled on separate threads -- same draws, same negatives.
+    // keep_stride > 1: only the negatives idx = 0, stride, 2 stride, ... with idx + stride <= total are generated and
+    // returned (the others still consume their draws): --FDR scores nothing else (FDR.cpp:58-60).
+    const size_t total_neg = n_seqs * m_fold;
+    auto kept = [&](size_t idx) { return keep_stride <= 1 || (idx % keep_stride == 0 && idx + keep_stride <= total_neg); };
+    std::vector<uint64_t> d0(n_seqs + 1, 0);                 // first draw of positive i
+    std::vector<uint64_t> c0(n_seqs + 1, 0), k0(n_seqs + 1, 0);   // first output byte / first kept negative of positive i
     for (size_t i = 0; i < n_seqs; i++) {
-        const size_t L = off[i + 1] - off[i];
-        // the reference recomputes the rescaled tables for every fold (SeqGenerator.cpp:296); they
-        // only depend on the positive sequence, so once per sequence gives the same tables
-        if (!generic) g.rescale(y_s + off[i], L);
-        const size_t o = codes_out.size();
-        codes_out.resize(o + L * m_fold);
-        g.draw_many(L, m_fold, codes_out.data() + o, rnd, ctx);
-        for (size_t f = 0; f < m_fold; f++) off_out.push_back(o + L * (f + 1));
+        const uint64_t L = off[i + 1] - off[i];
+        size_t nk = 0;
+        for (size_t f = 0; f < m_fold; f++) nk += kept(i * m_fold + f);
+        d0[i + 1] = d0[i] + L * m_fold;
+        c0[i + 1] = c0[i] + L * nk;
+        k0[i + 1] = k0[i] + nk;
+    }
+    codes_out.resize((size_t)c0[n_seqs]);                     // every byte is written by the range that owns it
+    off_out.assign((size_t)k0[n_seqs] + 1, 0);
+    const int threads = host_parallelism();
+    const bool parallel = g.stream.fast && threads > 1 && n_seqs >= 256;
+    const size_t P = parallel ? (size_t)threads : 1;
+    std::vector<size_t> first(P + 1, n_seqs);
+    first[0] = 0;
+    for (size_t p = 1; p < P; p++)                            // ranges of about equal numbers of draws
+        first[p] = (size_t)(std::lower_bound(d0.begin(), d0.end(), d0[n_seqs] * p / P) - d0.begin());
+    for (size_t p = 1; p <= P; p++) first[p] = std::max(first[p], first[p - 1]);
+    first[P] = n_seqs;
+    std::vector<decltype(g.stream)> start(P, g.stream);
+    for (size_t p = 1; p < P; p++) start[p].jump(d0[first[p]]);   // nobody steps through the stream
+#pragma omp parallel for schedule(static, 1) num_threads((int)P)
+    for (long p = 0; p < (long)P; p++) {
+        NegSampler w = g;                                      // own tables (rescale writes them), own stream position
+        w.stream = start[(size_t)p];
+        std::vector<float> rnd2;
+        std::vector<size_t> ctx2;
+        std::vector<uint8_t> keep_f(m_fold, 1);
+        for (size_t i = first[(size_t)p]; i < first[(size_t)p + 1]; i++) {
+            const size_t L = off[i + 1] - off[i];
+            // the reference recomputes the rescaled tables for every fold (SeqGenerator.cpp:296); they
+            // only depend on the positive sequence, so once per sequence gives the same tables
+            if (!generic) w.rescale(y_s + off[i], L);
+            size_t nk = 0;
+            for (size_t f = 0; f < m_fold; f++) {
+                keep_f[f] = kept(i * m_fold + f) ? 1 : 0;
+                if (keep_f[f]) { off_out[(size_t)k0[i] + nk + 1] = c0[i] + L * (nk + 1); nk++; }
+            }
+            w.draw_many(L, m_fold, codes_out.data() + c0[i], rnd2, ctx2, keep_stride > 1 ? keep_f.data() : nullptr);
+        }
     }
     return 0;
 }

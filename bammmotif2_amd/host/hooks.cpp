@@ -124,7 +124,8 @@ int bh_load_seed_dev(const char* path, const char* tag, uint32_t l_flank, uint32
 }
 
 // OpenMP threads of the host-side loops (the CLI's --threads)
-void bh_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+void bh_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); set_host_parallelism(n > 0 ? n : 1); }
+void bh_auto_threads() { set_host_parallelism(0); }
 
 const char* bh_base_name(const char* path) {
     g_err = base_name(path);
@@ -137,8 +138,15 @@ const char* bh_base_name(const char* path) {
 extern "C" {
 
 // negatives for a packed (positive) set; two-call protocol (codes == NULL -> sizes only)
+int bh_sample_negatives_strided(const bamm_packed* packed, uint32_t s_order, uint64_t m_fold, int generic, uint64_t keep_stride,
+                                uint64_t* n_out, uint64_t* n_codes, uint8_t* codes, uint64_t* off);
 int bh_sample_negatives(const bamm_packed* packed, uint32_t s_order, uint64_t m_fold, int generic, uint64_t* n_out,
                         uint64_t* n_codes, uint8_t* codes, uint64_t* off) {
+    return bh_sample_negatives_strided(packed, s_order, m_fold, generic, 0, n_out, n_codes, codes, off);
+}
+// keep_stride > 1: only every keep_stride-th negative (what --FDR scores, FDR.cpp:58-60) is generated and returned
+int bh_sample_negatives_strided(const bamm_packed* packed, uint32_t s_order, uint64_t m_fold, int generic, uint64_t keep_stride,
+                                uint64_t* n_out, uint64_t* n_codes, uint8_t* codes, uint64_t* off) {
     static thread_local ByteVec c;
     static thread_local std::vector<uint64_t> o;
     if (!codes) {
@@ -146,7 +154,7 @@ int bh_sample_negatives(const bamm_packed* packed, uint32_t s_order, uint64_t m_
         if (bamm_unpack_y(packed, s_order, ys.data())) { g_err = bamm_last_error(); return 1; }
         std::vector<uint64_t> poff(packed->n_seqs + 1, 0);
         for (uint64_t n = 0; n < packed->n_seqs; n++) poff[n + 1] = poff[n] + packed->len[n];
-        if (sample_negatives(ys.data(), poff.data(), packed->n_seqs, s_order, m_fold, generic != 0, c, o, g_err)) return 1;
+        if (sample_negatives(ys.data(), poff.data(), packed->n_seqs, s_order, m_fold, generic != 0, c, o, g_err, (size_t)keep_stride)) return 1;
         *n_out = o.size() - 1;
         *n_codes = c.size();
         return 0;

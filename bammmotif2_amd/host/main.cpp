@@ -6,6 +6,8 @@
 // sequences (--EM) and spreads the cross-validation folds (--FDR) over N GPUs.  Not ported (exit
 // with a clear message): --CGS, non-STANDARD alphabets.
 #include <omp.h>
+
+#include <algorithm>
 #include <thread>
 #include <sys/stat.h>
 
@@ -27,7 +29,10 @@ using namespace bammhost;
 
 namespace {
 
+std::thread g_hip_warmup;                  // brings the HIP runtime up while the FASTA file is read (main)
+
 [[noreturn]] void die(const std::string& msg) {
+    if (g_hip_warmup.joinable()) g_hip_warmup.join();          // never exit() under a thread that is inside the HIP runtime
     std::cerr << msg << std::endl;
     exit(1);
 }
@@ -296,6 +301,12 @@ int main(int nargs, char* args[]) {
     if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
     if (o.K > BAMM_MAX_ORDER) die("Error: model order above 10 is not supported (kmer_ spans 11 bases).");
 
+    // the HIP runtime takes 0.1-0.2 s to come up on first use: it does so on a thread of its own while the FASTA
+    // file is read and packed (nothing is decided there: the contexts proper are created where they always were)
+    std::thread& hip_warmup = g_hip_warmup;
+    if (o.EM || o.score || o.FDR) hip_warmup = std::thread([] { int n = 0; (void)bamm_device_count(&n); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warmup_joiner{hip_warmup};
+
     std::string err;
     FastaSet pos;
     if (read_fasta(o.fasta, pos, err)) die(err);
@@ -329,7 +340,8 @@ int main(int nargs, char* args[]) {
         bamm_ctx* ctx = nullptr;
         bamm_seqs* full = nullptr;         // every kept positive (scoring, fold replicas, single-GPU EM)
         bamm_seqs* shard = nullptr;        // this GPU's range of the kept positives (the full set with one GPU)
-        bamm_seqs* neg = nullptr;          // the sampled negatives
+        bamm_seqs* neg = nullptr;          // the sampled negatives, all of them (--scoreSeqset scores them on the first GPU)
+        bamm_seqs* neg_cv = nullptr;       // every cvFold-th negative: all the folds of --FDR ever score (FDR.cpp:58-60)
         bamm_comm* comm = nullptr;
         uint64_t begin = 0, end = 0;
     };
@@ -337,6 +349,7 @@ int main(int nargs, char* args[]) {
     std::vector<Dev> devs(ndev);
     for (size_t d = 0; d < ndev; d++) devs[d].device = o.device_list[d];
     auto make_ctx = [&](Dev& dv) {
+        if (hip_warmup.joinable()) hip_warmup.join();
         if (!dv.ctx && bamm_ctx_create(dv.device, nullptr, &dv.ctx)) die_abi("no usable MI355X");
     };
     bamm_seqs* dseqs_all = nullptr;                          // every positive record, resident (seeding, then EM)
@@ -366,12 +379,44 @@ int main(int nargs, char* args[]) {
 
     if (o.verbose) std::cout << std::endl << "*********************" << std::endl << "*   BaMM Training   *" << std::endl << "*********************" << std::endl;
     ByteVec neg_codes;
+    size_t negN = 0;                        // negatives the reference would hold (all of them, sampled or not)
+    std::vector<uint32_t> neg_cv_len;       // lengths of the folds' subset (every cvFold-th negative)
     std::vector<uint64_t> neg_off{0};
     std::vector<uint32_t> kept_len;
-    // sequences sharded over the GPUs for the main EM run: one RCCL rank per GPU, so only over distinct devices
-    // (a device listed twice still hosts fold replicas of --FDR, each with a context and a stream of its own)
-    const bool distinct = std::set<int>(o.device_list.begin(), o.device_list.end()).size() == ndev;
-    const bool sharded = ndev > 1 && o.EM && distinct;
+    // The plan: which GPU slot does what (FDR.cpp:37-127, mainBaMM.cpp:131-147).
+    //   * the main EM run is sharded over its group of slots, one all-reduce of the count table per iteration: RCCL when
+    //     the group's devices are distinct, else (a device listed twice: self-tests on a 1-GPU box) the host-staged sum;
+    //   * --FDR trains fold f on fold_slot[f] from the SEED model, so the folds do not wait for the main run: with at
+    //     least cvFold + 1 slots the folds take the last cvFold of them and the main run the others, AT THE SAME TIME
+    //     (8 GPUs, 5 folds: 3 + 5, no idle device); with fewer slots the main run uses all of them first and the folds
+    //     then go round them (fold f on slot f mod N).
+    //   --advanceEM --optimizeQ re-estimates q after every sequence (EM.cpp:321): that chain runs on one slot.
+    const size_t cvF = std::max<size_t>(1, o.cvFold);
+    const bool overlap = need_gpu && o.FDR && o.EM && ndev >= cvF + 1;
+    std::vector<size_t> em_slots, fold_slot(cvF, 0);
+    for (size_t d = 0; d < (overlap ? ndev - cvF : ndev); d++) em_slots.push_back(d);
+    for (size_t f = 0; f < cvF; f++) fold_slot[f] = overlap ? ndev - cvF + f : f % ndev;
+    if (o.advanceEM && o.optimizeQ) em_slots.resize(1);
+    const size_t ne = em_slots.size();
+    std::set<int> em_devices;
+    for (size_t d : em_slots) em_devices.insert(o.device_list[d]);
+    const bool distinct = em_devices.size() == ne;
+    const bool sharded = ne > 1 && o.EM;
+    auto in_em_group = [&](size_t d) { return d < ne; };
+    auto runs_folds = [&](size_t d) { return o.FDR && std::find(fold_slot.begin(), fold_slot.end(), d) != fold_slot.end(); };
+    if (timing && need_gpu) {
+        std::cerr << "  plan over " << ndev << " GPU slot(s) [devices";
+        for (int dv : o.device_list) std::cerr << ' ' << dv;
+        std::cerr << "]:";
+        if (o.EM) std::cerr << " main EM on slot(s) 0.." << ne - 1 << (sharded ? (distinct ? " (sharded, RCCL all-reduce per iteration)" : " (sharded, host-staged all-reduce: a device is listed twice)") : "");
+        if (o.FDR) {
+            std::cerr << "; fold -> slot";
+            for (size_t f = 0; f < cvF; f++) std::cerr << ' ' << f << "->" << fold_slot[f];
+            std::cerr << (overlap ? " (while the main run trains)" : " (after the main run)");
+        }
+        if (o.score) std::cerr << "; --scoreSeqset on slot 0";
+        std::cerr << std::endl;
+    }
     if (need_gpu) {
         for (auto& dv : devs) make_ctx(dv);
         bamm_packed* use = packed;
@@ -387,19 +432,19 @@ int main(int nargs, char* args[]) {
             use = filtered;
         }
         if (dseqs_all && use != packed) { bamm_seqs_destroy(dseqs_all); dseqs_all = nullptr; }
-        // which GPU needs what: the full set where sequences are scored (GPU 0) or folds are trained (every GPU
-        // with --FDR), a shard where the main EM run is sharded
+        // which slot needs what: the full set where sequences are scored (slot 0) or folds are trained, a shard
+        // where the main EM run is sharded
         for (size_t d = 0; d < ndev; d++) {
             Dev& dv = devs[d];
-            const bool want_full = !sharded || (d == 0 && o.score) || o.FDR;
+            const bool want_full = (in_em_group(d) && !sharded) || (d == 0 && o.score) || runs_folds(d);
             if (want_full) {
                 if (d == 0 && dseqs_all) dv.full = dseqs_all;   // nothing was dropped: the seeding copy is the training set
                 else if (bamm_seqs_upload(dv.ctx, use, 0, use->n_seqs, &dv.full)) die_abi("upload");
             } else if (d == 0 && dseqs_all) {
                 bamm_seqs_destroy(dseqs_all);
             }
-            if (sharded) {
-                if (bamm_shard_range(use->len, use->n_seqs, seeds.max_w, (uint32_t)d, (uint32_t)ndev, &dv.begin, &dv.end)) die_abi("shard range");
+            if (sharded && in_em_group(d)) {
+                if (bamm_shard_range(use->len, use->n_seqs, seeds.max_w, (uint32_t)d, (uint32_t)ne, &dv.begin, &dv.end)) die_abi("shard range");
                 if (bamm_seqs_upload(dv.ctx, use, dv.begin, dv.end, &dv.shard)) die_abi("upload of a shard");
             } else {
                 dv.shard = dv.full; dv.begin = 0; dv.end = use->n_seqs;
@@ -409,12 +454,18 @@ int main(int nargs, char* args[]) {
         kept_len.assign(use->len, use->len + use->n_seqs);
         stage("device contexts + upload of the positives");
         if (sharded || o.forceComm) {
+            const size_t nc = sharded ? ne : 1;
             std::vector<bamm_ctx*> ctxs;
-            std::vector<bamm_comm*> comms(ndev, nullptr);
-            for (auto& dv : devs) ctxs.push_back(dv.ctx);
-            if (bamm_comm_init_all(ctxs.data(), (uint32_t)ndev, comms.data())) die_abi("RCCL communicator");
-            for (size_t d = 0; d < ndev; d++) devs[d].comm = comms[d];
-            stage("RCCL communicator over the GPUs");
+            std::vector<bamm_comm*> comms(nc, nullptr);
+            for (size_t d = 0; d < nc; d++) ctxs.push_back(devs[d].ctx);
+            if (distinct) {
+                if (bamm_comm_init_all(ctxs.data(), (uint32_t)nc, comms.data())) die_abi("RCCL communicator");
+            } else {                                         // the largest buffer summed: the count table + 3, or EM::mask's histogram
+                const uint64_t words = std::max<uint64_t>((uint64_t)seeds.max_w * (uint64_t(1) << (2 * (o.K + 1))) + 3, 2049);
+                if (bamm_comm_init_local(ctxs.data(), (uint32_t)nc, words, comms.data())) die_abi("host-staged communicator");
+            }
+            for (size_t d = 0; d < nc; d++) devs[d].comm = comms[d];
+            stage(distinct ? "RCCL communicator over the GPUs" : "host-staged communicator over the contexts");
         }
         if (o.score || o.FDR) {
             // negative set sampled from the s-mer statistics of the (kept) positives, mainBaMM.cpp:97-116
@@ -425,19 +476,40 @@ int main(int nargs, char* args[]) {
             if (bamm_unpack_y(use, (uint32_t)o.sOrder, ys.data())) die_abi("unpack");
             std::vector<uint64_t> uoff(use->n_seqs + 1, 0);
             for (uint64_t n = 0; n < use->n_seqs; n++) uoff[n + 1] = uoff[n] + use->len[n];
-            if (sample_negatives(ys.data(), uoff.data(), use->n_seqs, (uint32_t)o.sOrder, mFold, o.genericNeg, neg_codes, neg_off, err)) die(err);
+            negN = (size_t)use->n_seqs * mFold;
+            // the folds of --FDR score every cvFold-th negative and nothing else (FDR.cpp:58-60): without --scoreSeqset
+            // only those are generated, packed and uploaded (the others still consume their draws of the stream)
+            const size_t stride = (o.FDR && !o.score) ? cvF : 0;
+            if (sample_negatives(ys.data(), uoff.data(), use->n_seqs, (uint32_t)o.sOrder, mFold, o.genericNeg, neg_codes, neg_off, err, stride)) die(err);
             stage("negative set: sample (host, rand() stream of the reference)");
             bamm_packed* npk = nullptr;
             if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) die_abi("packing negatives");
-            for (size_t d = 0; d < ndev; d++)
-                if (d == 0 || o.FDR)
-                    if (bamm_seqs_upload(devs[d].ctx, npk, 0, npk->n_seqs, &devs[d].neg)) die_abi("upload negatives");
+            if (stride > 1) {                                // what was sampled IS the folds' subset
+                for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_cv_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
+                for (size_t d = 0; d < ndev; d++)
+                    if (runs_folds(d) && bamm_seqs_upload(devs[d].ctx, npk, 0, npk->n_seqs, &devs[d].neg_cv)) die_abi("upload negatives");
+            } else {
+                if (bamm_seqs_upload(devs[0].ctx, npk, 0, npk->n_seqs, &devs[0].neg)) die_abi("upload negatives");
+                if (o.FDR) {                                 // the folds' subset as a set of its own, on the slots that run folds
+                    std::vector<uint64_t> sub_off{0};
+                    ByteVec sub_codes;
+                    for (size_t i = 0; i + cvF <= negN; i += cvF) {
+                        sub_codes.insert(sub_codes.end(), neg_codes.begin() + (ptrdiff_t)neg_off[i], neg_codes.begin() + (ptrdiff_t)neg_off[i + 1]);
+                        sub_off.push_back(sub_codes.size());
+                        neg_cv_len.push_back((uint32_t)(neg_off[i + 1] - neg_off[i]));
+                    }
+                    bamm_packed* spk = nullptr;
+                    if (bamm_pack_codes(sub_codes.data(), sub_off.data(), sub_off.size() - 1, 1, &spk)) die_abi("packing negatives");
+                    for (size_t d = 0; d < ndev; d++)
+                        if (runs_folds(d) && bamm_seqs_upload(devs[d].ctx, spk, 0, spk->n_seqs, &devs[d].neg_cv)) die_abi("upload negatives");
+                    bamm_packed_free(spk);
+                }
+            }
             bamm_packed_free(npk);
             stage("negative set: pack + upload");
         }
         if (filtered) bamm_packed_free(filtered);
     }
-    const size_t negN = neg_off.size() - 1;
     // scorer over a resident set: MOPS scores (concatenated), ZOOPS maxima
     auto score_set = [&](bamm_ctx* ctx, bamm_seqs* set, const std::vector<uint32_t>& lens, const Motif& m, std::vector<float>& mops,
                          std::vector<float>& zoops, const uint8_t* subset = nullptr, bool want_mops = true,
@@ -455,8 +527,8 @@ int main(int nargs, char* args[]) {
         zoops.resize(lens.size());
         return 0;
     };
-    std::vector<uint32_t> neg_len;
-    for (size_t n = 0; n < negN; n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
+    std::vector<uint32_t> neg_len;                           // all negatives: only sampled for --scoreSeqset
+    if (o.score) for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
     // kept positives: FASTA codes / headers in the same order as the resident set
     std::vector<std::string> kept_headers;
     std::vector<uint8_t> kept_codes;
@@ -476,21 +548,82 @@ int main(int nargs, char* args[]) {
         return p;
     };
 
+    // ---- --FDR: the folds of one motif (FDR.cpp:37-127).  Fold f trains on the positives {n : n mod cvFold != f} from the SEED
+    // model and scores its test positives and every cvFold-th negative on slot fold_slot[f]; one host thread per slot in
+    // use (the reference runs its folds on OpenMP threads, FDR.cpp:37); every fold keeps its scores to itself and they
+    // are merged in fold order afterwards, so the files do not depend on the plan or on which fold finishes first.
+    struct FoldOut { std::vector<float> posMax, negMax, posAll, negAll; float q = 0.f; std::string log, err; };
+    std::vector<std::vector<FoldOut>> fold_results(seeds.motifs.size());
+    auto run_folds = [&](size_t n, std::vector<FoldOut>& folds) {
+        const size_t cv = o.cvFold, P = kept_len.size();
+        const Motif& seed = seeds.motifs[n];
+        folds.assign(cv, FoldOut());
+        for (auto& f : folds) f.q = seed.q;
+        std::vector<size_t> slots_in_use;
+        for (size_t f = 0; f < cv; f++)
+            if (std::find(slots_in_use.begin(), slots_in_use.end(), fold_slot[f]) == slots_in_use.end()) slots_in_use.push_back(fold_slot[f]);
+        auto one_fold = [&](size_t fold) {
+            Dev& dv = devs[fold_slot[fold]];
+            FoldOut& fo = folds[fold];
+            Motif m = seed;
+            std::vector<uint8_t> train(P, 0), test(P, 0);
+            for (size_t i = 0; i + cv <= P; i += cv)         // strided split; the last P mod cv records are unused
+                for (size_t f = 0; f < cv; f++) (f != fold ? train : test)[i + f] = 1;
+            if (o.EM) {
+                bamm_em_params p = em_params(m);
+                bamm_em* em = nullptr;
+                if (bamm_em_create(dv.ctx, dv.full, &p, bg.v.data(), m.A.data(), m.v.data(), train.data(), &em)) { fo.err = bamm_last_error(); return; }
+                uint32_t it = 0;
+                auto t0 = std::chrono::high_resolution_clock::now();
+                int rc;
+                if (!o.advanceEM) rc = bamm_em_optimize(em, &it);                              // FDR.cpp:67-72
+                else rc = bamm_em_mask(em, o.f, &it, nullptr, nullptr);
+                if (rc) { fo.err = bamm_last_error(); bamm_em_destroy(em); return; }
+                bamm_em_get_v(em, m.v.data());
+                bamm_em_get_q(em, &fo.q);
+                bamm_em_destroy(em);
+                std::ostringstream os;
+                os << "\n--- Runtime for EM: " << std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() << " seconds ---\n";
+                fo.log = os.str();
+            }
+            std::vector<float> mops, zoops;
+            if (score_set(dv.ctx, dv.full, kept_len, m, mops, zoops, test.data(), o.mops)) { fo.err = bamm_last_error(); return; }
+            size_t o_m = 0;
+            for (size_t i = 0; i < P; i++) {
+                const size_t nw = kept_len[i] - m.W + 1;
+                if (test[i]) {
+                    if (o.mops) fo.posAll.insert(fo.posAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
+                    if (o.zoops) fo.posMax.push_back(zoops[i]);
+                }
+                o_m += nw;
+            }
+            // negSet = every cv-th negative (FDR.cpp:58-60): resident as a set of its own, scored as a whole
+            if (score_set(dv.ctx, dv.neg_cv, neg_cv_len, m, mops, zoops, nullptr, o.mops)) { fo.err = bamm_last_error(); return; }
+            if (o.mops) fo.negAll = mops;
+            if (o.zoops) fo.negMax = zoops;
+        };
+        std::vector<std::thread> team;
+        for (size_t slot : slots_in_use)
+            team.emplace_back([&, slot] { for (size_t f = 0; f < cv; f++) if (fold_slot[f] == slot) one_fold(f); });
+        for (auto& t : team) t.join();
+    };
+
     for (size_t n = 0; n < seeds.motifs.size(); n++) {
         Motif motif = seeds.motifs[n];                       // deep copy (mainBaMM.cpp:121)
         const std::string mbase = o.basename + "_motif_" + std::to_string(n + 1);
         if (o.saveInitial && motif_write(o.out_dir, o.basename + "_init_motif_" + std::to_string(n + 1), motif, err)) die(err);
+        std::thread fold_thread;                             // overlap mode: this motif's folds train while its main run does
+        if (overlap) fold_thread = std::thread([&, n] { run_folds(n, fold_results[n]); });
+        struct FoldJoin { std::thread& t; ~FoldJoin() { if (t.joinable()) t.join(); } } fold_join{fold_thread};
         if (o.EM) {
             auto t0 = std::chrono::high_resolution_clock::now();
-            if (o.advanceEM && o.optimizeQ && devs[0].comm)
-                die("Error: --advanceEM --optimizeQ re-estimates q after every sequence (EM.cpp:321); that chain cannot be sharded over GPUs.");
             const bamm_em_params p = em_params(motif);
             // one handle per GPU over its shard; with several GPUs each is driven by a host thread of its own and
             // every pass ends in one RCCL all-reduce, after which all of them hold the same model
             std::vector<bamm_em*> ems(ndev, nullptr);
             std::vector<std::string> thread_err(ndev);
             std::vector<uint32_t> its(ndev, 0);
-            for (size_t d = 0; d < ndev; d++) {
+            for (size_t d = 0; d < ne; d++) {
                 if (d > 0 && !sharded) break;
                 if (bamm_em_create(devs[d].ctx, devs[d].shard, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &ems[d])) die_abi("EM");
                 if (devs[d].comm && bamm_em_set_comm(ems[d], devs[d].comm)) die_abi("EM communicator");
@@ -520,7 +653,7 @@ int main(int nargs, char* args[]) {
             };
             if (sharded) {
                 std::vector<std::thread> team;
-                for (size_t d = 0; d < ndev; d++) if (ems[d]) team.emplace_back(run_rank, d);
+                for (size_t d = 0; d < ne; d++) if (ems[d]) team.emplace_back(run_rank, d);
                 for (auto& t : team) t.join();
             } else if (ems[0]) {
                 run_rank(0);
@@ -633,62 +766,9 @@ int main(int nargs, char* args[]) {
         const size_t cv = o.cvFold, P = kept_len.size();
         for (size_t n = 0; n < seeds.motifs.size(); n++) {
             const Motif& seed = seeds.motifs[n];
-            // Fold f trains and scores on GPU f mod N, on a host thread per GPU (the reference runs its folds on
-            // OpenMP threads, FDR.cpp:37); every fold keeps its scores to itself and they are merged in fold
-            // order afterwards, so the files do not depend on N or on which fold finishes first.
-            struct FoldOut { std::vector<float> posMax, negMax, posAll, negAll; float q = 0.f; std::string log, err; };
-            std::vector<FoldOut> folds(cv);
-            for (auto& f : folds) f.q = seed.q;
-#pragma omp parallel for num_threads((int)ndev) schedule(static, 1)
-            for (long fold_l = 0; fold_l < (long)cv; fold_l++) {
-                const size_t fold = (size_t)fold_l;
-                Dev& dv = devs[fold % ndev];                 // schedule(static, 1): thread t owns the folds t, t+N, ...
-                FoldOut& fo = folds[fold];
-                Motif m = seed;
-                std::vector<uint8_t> train(P, 0), test(P, 0);
-                for (size_t i = 0; i + cv <= P; i += cv)     // strided split; the last P mod cv records are unused
-                    for (size_t f = 0; f < cv; f++) (f != fold ? train : test)[i + f] = 1;
-                if (o.EM) {
-                    bamm_em_params p = em_params(m);
-                    bamm_em* em = nullptr;
-                    if (bamm_em_create(dv.ctx, dv.full, &p, bg.v.data(), m.A.data(), m.v.data(), train.data(), &em)) { fo.err = bamm_last_error(); continue; }
-                    uint32_t it = 0;
-                    auto t0 = std::chrono::high_resolution_clock::now();
-                    int rc;
-                    if (!o.advanceEM) rc = bamm_em_optimize(em, &it);                              // FDR.cpp:67-72
-                    else rc = bamm_em_mask(em, o.f, &it, nullptr, nullptr);
-                    if (rc) { fo.err = bamm_last_error(); bamm_em_destroy(em); continue; }
-                    bamm_em_get_v(em, m.v.data());
-                    bamm_em_get_q(em, &fo.q);
-                    bamm_em_destroy(em);
-                    std::ostringstream os;
-                    os << "\n--- Runtime for EM: " << std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count() << " seconds ---\n";
-                    fo.log = os.str();
-                }
-                std::vector<float> mops, zoops;
-                if (score_set(dv.ctx, dv.full, kept_len, m, mops, zoops, test.data(), o.mops)) { fo.err = bamm_last_error(); continue; }
-                size_t o_m = 0;
-                for (size_t i = 0; i < P; i++) {
-                    const size_t nw = kept_len[i] - m.W + 1;
-                    if (test[i]) {
-                        if (o.mops) fo.posAll.insert(fo.posAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
-                        if (o.zoops) fo.posMax.push_back(zoops[i]);
-                    }
-                    o_m += nw;
-                }
-                std::vector<uint8_t> neg_sel(negN ? negN : 1, 0);
-                for (size_t i = 0; i + cv <= negN; i += cv) neg_sel[i] = 1;
-                if (score_set(dv.ctx, dv.neg, neg_len, m, mops, zoops, neg_sel.data(), o.mops)) { fo.err = bamm_last_error(); continue; }
-                o_m = 0;
-                for (size_t i = 0; i < negN; i++) {
-                    const size_t nw = neg_len[i] - m.W + 1;
-                    if (i % cv == 0 && i + cv <= negN) {       // negSet = every cv-th negative (FDR.cpp:58-60)
-                        if (o.mops) fo.negAll.insert(fo.negAll.end(), mops.begin() + o_m, mops.begin() + o_m + nw);
-                        if (o.zoops) fo.negMax.push_back(zoops[i]);
-                    }
-                    o_m += nw;
-                }
-            }
+            // the folds of this motif (run_folds above): trained while the main run was training (overlap mode), else here
+            if (fold_results[n].empty()) run_folds(n, fold_results[n]);
+            std::vector<FoldOut>& folds = fold_results[n];
             std::vector<float> posMax, negMax, posAll, negAll;
             float updatedQ = seed.q;
             for (size_t fold = 0; fold < cv; fold++) {        // merge in fold order
@@ -728,6 +808,7 @@ int main(int nargs, char* args[]) {
     for (auto& dv : devs) {
         if (dv.comm) bamm_comm_destroy(dv.comm);
         if (dv.neg) bamm_seqs_destroy(dv.neg);
+        if (dv.neg_cv) bamm_seqs_destroy(dv.neg_cv);
         if (dv.shard && dv.shard != dv.full) bamm_seqs_destroy(dv.shard);
         if (dv.full) bamm_seqs_destroy(dv.full);
         if (dv.ctx) bamm_ctx_destroy(dv.ctx);

@@ -222,19 +222,33 @@ def test_cli_fold_replicas_and_native_comm_do_not_change_the_files(tmp_path, gpu
     g = dict(np.load(os.path.join(gu.GOLDEN_DIR, "config5_small.npz")))
     fasta, seed = _write_config5_inputs(tmp_path, g)
     flags = CONFIG5_FLAGS + ["--scoreSeqset", "--saveBaMMs"]
-    outs = {}
+    outs, plans = {}, {}
     for tag, extra in (("one", []), ("gpus1", ["--gpus", "1"]), ("two", ["--deviceList", "0,0"]),
-                       ("three", ["--deviceList", "0,0,0"]), ("comm", ["--forceComm"])):
+                       ("three", ["--deviceList", "0,0,0"]), ("comm", ["--forceComm"]),
+                       # 8 slots, 5 folds: the main run sharded over 3 contexts (host-staged all-reduce: one device) WHILE
+                       # the folds train on the other 5 -- the plan an 8-GPU node gets
+                       ("eight", ["--deviceList", "0,0,0,0,0,0,0,0", "--timing"])):
         out = tmp_path / tag
         r = subprocess.run([build.CLI, str(out), fasta, "--BaMMFile", seed] + flags + extra, capture_output=True, text=True)
         assert r.returncode == 0, tag + ": " + r.stderr + r.stdout[-2000:]
         assert r.stdout.count("--- Runtime for EM:") == 6
         outs[tag] = {f: open(out / f, "rb").read() for f in sorted(os.listdir(out))}
+        plans[tag] = r.stderr
     names = sorted(outs["one"])
     assert {"pos_motif_1.zoops.stats", "pos_motif_1.zoops.pvalues", "pos_motif_1.zoops.logOdds", "pos_motif_1.ihbcp",
             "pos_motif_1.occurrence", "pos_motif_1.logOddsZoops", "pos.negSet.logOddsZoops", "pos_motif_1.positions",
             "pos_motif_1.counts"} <= set(names)
-    for tag in ("gpus1", "two", "three", "comm"):
+    for tag in ("gpus1", "two", "three", "comm", "eight"):
         assert sorted(outs[tag]) == names, tag
         for f in names:
             assert outs[tag][f] == outs["one"][f], f"{tag}: {f} differs"
+    assert "main EM on slot(s) 0..2 (sharded, host-staged all-reduce" in plans["eight"] and "(while the main run trains)" in plans["eight"]
+    assert "fold -> slot 0->3 1->4 2->5 3->6 4->7" in plans["eight"]
+    # without --scoreSeqset only the folds' negatives (every cvFold-th) are sampled, packed and uploaded: same statistics
+    for tag, extra in (("fdr_only", []), ("fdr_only_eight", ["--deviceList", "0,0,0,0,0,0,0,0"])):
+        out = tmp_path / tag
+        r = subprocess.run([build.CLI, str(out), fasta, "--BaMMFile", seed] + CONFIG5_FLAGS + extra, capture_output=True, text=True)
+        assert r.returncode == 0, tag + ": " + r.stderr + r.stdout[-2000:]
+        for f in ("pos_motif_1.zoops.stats", "pos_motif_1.zoops.pvalues", "pos_motif_1.zoops.logOdds", "pos_motif_1.ihbcp"):
+            if f in outs["one"]:
+                assert open(out / f, "rb").read() == outs["one"][f], f"{tag}: {f} differs"

@@ -61,9 +61,25 @@ def test_negative_sampler_does_not_depend_on_threads(generic, host):
         assert host.bh_sample_negatives(packed._p, 2, C.c_uint64(3), generic, C.byref(n), C.byref(m),
                                         codes.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)) == 0
         out.append((codes, off))
-    host.bh_set_threads(4)
+    host.bh_auto_threads()
     assert out[0][0].size > 0 and out[0][0].min() >= 1 and out[0][0].max() <= 4
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
+    # --FDR only ever scores every cvFold-th negative (FDR.cpp:58-60): asked for just those, the sampler returns
+    # exactly that subset of the full set (the others still consume their draws of the stream)
+    codes_all, off_all = out[0]
+    total = len(off_all) - 1
+    for stride in (5, 4, 7):
+        n, m = C.c_uint64(), C.c_uint64()
+        assert host.bh_sample_negatives_strided(packed._p, 2, C.c_uint64(3), generic, C.c_uint64(stride), C.byref(n), C.byref(m), None, None) == 0
+        codes = np.zeros(m.value, np.uint8)
+        off = np.zeros(n.value + 1, np.uint64)
+        assert host.bh_sample_negatives_strided(packed._p, 2, C.c_uint64(3), generic, C.c_uint64(stride), C.byref(n), C.byref(m),
+                                                codes.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p)) == 0
+        keep = [i for i in range(0, total, stride) if i + stride <= total]
+        assert n.value == len(keep)
+        want = np.concatenate([codes_all[int(off_all[i]):int(off_all[i + 1])] for i in keep])
+        assert np.array_equal(codes, want)
+        assert np.array_equal(np.diff(off.astype(np.int64)), np.array([int(off_all[i + 1] - off_all[i]) for i in keep]))
 
 
 def test_fdr_statistics_and_files_match_reference(host, g, tmp_path):
