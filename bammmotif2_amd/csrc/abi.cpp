@@ -188,6 +188,7 @@ struct bamm_em {
     bamm_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
     bamm_comm* comm = nullptr;                  // native RCCL all-reduce (bamm_em_set_comm)
+    bool comm_verified = false;                 // verify_comm() ran with the peers
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     uint32_t events_used = 0;
     uint32_t timing_every = 8, pass_no = 0;     // bamm_em_set_kernel_timing
@@ -606,6 +607,44 @@ int fetch_status(bamm_em* em) {
     return BAMM_OK;
 }
 
+// In front of the first pass that all-reduces over a communicator (every rank is in that call, on a thread or a
+// process of its own): the ranks sum their sequence counts and compare their accumulator units.  A unit too fine for
+// the SUM (8 ranks of 2 M sequences at 2^-40: a cell could reach 2^64) or units that differ would wrap or mis-scale
+// silently; here they are an error on every rank at once.
+int verify_comm(bamm_em* em) {
+    if (!em->comm || em->comm_verified) return BAMM_OK;
+    uint32_t world = 1;
+    (void)bamm_comm_info(em->comm, nullptr, &world, nullptr);
+    if (world > 1) {
+        long long h[3] = {(long long)em->seqs->n, (long long)em->fix_shift, (long long)em->fix_shift * (long long)em->fix_shift};
+        long long* d = nullptr;
+        int rc = use_device(em->ctx);
+        if (!rc) rc = dev_alloc(&d, 3);
+        if (rc) return rc;
+        hipStream_t st = em->ctx->stream;
+        hipError_t e = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) rc = comm_allreduce_i64(em->comm, d, 3, st);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        if (rc) return rc;
+        if (e != hipSuccess) { set_error("accumulator-unit check over the communicator: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+        if ((long long)world * h[2] != h[1] * h[1]) {
+            set_error("the ranks' accumulator units differ (bamm_em_params.n_seqs_bound must be the same on every rank)");
+            return BAMM_ERR_ARG;
+        }
+        uint32_t bits = 0;
+        while ((uint64_t(1) << bits) < (uint64_t)h[0] && bits < 63u) bits++;
+        if (em->fix_shift > std::min(40u, 62u - std::min(bits, 38u))) {
+            set_error("%lld sequences over %u ranks need a coarser accumulator unit than 2^-%u: pass their number as "
+                      "bamm_em_params.n_seqs_bound on every rank", h[0], world, em->fix_shift);
+            return BAMM_ERR_ARG;
+        }
+    }
+    em->comm_verified = true;
+    return BAMM_OK;
+}
+
 }  // namespace
 
 namespace bamm {
@@ -841,16 +880,17 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     }
     const uint32_t Y = (uint32_t)ipow4(prm->K + 1);
     const size_t kLds = 160 * 1024;
-    const bool sliced = em_lds_bytes(prm->W, Y, true, 0, 0) > kLds;
+    bool sliced = em_lds_bytes(prm->W, Y, true, 0, 0) > kLds;
     uint32_t e_cols = 0, m_cols = 0;
+    // orders 7..10 (kmer_ spans 11 bases, Sequence.cpp:37): not even one column of the odds / count tables (4^(K+1) rows)
+    // fits the 160 KiB of a CU.  Those models run with their tables in global memory (long_seq.hip: every window
+    // multiplies its W odds straight from the table, the fixed-point addends go straight into the pass's
+    // accumulator) -- the same integers, written for coverage, not speed.
+    bool global_tables = false;
     if (sliced) {
         while (e_cols < prm->W && e_slice_lds_bytes(e_cols + 1, Y) <= kLds) e_cols++;
         while (m_cols < prm->W && m_slice_lds_bytes(m_cols + 1, Y, 0) <= kLds) m_cols++;
-        if (e_cols == 0 || m_cols == 0) {
-            set_error("K=%u: one column of the odds/count tables (%u rows) exceeds the 160 KiB LDS of a CU; "
-                      "orders above 6 are outside this build's envelope", prm->K, Y);
-            return BAMM_ERR_UNSUPPORTED;
-        }
+        if (e_cols == 0 || m_cols == 0) { global_tables = true; sliced = false; }
     }
     BAMM_HIP(hipSetDevice(c->device));
     bamm_em* em = new bamm_em();
@@ -942,9 +982,10 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     // takes (no exception, or all of them within its virtual rows) and the rest
     const bool want_grouped = !sliced && prm->K <= 3u && c->use_grouped;
     for (auto& b : seqs->buckets) {
-        if (b.mclass == kLongClass) {                        // beyond the length classes: long_seq.hip
+        if (b.mclass == kLongClass || global_tables) {       // beyond the length classes / tables beyond LDS: long_seq.hip
             EmBucket eb;
-            eb.mclass = kLongClass; eb.count = b.count; eb.d_idx = b.d_idx; eb.work = b.work;
+            eb.mclass = kLongClass; eb.count = b.count; eb.d_idx = b.d_idx;
+            eb.work = b.mclass == kLongClass ? b.work : (double)b.count * kMClasses[b.mclass];
             em->ebuckets.push_back(eb);
             continue;
         }
@@ -1082,9 +1123,12 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
 
 int bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
-    if (fn && !em->prm.n_seqs_bound && !em->prm.n_seqs_global && em->seqs->n > (uint64_t(1) << 21)) {
-        set_error("a shard of %llu sequences needs bamm_em_params.n_seqs_bound (the unit of the integer accumulator "
-                  "must be the same on every rank)", (unsigned long long)em->seqs->n);
+    // The int64 sums stay below 2^62 as long as (sequences summed over ALL ranks) x 2^fix_shift does; the unit was
+    // chosen from this handle's own count unless the caller named a bound.  A callback says nothing about the world
+    // behind it: up to 64 ranks of this size are assumed, beyond that the bound is required.
+    if (fn && !em->prm.n_seqs_bound && !em->prm.n_seqs_global && em->seqs->n > (uint64_t(1) << 16)) {
+        set_error("a shard of %llu sequences behind an all-reduce callback needs bamm_em_params.n_seqs_bound (all ranks together; "
+                  "the unit of the integer accumulator must be the same on every rank and sized for their sum)", (unsigned long long)em->seqs->n);
         return BAMM_ERR_ARG;
     }
     em->allreduce = fn;
@@ -1095,17 +1139,14 @@ int bamm_em_set_allreduce(bamm_em* em, bamm_allreduce_fn fn, void* user) {
 int bamm_em_set_comm(bamm_em* em, bamm_comm* comm) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
     if (comm && comm_ctx(comm) != em->ctx) { set_error("the communicator belongs to another context"); return BAMM_ERR_ARG; }
-    if (comm && !em->prm.n_seqs_bound && !em->prm.n_seqs_global && em->seqs->n > (uint64_t(1) << 21)) {
-        set_error("a shard of %llu sequences needs bamm_em_params.n_seqs_bound (the unit of the integer accumulator "
-                  "must be the same on every rank)", (unsigned long long)em->seqs->n);
-        return BAMM_ERR_ARG;
-    }
+    em->comm_verified = false;                                // checked with the peers in front of the first pass (verify_comm)
     em->comm = comm;
     return BAMM_OK;
 }
 
 int bamm_em_estep(bamm_em* em) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (int vrc = verify_comm(em)) return vrc;
     // s already reflects the current v (made at create / by the last update): E only
     int rc = run_accumulate(em, false);
     if (rc) return rc;
@@ -1118,6 +1159,7 @@ int bamm_em_estep(bamm_em* em) {
 
 int bamm_em_mstep(bamm_em* em) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (int vrc = verify_comm(em)) return vrc;
     if (!em->estep_done) { set_error("MStep needs the responsibilities of a preceding EStep"); return BAMM_ERR_STATE; }
     // the responsibilities are a pure function of (s, q), both unchanged since the EStep:
     // recompute them on the fly while accumulating counts instead of storing N*L floats
@@ -1183,6 +1225,7 @@ int bamm_em_update(bamm_em* em) {
 
 int bamm_em_iterate(bamm_em* em, uint32_t n) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (int vrc = verify_comm(em)) return vrc;
     em->events_used = 0; em->pass_no = 0;
     // fusable handles: the update of pass i runs in the prologue of pass i+1's first kernel (one launch and one
     // collective per iteration); the last pass's update is a k_update launch, so the handle is in the same state
@@ -1198,6 +1241,7 @@ int bamm_em_iterate(bamm_em* em, uint32_t n) {
 
 int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (int vrc = verify_comm(em)) return vrc;
     em->events_used = 0; em->pass_no = 0;
     if (iterations) *iterations = 0;
     const uint32_t max_it = em->prm.max_iterations;
@@ -1287,6 +1331,7 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
 
 int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint64_t* listed) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
+    if (int vrc = verify_comm(em)) return vrc;
     bamm_seqs* s = em->seqs;
     if (!(f > 0.0f && f < 1.0f)) { set_error("bamm_em_mask: fraction %g outside (0,1)", (double)f); return BAMM_ERR_ARG; }
     if (em->n_active == 0) { set_error("bamm_em_mask: no sequences (the reference indexes an empty array, EM.cpp:343)"); return BAMM_ERR_ARG; }
@@ -1299,6 +1344,8 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
         set_error("bamm_em_mask: the handle has already run E/M passes; the reference calls mask() on a fresh EM only");
         return BAMM_ERR_STATE;
     }
+    if (int rcc = use_device(em->ctx)) return rcc;
+    if (int rcc = clean_accumulator(em)) return rcc;          // sums nobody consumed (bamm_em_accumulate without an update, a getR replay)
     const size_t kLds = 160 * 1024;
     const uint32_t W = em->prm.W, Y = em->Y;
     const size_t wave_bytes = mask_wave_bytes(s->max_len);
@@ -1664,7 +1711,9 @@ int bamm_logodds_subset(bamm_ctx* c, bamm_seqs* s, const uint8_t* seq_mask, uint
         ScoreKernelArgs a{};
         a.sv = make_view(s, exc, bk, d_smask);
         a.K = K; a.W = W; a.Y = Y; a.s = d_tab; a.mops = d_mops; a.mops_off = d_moff; a.zoops = d_zoops; a.z = d_z;
-        if (bk.mclass == kLongClass) {
+        // beyond the length classes, or a log-odds table beyond the LDS of a CU (orders >= 6 at usual widths): the
+        // window-by-window scorer reads the table from global memory, same sums in the same order
+        if (bk.mclass == kLongClass || (size_t)W * Ys * sizeof(float) > 160u * 1024u) {
             rc = launch_long_score(a, std::min(bk.count, (uint32_t)std::max(1, c->num_cus) * 8u), st);
             continue;
         }

@@ -69,6 +69,17 @@ def test_hip_path_matches_reference_golden(name, gpu_ctx, orc):
         if it == it_ref:
             np.testing.assert_allclose(em.getQ(), g[f"opt{oq}_q"], rtol=2e-4)    # N1 is a serial fp32 sum in the reference
             np.testing.assert_allclose(em.getV(), g[f"opt{oq}_v"], rtol=1e-3, atol=1e-7)
+        elif it > it_ref:
+            # the reference stopped earlier ("llh decreased" on its own fp32 llh noise, profiles/r02_iteration_counts.txt):
+            # its final model is still the model of pass it_ref -- compared with this path's model after the same passes
+            em2 = bm.EM(gpu_ctx, ss, c.K, c.W, g["vbg"], c.A, c.v0, c.q, bg_order=c.bg_order, optimizeQ=bool(oq),
+                        max_iterations=it_ref)
+            em2.iterate(it_ref)
+            # (a model still moving by v_diff ~ 2 per pass after 26 passes over 24 long sequences: what separates the two
+            # fp32 / exact trajectories is amplified pass after pass -- 4e-3 relative on 4 % of the cells, 2e-4 absolute)
+            np.testing.assert_allclose(em2.getQ(), g[f"opt{oq}_q"], rtol=1e-3)
+            np.testing.assert_allclose(em2.getV(), g[f"opt{oq}_v"], rtol=1e-2, atol=5e-4)
+            em2.close()
         em.close()
     ss.close()
 

@@ -408,6 +408,48 @@ def test_shapes_and_length_buckets(spec, gpu_ctx, orc):
     em.close(); ss.close()
 
 
+HIGH_ORDER_CASES = [
+    dict(name="k7_w5", N=40, L0=70, W=5, K=7, ragged=15, n_frac=0.01),
+    dict(name="k8_w3_ss", N=30, L0=90, W=3, K=8, ss=True, ragged=10),
+    dict(name="k10_w2", N=12, L0=60, W=2, K=10, ragged=8, n_frac=0.02),
+]
+
+
+@pytest.mark.parametrize("spec", HIGH_ORDER_CASES, ids=[d["name"] for d in HIGH_ORDER_CASES])
+def test_orders_beyond_the_lds_envelope(spec, gpu_ctx, orc):
+    """Orders 7..10 (kmer_ spans 11 bases, Sequence.cpp:37; BaMM files go to order 8, MotifSet.cpp:202-205): not one
+    column of the 4^(K+1)-row tables fits a CU's LDS, so the pass runs with its tables in global memory
+    (csrc/long_seq.hip).  E-step, M-step, updateV, getR and the scorer against the oracle, as for every other order."""
+    c = Case(**spec)
+    em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
+    Kb = min(c.bg_order, c.K)
+    for it in range(2):
+        v, q = em.getV(), em.getQ()
+        em.EStep()
+        s_o = orc.linear_s(v, vbg, c.K, c.W, Kb)
+        assert np.array_equal(em.getS(), s_o)
+        r_o, llh_o = orc.estep(kmer, off, c.K, c.W, s_o, q)
+        np.testing.assert_allclose(em.getR(), r_o, rtol=R_RTOL, atol=R_ATOL)
+        np.testing.assert_allclose(em.getLLH(), llh_o, rtol=LLH_RTOL, atol=5e-7 * c.N)
+        em.MStep()
+        n_o = orc.mstep_counts(kmer, off, c.K, c.W, r_o)
+        np.testing.assert_allclose(em.getCounts(), n_o, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(em.getV(), orc.update_v(n_o, c.A, vbg, c.K, c.W), rtol=V_RTOL, atol=1e-9)
+    em.close()
+    em, ss2, *_ = make_em(gpu_ctx, c, orc, optimizeQ=True)     # EM::optimize's loop (q re-estimated in its first passes)
+    em.iterate(4)
+    assert em.iteration() == 4
+    res = orc.optimize(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, optimizeQ=True, epsilon=0.0, max_iter=4)
+    np.testing.assert_allclose(em.getV(), res["v"], rtol=5e-5, atol=1e-8)
+    np.testing.assert_allclose(em.getQ(), res["q"], rtol=1e-5)
+    ss2.close()
+    v = em.getV()
+    mops_o, zoops_o, z_o = orc.logodds(kmer, off, c.K, c.W, orc.log_s(v, vbg, c.K, c.W, Kb))
+    mops, zoops, z = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, v, vbg)
+    assert np.array_equal(mops, mops_o) and np.array_equal(zoops, zoops_o) and np.array_equal(z, z_o)
+    em.close(); ss.close()
+
+
 LONG_SPECS = [EXTRA_SHAPES[-2], EXTRA_SHAPES[-1], SLICED_CASES[1]]
 
 
