@@ -73,7 +73,8 @@ struct bamm_ctx {
     bool own_stream = false;
     uint32_t blocks = 0, threads = 0;   // 0 = default
     // bamm_ctx_set_tuning: kernel-selection switches for benchmarks and the cross-kernel parity tests
-    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true, use_fused_update = true;
+    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true, use_fused_update = true, use_adaptive_lists = true;
+    uint32_t list_threshold_pct = 45;   // sliced path: a pass takes lists when fewer than this share of the windows was non-zero in the pass before
     uint32_t group_size = 0;            // 0 = planner's choice
     int group_layout = -1;              // -1 = planner's choice
     int num_cus = 0;
@@ -178,6 +179,11 @@ struct bamm_em {
     float* d_list_r = nullptr;
     uint16_t* d_list_p = nullptr;
     uint32_t* d_list_n = nullptr;
+    // ... or dense r, chosen per pass on the device: [2] counts of windows with a non-zero addend (the pass before, this pass)
+    unsigned long long* d_nnz = nullptr;
+    uint32_t nnz_prev_slot = 0;
+    unsigned long long nnz_limit = 0;           // above it a pass takes the dense flavour
+    bool adaptive_lists = true;                 // bamm_ctx_set_tuning("adaptive_lists") when the handle was created
     // K = 3 through the grouped kernel: per-wave log of the virtual rows' counts (grouped_kernel.h), grown on demand
     unsigned long long* d_fix_log = nullptr;
     size_t fix_log_words = 0;
@@ -441,6 +447,8 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
     const bool fusing = fuse_q_window >= 0;
     if (fusing) prepare_update(em, fuse_q_window != 0, true, fuse);     // consumes the previous pass's sums on the stream
     else if ((rc = clean_accumulator(em))) return rc;
+    if (em->d_nnz && accum)                                   // sliced path: this pass's count of non-zero windows starts at 0
+        BAMM_HIP(hipMemsetAsync(em->d_nnz + (em->nnz_prev_slot ^ 1u), 0, sizeof(unsigned long long), st));
     if ((rc = record_event(em, true))) return rc;
     for (size_t b = 0; b < em->ebuckets.size(); b++) {
         const EmBucket& bk = em->ebuckets[b];
@@ -472,47 +480,66 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
             // in LDS (the E pass is k_em_seq) and a wave's copy of the decoded sequence fits beside the count slice
             const bool lists = em->e_fused && em->d_list_r && !dense_r &&
                                m_list_lds_bytes(widest, em->Y, em->m_slice_logc, kMClasses[bk.mclass], threads / 64u) <= 160u * 1024u;
-            if (!lists && !em->d_state) {
+            // ... and per pass, decided on the device: while the model is uninformative every window has a non-zero
+            // addend and the list walk costs far more than the dense one (config 4, pass 1: 26.5 against 15.4 ms,
+            // profiles/r03_c4_cold_passes.txt).  Both flavours of the pass are enqueued; the count the previous pass's
+            // E kernel took picks the one that runs (the other's launches return at entry).
+            const bool adaptive = lists && accum && em->d_nnz && em->adaptive_lists;
+            if ((!lists || adaptive) && !em->d_state) {
                 if ((rc = dev_alloc(&em->d_state, (size_t)s->total_len))) return rc;
             }
-            a.r_out = em->d_state;
-            if (em->e_fused) {
-                // the whole odds table fits LDS (only the count table does not): the fused kernel's E
-                // pass, leaving r in the reference's layout (k_em_seq WRITE_R) or the lists
-                a.seq_end = (uint32_t)s->n;
-                a.logC = 0; a.sparse_cap = 0; a.sparse_wave_bytes = 0;
-                if (lists) { a.list_r = em->d_list_r; a.list_p = em->d_list_p; a.list_n = em->d_list_n; }
-                rc = launch_em_seq(bk.mclass, false, true, a, bk.blocks, threads, st);
-                if (lists) {
-                    a.logC = em->m_slice_logc;
-                    for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
-                        rc = launch_m_list(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second, bk.blocks, threads, st);
-                    if (rc) return rc;
-                    continue;
+            auto flavour = [&](bool use_lists, int run_if_long) -> int {   // run_if_long: -1 = unconditional
+                EmKernelArgs f = a;
+                int r = BAMM_OK;
+                f.r_out = em->d_state;
+                if (run_if_long >= 0) {
+                    f.nnz_prev = em->d_nnz + em->nnz_prev_slot; f.nnz_limit = em->nnz_limit; f.run_if_long = (uint32_t)run_if_long;
                 }
+                if (em->d_nnz && accum) f.nnz_out = em->d_nnz + (em->nnz_prev_slot ^ 1u);
+                if (em->e_fused) {
+                    // the whole odds table fits LDS (only the count table does not): the fused kernel's E
+                    // pass, leaving r in the reference's layout (k_em_seq WRITE_R) or the lists
+                    f.seq_end = (uint32_t)s->n;
+                    f.logC = 0; f.sparse_cap = 0; f.sparse_wave_bytes = 0;
+                    if (use_lists) { f.list_r = em->d_list_r; f.list_p = em->d_list_p; f.list_n = em->d_list_n; }
+                    r = launch_em_seq(bk.mclass, false, true, f, bk.blocks, threads, st);
+                    if (use_lists) {
+                        f.logC = em->m_slice_logc;
+                        for (size_t i = 0; accum && i < em->m_slices.size() && !r; i++)
+                            r = launch_m_list(bk.mclass, f, em->m_slices[i].first, em->m_slices[i].second, bk.blocks, threads, st);
+                        return r;
+                    }
+                } else {
+                    for (size_t i = 0; i < em->e_slices.size() && !r; i++)
+                        r = launch_e_slice(bk.mclass, f, em->e_slices[i].first, em->e_slices[i].second,
+                                           i + 1 == em->e_slices.size(), bk.blocks, threads, st);
+                }
+                f.logC = em->m_slice_logc;
+                {   // this bucket's list capacity: what fits next to the widest slice's count table
+                    const size_t table = m_slice_lds_bytes(widest, em->Y, em->m_slice_logc);
+                    uint32_t cap = em->m_slice_cap;
+                    while (cap && table + (threads / 64u) * m_slice_wave_bytes(kMClasses[bk.mclass], cap) > 160u * 1024u) cap -= 64u;
+                    f.sparse_cap = cap;
+                    f.sparse_wave_bytes = (uint32_t)m_slice_wave_bytes(kMClasses[bk.mclass], cap);
+                }
+                for (size_t i = 0; accum && i < em->m_slices.size() && !r; i++)
+                    r = launch_m_slice(bk.mclass, f, em->m_slices[i].first, em->m_slices[i].second, em->e_fused,
+                                       bk.blocks, threads, st);
+                return r;
+            };
+            if (adaptive) {
+                rc = flavour(false, 1);                      // dense r while the lists would be long
+                if (!rc) rc = flavour(true, 0);
             } else {
-                for (size_t i = 0; i < em->e_slices.size() && !rc; i++)
-                    rc = launch_e_slice(bk.mclass, a, em->e_slices[i].first, em->e_slices[i].second,
-                                        i + 1 == em->e_slices.size(), bk.blocks, threads, st);
+                rc = flavour(lists, -1);
             }
-            a.logC = em->m_slice_logc;
-            const uint32_t mthreads = threads;
-            {   // this bucket's list capacity: what fits next to the widest slice's count table
-                const size_t table = m_slice_lds_bytes(widest, em->Y, em->m_slice_logc);
-                uint32_t cap = em->m_slice_cap;
-                while (cap && table + (mthreads / 64u) * m_slice_wave_bytes(kMClasses[bk.mclass], cap) > 160u * 1024u) cap -= 64u;
-                a.sparse_cap = cap;
-                a.sparse_wave_bytes = (uint32_t)m_slice_wave_bytes(kMClasses[bk.mclass], cap);
-            }
-            for (size_t i = 0; accum && i < em->m_slices.size() && !rc; i++)
-                rc = launch_m_slice(bk.mclass, a, em->m_slices[i].first, em->m_slices[i].second, em->e_fused,
-                                    bk.blocks, mthreads, st);
         }
         if (rc) return rc;
     }
     rc = record_event(em, false);
     if (rc) return rc;
     if (!replay_last) { em->s_last = em->d_s; em->q_last = em->d_q; em->mask_done = false; }
+    if (em->d_nnz && accum) em->nnz_prev_slot ^= 1u;          // the next pass chooses from what this one counted
     em->acc_dirty = true;                                     // until the update (or the E-only read-out) has consumed it
     return BAMM_OK;
 }
@@ -740,6 +767,11 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
     else if (k == "e_fused") c->use_e_fused = value != 0;
     else if (k == "e_list") c->use_e_list = value != 0;
     else if (k == "fused_update") c->use_fused_update = value != 0;
+    else if (k == "adaptive_lists") c->use_adaptive_lists = value != 0;
+    else if (k == "list_threshold_pct") {
+        if (value < 0 || value > 100) { set_error("list_threshold_pct must be 0..100"); return BAMM_ERR_ARG; }
+        c->list_threshold_pct = (uint32_t)value;
+    }
     else if (k == "group_size") {
         if (value != 0 && (value < 2 || value > 4)) { set_error("group_size must be 0 (auto) or 2..4"); return BAMM_ERR_ARG; }
         c->group_size = (uint32_t)value;
@@ -850,7 +882,7 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_acc_ring,
-                    (void*)em->d_v_alt, (void*)em->d_llh[0], (void*)em->d_s_block,
+                    (void*)em->d_v_alt, (void*)em->d_llh[0], (void*)em->d_s_block, (void*)em->d_nnz,
                     (void*)em->d_state, (void*)em->d_list_r, (void*)em->d_list_p, (void*)em->d_list_n, (void*)em->d_s_alt, (void*)em->d_fix_log,
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
@@ -1112,6 +1144,16 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         if ((rc = dev_alloc(&em->d_list_r, (size_t)seqs->total_len)) || (rc = dev_alloc(&em->d_list_p, (size_t)seqs->total_len)) ||
             (rc = dev_alloc(&em->d_list_n, (size_t)seqs->n))) return fail(rc);
         if (hipMemsetAsync(em->d_list_n, 0, (seqs->n ? seqs->n : 1) * sizeof(uint32_t), st) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(BAMM_ERR_HIP); }
+        // lists or dense r, per pass: the first pass of a handle takes the dense flavour (nothing is known yet: the
+        // counter starts saturated), later ones lists once fewer than list_threshold_pct of the windows are non-zero
+        if ((rc = dev_alloc(&em->d_nnz, 2))) return fail(rc);
+        const unsigned long long start[2] = {~0ull, 0ull};
+        if (hipMemcpyAsync(em->d_nnz, start, sizeof start, hipMemcpyHostToDevice, st) != hipSuccess) { set_error("hipMemcpyAsync failed"); return fail(BAMM_ERR_HIP); }
+        unsigned long long windows = 0;
+        for (uint64_t n = 0; n < seqs->n; n++) windows += seqs->h_len[n] - prm->W + 1u;
+        if (seq_mask && seqs->n) windows = (unsigned long long)((double)windows * (double)em->n_active / (double)seqs->n);
+        em->nnz_limit = windows / 100u * c->list_threshold_pct;
+        em->adaptive_lists = c->use_adaptive_lists;
     }
     if ((rc = launch_make_s(em->d_v, em->d_vbg, prm->K, prm->W, em->Kbg, em->d_s, st))) return fail(rc);
     em->s_last = em->d_s;

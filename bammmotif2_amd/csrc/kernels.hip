@@ -89,6 +89,7 @@ __device__ __forceinline__ void dense_count_walk(uint32_t ncols, uint32_t col, u
 template <int M, bool ACCUM, bool WRITE_R, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
     if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+    if (a.nnz_prev != nullptr && ((*a.nnz_prev > a.nnz_limit) != (a.run_if_long != 0u))) return;   // the pass's other flavour runs
 
     extern __shared__ __align__(16) float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u;
@@ -131,6 +132,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0;
+    [[maybe_unused]] unsigned long long nnz_acc = 0ull;   // windows with a non-zero addend (sliced path: next pass's lists-or-dense choice)
 
     for (; t < a.sv.count; t += total_waves) {
         const RawSeq<M> cur = nxt;
@@ -239,7 +241,12 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
                 nnz += (uint32_t)__popcll(mask);
             }
             if (lane == 0) a.list_n[seq] = nnz;
+            nnz_acc += nnz;
         } else if (WRITE_R) {                            // EM::getR layout: r[L-W-i], i = p-W+1
+            if (a.nnz_out != nullptr) {
+#pragma unroll
+                for (int m = 0; m < M; m++) nnz_acc += (uint32_t)__popcll(__ballot(U[m] * a.fix_scale >= 0x1p-40f));
+            }
             float* ro = a.r_out + (a.sv.pos_off[seq] - a.r_base);
             bool done = false;
             if constexpr (M % 4 == 0) {
@@ -341,6 +348,8 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
 
     // ---- block epilogue: this block's table and statistics into the pass's accumulator
     lds_drain();
+    if constexpr (WRITE_R)
+        if (a.nnz_out != nullptr && lane == 0 && nnz_acc != 0ull) (void)__hip_atomic_fetch_add(a.nnz_out, nnz_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
         stat_lds[wave * 3 + 1] = sumr_acc;
@@ -455,6 +464,7 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0, uint32_t j1, int r_reversed) {
     if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+    if (a.nnz_prev != nullptr && ((*a.nnz_prev > a.nnz_limit) != (a.run_if_long != 0u))) return;   // the pass's other flavour runs
 
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;
@@ -573,6 +583,7 @@ __global__ void __launch_bounds__(THREADS) k_m_slice(EmKernelArgs a, uint32_t j0
 template <int M, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0, uint32_t j1) {
     if (a.stop != nullptr && *a.stop != 0u) return;      // optimize(): the stop rule fired in an earlier pass
+    if (a.nnz_prev != nullptr && ((*a.nnz_prev > a.nnz_limit) != (a.run_if_long != 0u))) return;   // the pass's other flavour runs
 
     extern __shared__ float lds[];
     const uint32_t W = a.W, Y = a.Y, Ys = a.Y + 1u, nc = j1 - j0, logC = a.logC;

@@ -192,6 +192,8 @@ def kernel_label(em, K):
 
 
 def git_head():
+    if os.environ.get("BAMM_COMMIT"):                # the GPU box has no .git: the launcher passes the hash
+        return os.environ["BAMM_COMMIT"]
     try:
         import subprocess
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None

@@ -129,6 +129,9 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
  *   "e_fused"      1/0  sliced path: whole-table E pass when the odds table fits LDS (default 1)
  *   "e_list"       1/0  sliced path: the E pass hands the M slices compacted lists of the non-zero
  *                       windows instead of all responsibilities (default 1)
+ *   "adaptive_lists" 1/0  sliced path: per pass, lists or dense r between the E pass and the M slices, chosen on the
+ *                       device from the previous pass's count of non-zero windows (default 1; 0 = always lists)
+ *   "list_threshold_pct" 0..100  ... lists when fewer than this percentage of the windows was non-zero (default 45)
  *   "fused_update" 1/0 inside iterate() / optimize() the model update of pass p runs in the block prologue of
  *                       pass p+1's first kernel instead of a launch of its own (default 1; K <= 2-sized tables)
  * There are no environment variables that change what the library computes or launches.          */

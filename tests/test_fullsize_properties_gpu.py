@@ -106,7 +106,11 @@ def test_full_size_invariants_c4(gpu_ctx):
     cells = 4 ** (K + 1) * W
 
     whole = bm.SeqSet(gpu_ctx, pk)
-    em = bm.EM(gpu_ctx, whole, K, W, vbg, A, v0, 0.3, max_iterations=40)
+    gpu_ctx.set_tuning(adaptive_lists=0)                      # lists in every pass: pass 1 is their worst case
+    try:
+        em = bm.EM(gpu_ctx, whole, K, W, vbg, A, v0, 0.3, max_iterations=40)
+    finally:
+        gpu_ctx.set_tuning(adaptive_lists=1)
     g, o, launches = em.plan()
     assert g == 0 and o == N                                  # the sliced path, one length class
 
@@ -136,18 +140,23 @@ def test_full_size_invariants_c4(gpu_ctx):
         return buf
 
     check(em, v0, 0.3, "from the seed")                       # pass 1: the longest lists
-    # the dense walk (round-1 path: all responsibilities through HBM, no lists) adds the same integers
+    # the dense walk (round-1 path, no lists) and the default handle (lists or dense r per pass, chosen on the
+    # device: dense in pass 1) add the same integers, pass after pass
     gpu_ctx.set_tuning(e_list=0)
     try:
         dense = bm.EM(gpu_ctx, whole, K, W, vbg, A, v0, 0.3, max_iterations=4)
     finally:
         gpu_ctx.set_tuning(e_list=1)
-    dense.accumulate(); em.accumulate()
-    assert np.array_equal(read_buffer(dense, gpu_ctx)[:cells], read_buffer(em, gpu_ctx)[:cells])
+    auto = bm.EM(gpu_ctx, whole, K, W, vbg, A, v0, 0.3, max_iterations=40)
+    dense.accumulate(); em.accumulate(); auto.accumulate()
+    first = read_buffer(em, gpu_ctx)[:cells]
+    assert np.array_equal(read_buffer(dense, gpu_ctx)[:cells], first) and np.array_equal(read_buffer(auto, gpu_ctx)[:cells], first)
     dense.close()
-    em.update()
-    em.iterate(11)
+    em.update(); auto.update()
+    em.iterate(11); auto.iterate(11)
     v12, q12 = em.getV(), em.getQ()
+    assert np.array_equal(auto.getV(), v12)                   # whichever flavour each pass took
+    auto.close()
     check(em, v12, q12, "after 12 passes")
     em.update()
     v, n = em.getV(), em.getCounts()

@@ -179,21 +179,24 @@ def test_sliced_path_for_large_tables(spec, gpu_ctx, orc):
 @pytest.mark.parametrize("spec", SLICED_CASES[:3], ids=[d["name"] for d in SLICED_CASES[:3]])
 def test_sliced_paths_agree_bit_for_bit(spec, gpu_ctx, orc):
     """k >= 4 with the whole odds table in LDS: the E pass hands the M slices compacted lists of the windows with a
-    non-zero fixed-point addend (default) or all responsibilities (e_list = 0); with e_fused = 0 the E chain itself
-    is cut into column ranges.  The two whole-table variants add the same integers: identical counts."""
+    non-zero fixed-point addend (adaptive_lists = 0: in every pass; default: chosen per pass on the device from the
+    previous pass's count of non-zero windows, the first pass dense) or all responsibilities (e_list = 0); with
+    e_fused = 0 the E chain itself is cut into column ranges.  The whole-table variants add the same integers: identical counts."""
     c = Case(**spec)
     res = {}
-    for tag, tune in (("list", {}), ("dense", dict(e_list=0)), ("e_sliced", dict(e_fused=0))):
+    for tag, tune in (("list", dict(adaptive_lists=0)), ("adaptive", {}), ("never_lists", dict(list_threshold_pct=0)),
+                      ("lists_from_pass_2", dict(list_threshold_pct=100)), ("dense", dict(e_list=0)), ("e_sliced", dict(e_fused=0))):
         gpu_ctx.set_tuning(**tune)
         try:
             em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, optimizeQ=True)
         finally:
-            gpu_ctx.set_tuning(e_list=1, e_fused=1)
+            gpu_ctx.set_tuning(e_list=1, e_fused=1, adaptive_lists=1, list_threshold_pct=45)
         em.iterate(3)
         res[tag] = (em.getCounts(), em.getV(), em.getQ(), em.trace()[0], em.getR())
         em.close(); ss.close()
-    for k in range(5):
-        assert np.array_equal(res["list"][k], res["dense"][k]), k
+    for tag in ("dense", "adaptive", "never_lists", "lists_from_pass_2"):
+        for k in range(5):
+            assert np.array_equal(res["list"][k], res[tag][k]), (tag, k)
     np.testing.assert_allclose(res["list"][1], res["e_sliced"][1], rtol=2e-6, atol=1e-10)
     np.testing.assert_allclose(res["list"][4], res["e_sliced"][4], rtol=1e-5, atol=1e-12)
 

@@ -1,10 +1,10 @@
 #!/bin/bash
 # One GPU call that refreshes the judged files for the bench workload (config 3) and for config 4:
 #   bench line, rocprofv3 kernel stats of the same command, PMC passes + LDS ceiling (tools/pmc_run.sh).
-# Usage (GPU box): bash tools/profile_round.sh rNN     ->  gpurun_out/rNN_*  (copy into profiles/)
+# Usage (GPU box): BAMM_COMMIT=<hash> bash tools/profile_round.sh rNN     ->  gpurun_out/rNN_*  (copy into profiles/)
 set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
-tag=${1:-r02}
+tag=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof
 # PMC first: bench.py picks the summary up from profiles/ (same commit) or gpurun_out/ (this call)

@@ -22,6 +22,7 @@ ap.add_argument("positions", type=int)
 ap.add_argument("--order", type=int, default=2)
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "hbm_traffic.json"))
 ap.add_argument("--lds-mix", default=None)
+ap.add_argument("--commit", default=os.environ.get("BAMM_COMMIT"), help="git commit the counters were taken at (the GPU box has no .git)")
 args = ap.parse_args()
 
 acc = defaultdict(lambda: defaultdict(list))
@@ -86,5 +87,6 @@ if args.lds_mix and os.path.exists(args.lds_mix):
                 res["lds_mix_bench"]["uniform_rows_wave_instr_per_s"] = res["lds_mix_bench"]["wave_instr_per_s"]
                 res["lds_mix_bench"]["wave_instr_per_s"] = res["lds_mix_bench"]["mixed_rows_wave_instr_per_s"]
                 res["lds_mix_bench"]["what"] = res["lds_mix_bench"]["mixed_rows_what"]
+res["commit"] = args.commit
 json.dump(res, open(args.out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_mean_counters"}))
