@@ -57,9 +57,19 @@ constexpr double kLlhScale = 16777216.0, kSumrScale = 1073741824.0;
 __device__ __forceinline__ void acc_add(long long* cell, long long v) {
     (void)__hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The sequence count shares its word with a count of blocks whose statistics were not finite (log Z of a Z = 0 at
+// q = 1, NaN odds from a degenerate model: the fp64 sums carry them, an integer cannot): bits 40.. of the word.  The
+// update turns a non-zero count back into NaN for llh, which is what the reference's float sum would hold.
+constexpr long long kStatBadUnit = 1ll << 40;
+__device__ __forceinline__ double stat_nseq(long long word) { return (double)(word & (kStatBadUnit - 1ll)); }
+__device__ __forceinline__ bool stat_bad(long long word) { return (word >> 40) != 0ll; }
 // a block's three statistics (threads 0..2 call this with their own k)
 __device__ __forceinline__ void acc_add_stat(long long* acc, uint32_t cells, uint32_t k, double v) {
     const double scaled = k == 0u ? v * kLlhScale : (k == 1u ? v * kSumrScale : v);
+    if (k < 2u && !(fabs(scaled) < 9.0e18)) {              // inf, NaN, or beyond int64: flagged, not converted
+        acc_add(acc + cells + 2u, kStatBadUnit);
+        return;
+    }
     acc_add(acc + cells + k, __double2ll_rn(scaled));
 }
 // 128-bit LDS gather.  hipcc splits a float4 LDS load whose components are consumed under

@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         (void)model_update_lds<true>(a, upd_lds, nullptr, true);
     } else {
     __shared__ double shd[16];
-    __shared__ double stat3[3];
+    __shared__ double stat3[4];                            // llh, sum_r, n_seqs, non-finite flag
     const uint32_t K = a.K, W = a.W;
     const uint32_t YK = 1u << (2 * (K + 1));
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -802,6 +802,7 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
 
     // order-K counts from the (all-reduced) integer accumulator, which is left zeroed for the next pass
     float* nK = n + voff(K);
+    if (tid == 3) stat3[3] = 0.0;
     for (uint32_t i = tid; i < YK * W; i += nt) {
         nK[i] = (float)((double)a.acc[i] * a.count_unit);
         a.acc[i] = 0ll;
@@ -809,7 +810,8 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
     if (tid < 3) {
         const long long x = a.acc[(size_t)YK * W + tid];
         a.acc[(size_t)YK * W + tid] = 0ll;
-        stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : (double)x);
+        stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : stat_nseq(x));
+        if (tid == 2 && stat_bad(x)) stat3[3] = 1.0;      // some block's statistics were not finite
     }
     if (a.acc_zero != nullptr)
         for (uint32_t i = tid; i < YK * W + 3u; i += nt) a.acc_zero[i] = 0ll;
@@ -885,7 +887,7 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         }
     }
     if (tid == 0) {
-        const double llh = stat3[0], sum_r = stat3[1];
+        const double llh = stat3[3] != 0.0 ? (double)NAN : stat3[0], sum_r = stat3[1];
         const double nseq = a.n_seqs_override > 0.0 ? a.n_seqs_override : stat3[2];
         const uint32_t it = *a.iteration + 1u;
         *a.iteration = it;
@@ -922,7 +924,8 @@ __global__ void k_stat_only(long long* acc, uint32_t cells, float* status) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         status[0] = (float)((double)acc[cells + 0] / kLlhScale);
         status[4] = (float)((double)acc[cells + 1] / kSumrScale);
-        status[5] = (float)acc[cells + 2];
+        status[5] = (float)stat_nseq(acc[cells + 2]);
+        if (stat_bad(acc[cells + 2])) status[0] = NAN;
         acc[cells + 0] = 0ll; acc[cells + 1] = 0ll; acc[cells + 2] = 0ll;
     }
 }

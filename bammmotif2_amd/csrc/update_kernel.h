@@ -49,12 +49,13 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
     float* const Al = n + vsz;                                       // [(K+1) * W]
     float* const bl = Al + ((nA + 1u) & ~1u);                        // vbg, orders 0..Kbg
     double* const shd = reinterpret_cast<double*>(n + ((vsz + 1) & ~size_t(1)) + ((nA + 1u) & ~1u) + ((nB + 1u) & ~1u));   // [16] v_diff partials, [3] statistics
-    double* const stat3 = shd + 16;
+    double* const stat3 = shd + 16;                                  // llh, sum_r, n_seqs, [3] = non-finite flag
     const float* const v_old = a.v_old ? a.v_old : a.v;             // the model the pass ran with (v_diff)
     long long* const acc = a.acc;
     const bool want_diff = writer || a.stop != nullptr;              // block-uniform
 
     // ---- phase A
+    if (tid == 0) stat3[3] = 0.0;
     const float q_in = *a.q;                                         // issued with the other loads of the update, used last
     const float llh_before = (a.stop != nullptr && a.llh_prev_from_status) ? *a.llh_in : a.llh_prev;
     float* nK = n + voff(K);
@@ -67,7 +68,8 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
     if (tid < 3) {
         const long long x = acc[(size_t)YK * W + tid];
         if (CONSUME) acc[(size_t)YK * W + tid] = 0ll;
-        stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : (double)x);
+        stat3[tid] = tid == 0 ? (double)x / kLlhScale : (tid == 1 ? (double)x / kSumrScale : stat_nseq(x));
+        if (tid == 2 && stat_bad(x)) stat3[3] = 1.0;      // some block's statistics were not finite
     }
     if (writer && a.acc_zero != nullptr)                             // the ring slot two passes ahead
         for (uint32_t i = tid; i < YK * W + 3u; i += nt) a.acc_zero[i] = 0ll;
@@ -166,7 +168,7 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
         for (uint32_t w = 0; w < (nt + 63u) / 64u; w++) v_diff += shd[w];      // same order in every thread
     }
     UpdateOut out;
-    const double llh = stat3[0], sum_r = stat3[1];
+    const double llh = stat3[3] != 0.0 ? (double)NAN : stat3[0], sum_r = stat3[1];
     const double nseq = a.n_seqs_override > 0.0 ? a.n_seqs_override : stat3[2];
     float q = q_in;
     if (a.optimize_q)                                                // EM.cpp:515; the host applies EM.cpp:99's `iteration <= 5`
