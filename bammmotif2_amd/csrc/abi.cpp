@@ -268,7 +268,7 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
 }
 
 // records of the grouped kernel for group size G (built once per (order, G)): x = first exception
-// position | B << 12, y/z/w = exact y of the positions lo-G+1 .. lo+B-1, 7 bits each, 4 per word
+// position | B << 12, y/z/w = exact y of the positions lo-G+1 .. lo+B-1, one bit string of 7-bit fields (10 at K = 3)
 int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XRec** out) {
     std::lock_guard<std::mutex> lock(s->mu);
     auto it = k->xrec.find(G);
@@ -308,8 +308,11 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
                 while (e < e1 && (int64_t)k->h_ex[e].x < pos) e++;
                 y = (e < e1 && (int64_t)k->h_ex[e].x == pos) ? k->h_ex[e].y : stream_y(n, pos);
             }
-            if (K == 3u) w3[i / 3u] |= y << (10u * (i % 3u));
-            else w3[i >> 2] |= y << (7u * (i & 3u));
+            // the fields form ONE bit string over the three words, 7 bits each (10 at K = 3), field i at bit i * width:
+            // a fix lane's consecutive fields are a single funnel shift of two neighbouring words (grouped_kernel.h: xrec_fields)
+            const uint32_t bit = (K == 3u ? 10u : 7u) * i, wd = bit >> 5, sh = bit & 31u;
+            w3[wd] |= y << sh;
+            if (sh + (K == 3u ? 10u : 7u) > 32u) w3[wd + 1u] |= y >> (32u - sh);
         }
         xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
     }

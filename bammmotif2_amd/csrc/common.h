@@ -168,7 +168,8 @@ struct GrpKernelArgs {
     EmKernelArgs e;
     GrpGeom g;
     const uint4* xrec;           // per sequence: x = lo | B<<12 (group ends lo..lo+B-1 need a virtual row), y/z/w = exact y of
-                                 // the positions lo-G+1.., 7 bits each, 4 per word (the value Y = position before the sequence)
+                                 // the positions lo-G+1.., ONE bit string of 7-bit fields (10-bit at K = 3; the value Y =
+                                 // position before the sequence)
     // K = 3, accumulating pass: the non-zero sums the fix lanes took out of their virtual count rows, logged per
     // wave (8-byte entries: grouped_kernel.h, GrpLogEntry) and folded into single-column bins in the block epilogue
     unsigned long long* fix_log;

@@ -128,6 +128,19 @@ __device__ __forceinline__ RawSeqG<M> fetch_seq_g(const SeqView& sv, const uint4
     return r;
 }
 
+// The sequence record's y fields (GrpKernelArgs::xrec: one bit string over the words y, z, w, FB bits per field): 32 bits
+// of it starting at field k0.  A fix lane's G consecutive fields come out of ONE funnel shift of two neighbouring
+// words -- the per-field word selects it replaces hung on eight loop-invariant lane masks that hipcc kept in SGPRs,
+// spilled, and fetched back with 16 v_readlane per sequence.
+template <int FB>
+__device__ __forceinline__ uint32_t xrec_fields(uint32_t wy, uint32_t wz, uint32_t ww, uint32_t k0) {   // by value: no stack copy of the record
+    const uint32_t o = (uint32_t)FB * k0;
+    const bool first = o < 32u, second = o < 64u;
+    const uint32_t lo = first ? wy : (second ? wz : ww);
+    const uint32_t hi = first ? wz : (second ? ww : 0u);
+    return __builtin_amdgcn_alignbit(hi, lo, o & 31u);
+}
+
 // One step of the E-step chain: slots move up by G, the G lowest come from the previous lane.
 template <int M, int G>
 __device__ __forceinline__ void grp_step(float (&U)[M], const float (&f)[M]) {
@@ -334,7 +347,18 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 
     for (; t < a.sv.count; t += total_waves) {
         const RawSeqG<M> cur = nxt;
-        if (t + total_waves < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t + total_waves, lane);   // prefetch
+        if (t + total_waves < a.sv.count) {                  // prefetch
+            // the sequence set's pointers are read again from the kernel-argument segment (scalar loads) instead of
+            // living in SGPRs across the loop body: what hipcc spills of them it fetches back with v_readlane, VALU
+            // instructions of a VALU-bound loop (mixed_kernel.h: 0.853 -> 0.842 ms per pass)
+            const __attribute__((address_space(4))) GrpKernelArgs* kp =
+                (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));                     // opaque per iteration: the loads are not hoisted out of the loop
+            SeqView sv2;
+            sv2.words = kp->e.sv.words; sv2.word_off = kp->e.sv.word_off; sv2.len = kp->e.sv.len; sv2.pos_off = nullptr;
+            sv2.exc_off = nullptr; sv2.exc = nullptr; sv2.mask = kp->e.sv.mask; sv2.idx = kp->e.sv.idx; sv2.count = a.sv.count;
+            nxt = fetch_seq_g<M>(sv2, kp->xrec, t + total_waves, lane);
+        }
         const uint32_t seq = cur.seq;
         if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
         if (!cur.ok) continue;
@@ -432,9 +456,12 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         const uint32_t xlo = xw & 0xfffu;
         // group ends cut by the edge that need a virtual row: none when the table has partial rows for them
         const uint32_t nE = g.np != 0u ? 0u : min((uint32_t)(G - 1), L - LW1);
-        uint32_t yfix[G];
+        // the y of the fix lane's G columns (Y = none) in ONE register, FB bits each: it lives until the virtual count rows
+        // are read back after the M-step, and these kernels run at the register limit of their block size
+        constexpr uint32_t FB = FIXG ? 10u : 7u, FM = (1u << FB) - 1u;
+        uint32_t yfix = 0;
 #pragma unroll
-        for (int c = 0; c < G; c++) yfix[c] = Y;
+        for (int c = 0; c < G; c++) yfix |= Y << (FB * (uint32_t)c);
         const bool fixJ = lane_b < B;                         // fix lanes: (b, t) = virtual row b, group t
         const bool fixE = lane_b >= g.Bj && lane_b < g.Bj + nE;
         const bool fix = fixJ || fixE;
@@ -447,6 +474,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
         for (int c = 0; c < G; c++) fs[c] = 1.0f;
         if (any_fix && fix) {
+            const uint32_t xfields = xrec_fields<FIXG ? 10 : 7>(cur.xr.y, cur.xr.z, cur.xr.w, lane_b);     // the fields of lane_b .. lane_b + G - 1
 #pragma unroll
             for (int c = 0; c < G; c++) {
                 const int col = (int)(G * lane_t + c) - (int)delta;
@@ -454,19 +482,13 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 if (fixJ) {
                     const uint32_t k = lane_b + (uint32_t)c;           // entry of position xlo-G+1+k
                     pos = xlo + k - (uint32_t)(G - 1);                 // wraps for positions before the sequence
-                    if constexpr (FIXG) {                              // 10-bit fields, three per word
-                        const uint32_t word = (k < 3u) ? cur.xr.y : ((k < 6u) ? cur.xr.z : cur.xr.w);
-                        yc = (word >> (10u * (k % 3u))) & 0x3ffu;
-                    } else {
-                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
-                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
-                    }
+                    yc = (xfields >> ((FIXG ? 10u : 7u) * (uint32_t)c)) & (FIXG ? 0x3ffu : 0x7fu);
                 } else {
                     pos = LW1 + (lane_b - g.Bj) - (uint32_t)(G - 1) + (uint32_t)c;
                     yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);   // only used when pos < LW1
                 }
                 if (col < 0 || pos >= LW1) yc = Y;                     // neutral column / EM.cpp:167 (also pos < 0)
-                yfix[c] = yc;
+                yfix = (yfix & ~(FM << (FB * (uint32_t)c))) | (yc << (FB * (uint32_t)c));
                 const uint32_t idx = __umul24((uint32_t)max(col, 0), Ys) + yc;
                 fs[c] = sfix[idx];
             }
@@ -644,7 +666,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
 #pragma unroll
                             for (int c = 0; c < G; c++) {
                                 const int col = (int)(G * lane_t + c) - (int)delta;
-                                if (yfix[c] != Y) atomicAdd(&n1[(uint32_t)col * Y + yfix[c]], acc);
+                                const uint32_t yc = (yfix >> (FB * (uint32_t)c)) & FM;
+                                if (yc != Y) atomicAdd(&n1[(uint32_t)col * Y + yc], acc);
                             }
                         }
                     }
@@ -654,7 +677,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                     const unsigned long long nzm = __ballot(acc != 0ull);
                     if (acc != 0ull) {
                         // code: group (4 bits), then the y of its two columns (9 bits each, Y = 256 = no bin)
-                        const uint32_t code = lane_t | (yfix[0] << 4) | (yfix[G - 1] << 13);
+                        const uint32_t code = lane_t | ((yfix & FM) << 4) | (((yfix >> (FB * (uint32_t)(G - 1))) & FM) << 13);
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
                         grp_log_store(my_log, nlog + rank, acc, code);
                     }

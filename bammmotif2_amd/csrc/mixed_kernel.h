@@ -79,7 +79,6 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     // accumulator -- its odds table lands where the prologue stages it anyway, and in this block's global copy for
     // the fix lanes; block 0 publishes the model.  Inside optimize() a fired stop rule ends the block here.
     [[maybe_unused]] float q_fused = 0.0f;
-    const float* const sfix = (ACCUM && ga.fused) ? ga.s_block + (size_t)blockIdx.x * (W * Ys) : a.s;
     {
         float* s1w = reinterpret_cast<float*>(lds_raw + g.off_s1);
         const float* s1 = s1_stage;
@@ -158,7 +157,19 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
 
     for (; t < a.sv.count; t += total_waves) {
         const RawSeqG<M> cur = nxt;
-        if (t + total_waves < a.sv.count) nxt = fetch_seq_g<M>(a.sv, ga.xrec, t + total_waves, lane);
+        // Pointers that are needed once per sequence are read again from the kernel-argument segment (scalar loads,
+        // scalar cache) instead of living in SGPRs across the whole loop body: the body is 100 SGPRs over budget, and
+        // what hipcc spills it parks in VGPR lanes and fetches back with v_readlane -- VALU instructions of a
+        // VALU-bound loop (0.853 -> 0.842 ms per pass at 1M for the sequence set's pointers alone).
+        const __attribute__((address_space(4))) GrpKernelArgs* kp =
+            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));                         // opaque per iteration: the loads are not hoisted out of the loop
+        if (t + total_waves < a.sv.count) {
+            SeqView sv2;
+            sv2.words = kp->e.sv.words; sv2.word_off = kp->e.sv.word_off; sv2.len = kp->e.sv.len; sv2.pos_off = nullptr;
+            sv2.exc_off = nullptr; sv2.exc = nullptr; sv2.mask = kp->e.sv.mask; sv2.idx = kp->e.sv.idx; sv2.count = a.sv.count;
+            nxt = fetch_seq_g<M>(sv2, kp->xrec, t + total_waves, lane);
+        }
         const uint32_t seq = cur.seq;
         if (WRITE_R && (seq < a.seq_begin || seq >= a.seq_end)) continue;
         if (!cur.ok) continue;
@@ -193,13 +204,17 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         const uint32_t Bx = (xw >> 12) & 0xfu;
         const uint32_t xlo = xw & 0xfffu;
         const uint32_t nE = min(kMixNe, L - LW1);
-        uint32_t yfix[4] = {Y, Y, Y, Y};
+        // the y of the fix lane's up to four columns, 7 bits each (Y = none), in ONE register: it lives until the virtual
+        // count rows are read back after the M-step, and the kernel runs at the 128-VGPR limit of a 1024-thread block
+        uint32_t yfix = Y | (Y << 7) | (Y << 14) | (Y << 21);
         const bool fixJ = lane_b < Bx;
         const bool fixE = lane_b >= kMixBj && lane_b < kMixBj + nE;
         const bool fix = fixJ || fixE;
         float fs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        const float* const sfix_now = (ACCUM && kp->fused) ? kp->s_block + (size_t)blockIdx.x * (W * Ys) : kp->e.s;
         if (fix) {
             const uint32_t pv = fixJ ? xlo + lane_b : LW1 + (lane_b - kMixBj);         // the row's position
+            const uint32_t xfields = xrec_fields<7>(cur.xr.y, cur.xr.z, cur.xr.w, lane_b + 4u - lane_G);     // the fields of the group's columns
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 uint32_t yc = Y;                                                       // the column's neutral entry
@@ -207,16 +222,14 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                 if ((uint32_t)c < lane_G) {
                     const uint32_t pos = pv - (lane_G - 1u) + (uint32_t)c;           // wraps for positions before the sequence
                     if (fixJ) {                                                        // record fields start at position xlo-3
-                        const uint32_t k = lane_b + (uint32_t)c + 4u - lane_G;
-                        const uint32_t word = (k < 4u) ? cur.xr.y : ((k < 8u) ? cur.xr.z : cur.xr.w);
-                        yc = (word >> (7u * (k & 3u))) & 0x7fu;
+                        yc = (xfields >> (7u * (uint32_t)c)) & 0x7fu;
                     } else {
                         yc = (sE >> (2u * ((LW1 - 1u - pos) & 15u))) & (Y - 1u);
                     }
                     if (pos >= LW1) yc = Y;                                            // EM.cpp:167 (also pos < 0)
                 }
-                yfix[c] = yc;
-                fs[c] = sfix[__umul24(colc, Ys) + yc];                                 // global, through L1 / L2
+                yfix = (yfix & ~(0x7fu << (7 * c))) | (yc << (7 * c));
+                fs[c] = sfix_now[__umul24(colc, Ys) + yc];                             // global, through L1 / L2
             }
         }
         // Which slots do not take their row from the stream -- beyond the EM.cpp:167 edge (neutral row), a
@@ -387,7 +400,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             bool any = false;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                uint32_t yc = ((uint32_t)c < lane_G) ? yfix[c] : Y;
+                uint32_t yc = ((uint32_t)c < lane_G) ? ((yfix >> (7 * c)) & 0x7fu) : Y;
                 if (yc != Y && lane_col0 + (uint32_t)c < n1c) {               // a resident bin: added here, not logged
                     if (acc != 0ull) atomicAdd(&n1p[(lane_col0 + (uint32_t)c) * Y + yc], acc);
                     yc = Y;
@@ -399,7 +412,8 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             const unsigned long long nzm = __ballot(acc != 0ull);
             if (acc != 0ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
-                grp_log_store(my_log, nlog + rank, acc, code);
+                GrpLogEntry* const log_now = reinterpret_cast<GrpLogEntry*>(kp->fix_log) + (size_t)(blockIdx.x * WAVES + wave) * kp->fix_log_cap;
+                grp_log_store(log_now, nlog + rank, acc, code);
             }
             nlog += (uint32_t)__builtin_popcountll(nzm);
             wave_lds_sync();
