@@ -73,7 +73,7 @@ struct bamm_ctx {
     bool own_stream = false;
     uint32_t blocks = 0, threads = 0;   // 0 = default
     // bamm_ctx_set_tuning: kernel-selection switches for benchmarks and the cross-kernel parity tests
-    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true, use_fused_update = true, use_adaptive_lists = true;
+    bool use_grouped = true, use_sparse = true, use_e_fused = true, use_e_list = true, use_fused_update = true, use_adaptive_lists = true, use_update_blocks = true;
     uint32_t list_threshold_pct = 45;   // sliced path: a pass takes lists when fewer than this share of the windows was non-zero in the pass before
     uint32_t group_size = 0;            // 0 = planner's choice
     int group_layout = -1;              // -1 = planner's choice
@@ -151,6 +151,8 @@ struct bamm_em {
     float* d_s_block = nullptr;                 // [blocks of the first launch][W * (Y + 1)]
     float* d_v_alt = nullptr;                   // fused updates read the old v while the writer block stores the new one
     float* d_llh[2] = {nullptr, nullptr};       // log-likelihood of the last two updates (the stop rule compares them)
+    double* d_upd_partial = nullptr;            // the update spread over blocks (tables beyond its LDS form): v_diff partials
+    uint32_t* d_upd_ticket = nullptr;           // ... and the word its blocks draw tickets from
     uint32_t llh_cur = 0;                       // slot the last update wrote
     bool ring_prev_dirty = false;               // the ring slot behind acc_cur was read by a fused update and awaits clearing
     bool acc_external = false;                 // caller-owned (bamm_em_set_reduce_buffer)
@@ -594,6 +596,7 @@ void prepare_update(bamm_em* em, bool q_window, bool fused, UpdateArgs& u) {
     u.iteration = em->d_iteration; u.optimize_q = (em->prm.optimize_q && q_window) ? 1 : 0;
     u.n_seqs_override = (double)em->prm.n_seqs_global;
     u.llh_in = em->d_llh[em->llh_cur]; u.llh_out = em->d_llh[em->llh_cur ^ 1u];
+    u.partial = em->d_upd_partial; u.ticket = em->d_upd_ticket;
     if (em->stop_arg) {
         u.stop = em->d_stop; u.epsilon = em->prm.epsilon; u.opt_iteration = em->opt_iteration;
         u.llh_prev = em->opt_llh_prev; u.llh_prev_from_status = em->opt_iteration > 1u ? 1 : 0;
@@ -771,6 +774,7 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
     else if (k == "e_list") c->use_e_list = value != 0;
     else if (k == "fused_update") c->use_fused_update = value != 0;
     else if (k == "adaptive_lists") c->use_adaptive_lists = value != 0;
+    else if (k == "update_blocks") c->use_update_blocks = value != 0;
     else if (k == "list_threshold_pct") {
         if (value < 0 || value > 100) { set_error("list_threshold_pct must be 0..100"); return BAMM_ERR_ARG; }
         c->list_threshold_pct = (uint32_t)value;
@@ -885,7 +889,7 @@ int bamm_em_destroy(bamm_em* em) {
     (void)hipStreamSynchronize(em->ctx->stream);
     for (void* p : {(void*)em->d_vbg, (void*)em->d_A, (void*)em->d_v, (void*)em->d_n, (void*)em->d_s, (void*)em->d_qbuf[0],
                     (void*)em->d_status, (void*)em->d_trace, (void*)em->d_iteration, (void*)em->d_mask, (void*)em->d_acc_ring,
-                    (void*)em->d_v_alt, (void*)em->d_llh[0], (void*)em->d_s_block, (void*)em->d_nnz,
+                    (void*)em->d_v_alt, (void*)em->d_llh[0], (void*)em->d_s_block, (void*)em->d_nnz, (void*)em->d_upd_partial, (void*)em->d_upd_ticket,
                     (void*)em->d_state, (void*)em->d_list_r, (void*)em->d_list_p, (void*)em->d_list_n, (void*)em->d_s_alt, (void*)em->d_fix_log,
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
@@ -988,6 +992,10 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if ((rc = dev_alloc(&em->d_v_alt, em->vsz))) return fail(rc);
     if ((rc = dev_alloc(&em->d_llh[0], 2))) return fail(rc);
     em->d_llh[1] = em->d_llh[0] + 1;
+    if (!update_fits_lds(prm->K, prm->W) && c->use_update_blocks) {
+        if ((rc = dev_alloc(&em->d_upd_partial, kUpdateMaxBlocks)) || (rc = dev_alloc(&em->d_upd_ticket, 1))) return fail(rc);
+        if (hipMemsetAsync(em->d_upd_ticket, 0, sizeof(uint32_t), st) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(BAMM_ERR_HIP); }
+    }
     {   // counts are sums of r * 2^fix_shift over at most n_seqs_global (else this handle's) sequences, each
         // contributing less than 1 per cell: keep the int64 total below 2^62
         const uint64_t n_hint = std::max<uint64_t>(prm->n_seqs_bound ? prm->n_seqs_bound : (prm->n_seqs_global ? prm->n_seqs_global : seqs->n), 1);

@@ -154,7 +154,12 @@ struct UpdateArgs {
     uint32_t opt_iteration;      // 1-based pass number inside this optimize() call (`iteration > 10`)
     float* status_mirror;        // nullable: pinned host memory (device address) that receives the 8 status words as
                                  // well, so that the host needs no copy in the stream to see them
+    // tables beyond the LDS form of the update (K >= 3 at usual widths): the update is spread over blocks in two
+    // launches (k_update_counts, k_update_model) instead of one block walking up to millions of cells
+    double*   partial;           // nullable ([kUpdateMaxBlocks]): per-block partial sums of v_diff, summed in block order by the last block
+    uint32_t* ticket;            // a zeroed word: the blocks of k_update_model draw tickets from it, the last one resets it
 };
+constexpr uint32_t kUpdateMaxBlocks = 1024;
 
 // the update with every order of n staged in LDS (update_kernel.h): scratch bytes, and
 // whether it applies -- at most 2048 cells of the top order (two per thread at 1024 threads), tables within 60 KiB

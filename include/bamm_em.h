@@ -134,6 +134,8 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
  *   "list_threshold_pct" 0..100  ... lists when fewer than this percentage of the windows was non-zero (default 45)
  *   "fused_update" 1/0 inside iterate() / optimize() the model update of pass p runs in the block prologue of
  *                       pass p+1's first kernel instead of a launch of its own (default 1; K <= 2-sized tables)
+ *   "update_blocks" 1/0 tables beyond the update's LDS form (k >= 3 at usual widths): the model update spread over
+ *                       blocks in three short launches instead of one block (default 1; same model bits)
  * There are no environment variables that change what the library computes or launches.          */
 int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
 
