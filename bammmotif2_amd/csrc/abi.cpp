@@ -9,19 +9,36 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 
 #include "common.h"
 
 using namespace bamm;
 
+static bool flush_idle_scratch(int device);
+
 namespace {
 
-template <class T>
-int dev_alloc(T** p, size_t count) {
+// hipMalloc; when the device is out of memory the contexts' idle scratch blocks (below) are released and it is tried again
+int dev_alloc_bytes(void** p, size_t bytes) {
     *p = nullptr;
-    BAMM_HIP(hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
+    hipError_t e = hipMalloc(p, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        int device = 0;
+        (void)hipGetDevice(&device);
+        if (flush_idle_scratch(device)) e = hipMalloc(p, bytes ? bytes : 1);
+    }
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+        *p = nullptr;
+        return BAMM_ERR_HIP;
+    }
     return BAMM_OK;
 }
+
+template <class T>
+int dev_alloc(T** p, size_t count) { return dev_alloc_bytes((void**)p, count * sizeof(T)); }
 
 template <class T>
 int dev_upload(T** p, const T* host, size_t count, hipStream_t st) {
@@ -79,7 +96,101 @@ struct bamm_ctx {
     int group_layout = -1;              // -1 = planner's choice
     int num_cus = 0;
     std::string name;
+    // Scratch that is as large as the sequence set (dense r, the lists between the E pass and the M slices, the fix
+    // lanes' log, getR's staging): 10 GB per handle at config 4, and 0.1-0.3 s per handle to allocate and free on
+    // some boxes of the pool (hipFree synchronises the device as well).  A handle returns such blocks to its context
+    // and the next handle on it -- the next motif, the next CV fold -- takes them over; everything on a context runs
+    // on its one stream, so the old owner's last kernel is ordered before the new owner's first.  At most a quarter
+    // of the device's memory stays idle here, and an allocation that fails releases every context's idle blocks first.
+    std::mutex scratch_mu;
+    std::unordered_map<void*, size_t> scratch_live;          // blocks handed out: bytes
+    std::vector<std::pair<void*, size_t>> scratch_idle;      // blocks waiting for their next owner, oldest first
+    size_t scratch_idle_bytes = 0, scratch_cap_bytes = 0;
+    bool scratch_poison = false;                             // tests: every block is filled with 0xFF when it is handed out
+    uint64_t scratch_hits = 0, scratch_misses = 0;
 };
+
+constexpr size_t kScratchMinBytes = size_t(4) << 20;         // smaller blocks are plain allocations
+static std::mutex g_ctx_mu;
+static std::vector<bamm_ctx*> g_ctxs;                                // live contexts (flush_idle_scratch walks them)
+
+static bool flush_idle_scratch(int device) {
+    bool any = false;
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    for (bamm_ctx* c : g_ctxs) {
+        if (c->device != device) continue;
+        std::lock_guard<std::mutex> l(c->scratch_mu);
+        for (auto& b : c->scratch_idle) { (void)hipFree(b.first); any = true; }
+        c->scratch_idle.clear();
+        c->scratch_idle_bytes = 0;
+    }
+    return any;
+}
+
+template <class T>
+int scratch_alloc(bamm_ctx* c, T** p, size_t count) {
+    *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    if (bytes < kScratchMinBytes) return dev_alloc(p, count);
+    bytes = (bytes + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    void* got = nullptr;
+    size_t got_bytes = 0;
+    {
+        std::lock_guard<std::mutex> l(c->scratch_mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c->scratch_idle.size(); i++) {   // the tightest idle block of at most twice the size
+            const size_t b = c->scratch_idle[i].second;
+            if (b >= bytes && b <= 2 * bytes && (best == (size_t)-1 || b < c->scratch_idle[best].second)) best = i;
+        }
+        if (best != (size_t)-1) {
+            got = c->scratch_idle[best].first; got_bytes = c->scratch_idle[best].second;
+            c->scratch_idle.erase(c->scratch_idle.begin() + (ptrdiff_t)best);
+            c->scratch_idle_bytes -= got_bytes;
+            c->scratch_hits++;
+        } else {
+            c->scratch_misses++;
+        }
+    }
+    if (!got) {
+        if (int rc = dev_alloc_bytes(&got, bytes)) return rc;
+        got_bytes = bytes;
+    }
+    if (c->scratch_poison && hipMemsetAsync(got, 0xff, got_bytes, c->stream) != hipSuccess) {
+        (void)hipFree(got);
+        set_error("hipMemsetAsync failed");
+        return BAMM_ERR_HIP;
+    }
+    {
+        std::lock_guard<std::mutex> l(c->scratch_mu);
+        c->scratch_live[got] = got_bytes;
+    }
+    *p = (T*)got;
+    return BAMM_OK;
+}
+
+// Returns a block to its context (the caller has made sure that nothing enqueued on OTHER streams still uses it;
+// work on the context's own stream is ordered before the next owner's).  Plain allocations are freed.
+void scratch_free(bamm_ctx* c, void* p) {
+    if (!p) return;
+    std::vector<void*> evict;
+    {
+        std::lock_guard<std::mutex> l(c->scratch_mu);
+        auto it = c->scratch_live.find(p);
+        if (it == c->scratch_live.end()) {
+            evict.push_back(p);
+        } else {
+            c->scratch_idle.emplace_back(p, it->second);
+            c->scratch_idle_bytes += it->second;
+            c->scratch_live.erase(it);
+            while (c->scratch_idle_bytes > c->scratch_cap_bytes && !c->scratch_idle.empty()) {     // oldest first
+                evict.push_back(c->scratch_idle.front().first);
+                c->scratch_idle_bytes -= c->scratch_idle.front().second;
+                c->scratch_idle.erase(c->scratch_idle.begin());
+            }
+        }
+    }
+    for (void* q : evict) (void)hipFree(q);
+}
 
 struct bamm_seqs {
     bamm_ctx* ctx = nullptr;
@@ -400,8 +511,8 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
         const size_t cap = ((eb.count + waves - 1) / waves) * std::min<size_t>(64, (size_t)ga.g.Bv * ga.g.T);   // entries per wave
         const size_t need = waves * cap;                      // 8-byte entries
         if (need > em->fix_log_words) {
-            if (em->d_fix_log) { BAMM_HIP(hipStreamSynchronize(st)); BAMM_HIP(hipFree(em->d_fix_log)); em->d_fix_log = nullptr; em->fix_log_words = 0; }
-            if (int rc = dev_alloc(&em->d_fix_log, need)) return rc;
+            if (em->d_fix_log) { scratch_free(em->ctx, em->d_fix_log); em->d_fix_log = nullptr; em->fix_log_words = 0; }
+            if (int rc = scratch_alloc(em->ctx, &em->d_fix_log, need)) return rc;
             em->fix_log_words = need;
         }
         ga.fix_log = em->d_fix_log;
@@ -470,7 +581,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
         if (bk.mclass == kLongClass) {
             // the sliced path's getR() reads dense r from d_state (slot layout unless the E pass is k_em_seq)
             const bool want_r = em->sliced && dense_r;
-            if (want_r && !em->d_state && (rc = dev_alloc(&em->d_state, (size_t)s->total_len))) return rc;
+            if (want_r && !em->d_state && (rc = scratch_alloc(em->ctx, &em->d_state, (size_t)s->total_len))) return rc;
             a.r_out = em->d_state;
             if ((rc = launch_long_em(a, accum, want_r, want_r && !em->e_fused, bk.blocks, st))) return rc;
             continue;
@@ -491,7 +602,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
             // E kernel took picks the one that runs (the other's launches return at entry).
             const bool adaptive = lists && accum && em->d_nnz && em->adaptive_lists;
             if ((!lists || adaptive) && !em->d_state) {
-                if ((rc = dev_alloc(&em->d_state, (size_t)s->total_len))) return rc;
+                if ((rc = scratch_alloc(em->ctx, &em->d_state, (size_t)s->total_len))) return rc;
             }
             auto flavour = [&](bool use_lists, int run_if_long) -> int {   // run_if_long: -1 = unconditional
                 EmKernelArgs f = a;
@@ -723,6 +834,12 @@ int bamm_ctx_create(int device, void* hip_stream, bamm_ctx** out) {
         }
         c->own_stream = true;
     }
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->scratch_cap_bytes = total_b / 4;
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctxs.push_back(c);
+    }
     *out = c;
     return BAMM_OK;
 }
@@ -741,6 +858,13 @@ int bamm_device_count(int* n) {
 
 int bamm_ctx_destroy(bamm_ctx* c) {
     if (!c) return BAMM_OK;
+    {
+        std::lock_guard<std::mutex> g(g_ctx_mu);
+        g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
+    }
+    (void)hipSetDevice(c->device);
+    if (!c->scratch_idle.empty()) (void)hipStreamSynchronize(c->stream);
+    for (auto& b : c->scratch_idle) (void)hipFree(b.first);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BAMM_OK;
@@ -775,6 +899,12 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
     else if (k == "fused_update") c->use_fused_update = value != 0;
     else if (k == "adaptive_lists") c->use_adaptive_lists = value != 0;
     else if (k == "update_blocks") c->use_update_blocks = value != 0;
+    else if (k == "scratch_poison") c->scratch_poison = value != 0;
+    else if (k == "scratch_cache_mb") {
+        if (value < 0) { set_error("scratch_cache_mb must be >= 0"); return BAMM_ERR_ARG; }
+        c->scratch_cap_bytes = (size_t)value << 20;
+        if (value == 0) (void)flush_idle_scratch(c->device);
+    }
     else if (k == "list_threshold_pct") {
         if (value < 0 || value > 100) { set_error("list_threshold_pct must be 0..100"); return BAMM_ERR_ARG; }
         c->list_threshold_pct = (uint32_t)value;
@@ -894,7 +1024,7 @@ int bamm_em_destroy(bamm_em* em) {
                     (void*)em->d_qbuf[1], (void*)em->d_qbuf[2],
                     (void*)em->d_mask_r, (void*)em->d_mask_bits, (void*)em->d_mask_hist, (void*)em->d_mask_sel, (void*)em->d_mask_qseq,
                     (void*)em->d_mask_partial_n, (void*)em->d_mask_partial_stat})
-        (void)hipFree(p);
+        scratch_free(em->ctx, p);                             // set-sized blocks go back to the context, the rest is freed
     for (uint32_t* p : em->owned_idx) (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
     (void)hipFree(em->d_stop);
@@ -1152,7 +1282,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         }
     }
     if (sliced && em->e_fused && c->use_e_list) {
-        if ((rc = dev_alloc(&em->d_list_r, (size_t)seqs->total_len)) || (rc = dev_alloc(&em->d_list_p, (size_t)seqs->total_len)) ||
+        if ((rc = scratch_alloc(c, &em->d_list_r, (size_t)seqs->total_len)) || (rc = scratch_alloc(c, &em->d_list_p, (size_t)seqs->total_len)) ||
             (rc = dev_alloc(&em->d_list_n, (size_t)seqs->n))) return fail(rc);
         if (hipMemsetAsync(em->d_list_n, 0, (seqs->n ? seqs->n : 1) * sizeof(uint32_t), st) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(BAMM_ERR_HIP); }
         // lists or dense r, per pass: the first pass of a handle takes the dense flavour (nothing is known yet: the
@@ -1429,7 +1559,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
         em->mask_blocks = mblocks;
         if ((rc = dev_alloc(&em->d_mask_partial_n, (size_t)mblocks * em->cells)) ||
             (rc = dev_alloc(&em->d_mask_partial_stat, (size_t)mblocks * 4)) ||
-            (rc = dev_alloc(&em->d_mask_r, (size_t)s->total_len)) ||
+            (rc = scratch_alloc(em->ctx, &em->d_mask_r, (size_t)s->total_len)) ||
             (rc = dev_alloc(&em->d_mask_bits, (size_t)s->total_len / 32 + 2)) ||
             (rc = dev_alloc(&em->d_mask_hist, 2049)) || (rc = dev_alloc(&em->d_mask_sel, 1)) ||
             (em->prm.optimize_q && (rc = dev_alloc(&em->d_mask_qseq, (size_t)s->n))))
@@ -1595,9 +1725,9 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         return BAMM_OK;
     }
     float* d_r = nullptr;
-    int rc = dev_alloc(&d_r, total);
+    int rc = scratch_alloc(em->ctx, &d_r, total);
     if (rc) return rc;
-    BAMM_HIP(hipMemsetAsync(d_r, 0, total * sizeof(float), st));
+    if (hipMemsetAsync(d_r, 0, total * sizeof(float), st) != hipSuccess) { scratch_free(em->ctx, d_r); set_error("hipMemsetAsync failed"); return BAMM_ERR_HIP; }
     for (size_t b = 0; b < em->ebuckets.size() && !rc; b++) {
         const EmBucket& bk = em->ebuckets[b];
         EmKernelArgs a{};
@@ -1615,7 +1745,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("copy of r failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
     }
-    (void)hipFree(d_r);
+    scratch_free(em->ctx, d_r);
     return rc;
 }
 

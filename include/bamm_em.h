@@ -136,6 +136,9 @@ int  bamm_ctx_set_launch(bamm_ctx* ctx, uint32_t blocks, uint32_t threads_per_bl
  *                       pass p+1's first kernel instead of a launch of its own (default 1; K <= 2-sized tables)
  *   "update_blocks" 1/0 tables beyond the update's LDS form (k >= 3 at usual widths): the model update spread over
  *                       blocks in three short launches instead of one block (default 1; same model bits)
+ *   "scratch_cache_mb" n  idle set-sized scratch blocks (dense r, lists, logs) a context keeps for its next handle
+ *                       instead of freeing them (default: a quarter of the device's memory; 0 = keep nothing)
+ *   "scratch_poison" 1/0 tests: fill every such block with 0xFF bytes when it is handed out (default 0)
  * There are no environment variables that change what the library computes or launches.          */
 int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
 

@@ -31,5 +31,8 @@ def lib():
 def gpu_ctx(lib):
     import bammmotif2_amd as bm
     ctx = bm.Context(0)          # raises loudly without a gfx950 device: no fallback
+    # set-sized scratch (dense r, lists, logs) travels from handle to handle through the context: every block is
+    # filled with 0xFF (NaNs / huge indices) when it is handed out, so that a kernel reading what it did not write shows
+    ctx.set_tuning(scratch_poison=1)
     yield ctx
     ctx.close()

@@ -56,3 +56,23 @@ def test_update_over_blocks_equals_one_block(shape, gpu_ctx):
     assert np.array_equal(la, lb) and np.array_equal(qa, qb)
     np.testing.assert_allclose(va, vb, rtol=3e-7, atol=0)
     assert 1 < a[6] <= 60
+
+
+def test_scratch_blocks_pass_from_handle_to_handle(gpu_ctx):
+    """The context keeps a closed handle's set-sized scratch for the next one (csrc/abi.cpp: scratch_alloc): same
+    results from a block that is fresh, reused, reused after a LARGER owner, and with the cache turned off."""
+    shape = dict(N=6000, L0=400, W=24, K=4, n_frac=0.01, ragged=60)      # sliced path: dense r, lists
+    small = dict(N=3000, L0=300, W=24, K=4)
+    ref = run(gpu_ctx, True, **shape)
+    again = run(gpu_ctx, True, **shape)                      # takes over the first run's blocks (poisoned by the fixture)
+    run(gpu_ctx, True, **small)
+    third = run(gpu_ctx, True, **shape)
+    gpu_ctx.set_tuning(scratch_cache_mb=0)
+    try:
+        plain = run(gpu_ctx, True, **shape)
+    finally:
+        gpu_ctx.set_tuning(scratch_cache_mb=16384)
+    for other in (again, third, plain):
+        for i in (0, 1, 2, 7, 8, 9, 12):
+            assert np.array_equal(ref[i], other[i]), i
+        assert ref[6] == other[6] and ref[10] == other[10]

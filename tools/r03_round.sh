@@ -10,6 +10,7 @@ python3 tools/config5_run.py 200000 /tmp/c5b --deviceList 0,0,0,0,0,0,0,0 > gpur
 python3 tools/config5_run.py 1000000 /tmp/c3 em > gpurun_out/r03_config3_cli.txt 2>&1; echo "config3 cli rc=$?"
 timeout -k 10 900 python3 -m tests.fuzz_parity --n 1500 --seed 31 > gpurun_out/r03_fuzz_parity.txt 2>&1; echo "fuzz rc=$?"; tail -3 gpurun_out/r03_fuzz_parity.txt
 python3 -m tests.deviation_report > gpurun_out/r03_deviation_vs_fp64.txt 2>&1; echo "deviation rc=$?"
+python3 tools/pass_times.py 1000000 120 > gpurun_out/r03_pass_times.txt 2>&1; echo "pass times rc=$?"
 # the per-iteration cost at an eighth of the set (one GPU's shard of 8), with the model update fused into the next
 # pass's kernel and as a launch of its own, without a collective and with the library's RCCL call on a 1-rank communicator
 rm -f gpurun_out/r03_shard_sizes.jsonl
