@@ -1534,24 +1534,31 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     const size_t wave_bytes = mask_wave_bytes(s->max_len);
     auto round16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t s_bytes = round16((size_t)W * (Y + 1) * sizeof(float));
-    const bool s_in_lds = s_bytes <= 64 * 1024 && s_bytes + wave_bytes <= kLds;
-    const size_t e_table = s_in_lds ? s_bytes : 0;
-    // M-step: as many columns per launch as fit next to one wave's arrays
-    if (wave_bytes + round16((size_t)Y * 8) > kLds || s->max_len > 65535u) {
-        set_error("bamm_em_mask: sequences of %u positions / order %u exceed the LDS plan of the masked kernels", s->max_len, em->prm.K);
+    // M-step: as many columns per launch as fit next to one wave's arrays.  Sequences whose arrays (10 bytes per
+    // position) do not fit beside one column's counts keep them in a global scratch region per wave instead
+    // (~16 000 positions at k = 2): slower, same arithmetic in the same order.
+    if (round16((size_t)Y * 8) > kLds || s->max_len > 65535u) {
+        set_error("bamm_em_mask: %s", round16((size_t)Y * 8) > kLds ? "one column of the count table exceeds the LDS (order > 6)"
+                                                                       : "sequences beyond 65 535 positions (16-bit window lists)");
         return BAMM_ERR_UNSUPPORTED;
     }
-    uint32_t m_cols = std::min<size_t>(W, (std::min(kLds / 2, kLds - wave_bytes)) / ((size_t)Y * 8));
+    const bool wave_global = wave_bytes + round16((size_t)Y * 8) > kLds;
+    const bool s_in_lds = s_bytes <= 64 * 1024 && (wave_global || s_bytes + wave_bytes <= kLds);
+    const size_t e_table = s_in_lds ? s_bytes : 0;
+    uint32_t m_cols = std::min<size_t>(W, (wave_global ? kLds / 2 : std::min(kLds / 2, kLds - wave_bytes)) / ((size_t)Y * 8));
     m_cols = std::max(1u, m_cols);
     const size_t m_table = round16((size_t)m_cols * Y * 8);
-    auto waves_for = [&](size_t table) { return (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (kLds - table) / wave_bytes)); };
+    auto waves_for = [&](size_t table) {
+        return wave_global ? 4u : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (kLds - table) / wave_bytes));
+    };
     const uint32_t init_table = (uint32_t)round16((size_t)W * 4 * sizeof(float));
     int rc = use_device(em->ctx);
     if (rc) return rc;
     hipStream_t st = em->ctx->stream;
     const uint32_t e_waves = waves_for(e_table), m_waves = waves_for(m_table);
     // 16 waves per CU (as the fused kernel), but no more partial tables than 64 MiB worth
-    const uint32_t cus = (uint32_t)std::max(1, em->ctx->num_cus);
+    // (arrays in global memory: at most 2048 waves' worth of them)
+    const uint32_t cus = wave_global ? std::min(64u, (uint32_t)std::max(1, em->ctx->num_cus)) : (uint32_t)std::max(1, em->ctx->num_cus);
     const uint32_t per_cu = std::max(1u, 16u / std::min(e_waves, m_waves));
     const uint32_t cap_blocks = (uint32_t)std::max<size_t>(cus, std::min<size_t>((size_t)cus * per_cu, ((size_t)64 << 20) / (em->cells * 8)));
     const uint32_t mblocks = std::max(1u, std::min(((uint32_t)s->n + std::min(e_waves, m_waves) - 1) / std::min(e_waves, m_waves), cap_blocks));
@@ -1584,6 +1591,12 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     a.fix_scale = ldexpf(1.0f, (int)em->fix_shift - 40);
     a.r = em->d_mask_r; a.bits = em->d_mask_bits; a.hist = em->d_mask_hist; a.sel = em->d_mask_sel;
     a.partial_n = em->d_mask_partial_n; a.partial_stat = em->d_mask_partial_stat;
+    unsigned char* d_wave = nullptr;
+    if (wave_global) {                                       // every launch below has at most cus * 8 blocks of 4 waves
+        if ((rc = scratch_alloc(em->ctx, &d_wave, (size_t)std::max(cus * 8u, mblocks) * 4u * wave_bytes))) return rc;
+        a.wave_scratch = d_wave;
+    }
+    struct WaveScratch { bamm_ctx* c; unsigned char* p; ~WaveScratch() { scratch_free(c, p); } } wave_guard{em->ctx, d_wave};
 
     auto blocks_for = [&](uint32_t waves, uint32_t cap) {
         const uint32_t need = ((uint32_t)s->n + waves - 1) / waves;
@@ -1822,7 +1835,8 @@ int bamm_seed_from_pwm(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, const 
     double* d_u = nullptr;
     int* d_counts = nullptr;
     uint32_t* d_z = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_score); (void)hipFree(d_u); (void)hipFree(d_counts); (void)hipFree(d_z); };
+    unsigned char* d_wave = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_score); (void)hipFree(d_u); (void)hipFree(d_counts); (void)hipFree(d_z); scratch_free(c, d_wave); };
     if ((rc = dev_upload(&d_score, score, (size_t)4 * W, st)) || (rc = dev_upload(&d_u, u, s->n, st)) ||
         (rc = dev_alloc(&d_counts, vsz)) || (z && (rc = dev_alloc(&d_z, s->n)))) { cleanup(); return rc; }
     if (hipMemsetAsync(d_counts, 0, vsz * sizeof(int), st) != hipSuccess) { set_error("hipMemsetAsync failed"); cleanup(); return BAMM_ERR_HIP; }
@@ -1833,6 +1847,10 @@ int bamm_seed_from_pwm(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, const 
     a.K = K; a.W = W; a.Y = (uint32_t)ipow4(K + 1);
     a.max_len = s->max_len; a.vsize = (uint32_t)vsz;
     a.score = d_score; a.q = q; a.u = d_u; a.counts = d_counts; a.z_out = d_z;
+    if (const size_t need = seed_global_scratch_bytes(a, (uint32_t)std::max(1, c->num_cus))) {   // sequences beyond the LDS plan
+        if ((rc = scratch_alloc(c, &d_wave, need))) { cleanup(); return rc; }
+        a.wave_scratch = d_wave;
+    }
     rc = launch_seed_pwm(a, (uint32_t)std::max(1, c->num_cus), st);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(counts, d_counts, vsz * sizeof(int), hipMemcpyDeviceToHost, st);

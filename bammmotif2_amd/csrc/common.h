@@ -217,7 +217,10 @@ struct SeedKernelArgs {          // Motif::initFromPWM's pass over the sequences
     const double* u;             // [N] the uniform variate of each sequence's draw
     int*     counts;             // [vsize] flat [k][y][j], zeroed by the caller
     uint32_t* z_out;             // nullable: sampled index per sequence (0 = no motif)
+    unsigned char* wave_scratch; // per-wave arrays in global memory (sequences whose arrays do not fit the LDS)
 };
+// bytes of global scratch the launch needs for its per-wave arrays (0: they fit the LDS), and the launch itself
+size_t seed_global_scratch_bytes(const SeedKernelArgs& a, uint32_t num_cus);
 int launch_seed_pwm(SeedKernelArgs a, uint32_t num_cus, hipStream_t st);
 
 struct ScoreKernelArgs {
@@ -260,6 +263,8 @@ struct MaskKernelArgs {          // EM::mask kernels (mask.hip)
     unsigned long long* partial_n;
     double*  partial_stat;
     uint32_t j0, j1;             // column range of k_mask_m
+    unsigned char* wave_scratch; // nullable: the per-wave arrays live here, one region per wave of the grid, instead of
+                                 // in LDS (sequences whose arrays do not fit beside the block's table)
 };
 
 // launchers (mask.hip)

@@ -69,6 +69,14 @@ __device__ __forceinline__ WaveLds wave_lds(unsigned char* base, const MaskKerne
     return w;
 }
 
+// WG: the arrays of wave `wave` of this block in the launch's global scratch (sequences beyond the LDS plan: the
+// reference has no limit, EM.cpp:261-503); else in LDS behind the block's table
+template <bool WG>
+__device__ __forceinline__ WaveLds wave_arrays(unsigned char* lds_base, const MaskKernelArgs& a, uint32_t wave, uint32_t wpb) {
+    if constexpr (WG) return wave_lds(a.wave_scratch, a, blockIdx.x * wpb + wave);
+    else return wave_lds(lds_base, a, wave);
+}
+
 // kmer_[p] mod Y for every position of one sequence (Sequence.cpp:35-41) into LDS
 __device__ __forceinline__ void decode_to_lds(const SeqView& sv, uint32_t seq, uint32_t L, uint32_t Y, int lane,
                                               uint32_t* ybuf) {
@@ -125,7 +133,7 @@ __device__ __forceinline__ float sequential_sum(float acc, const float* x, uint3
 }
 
 // ---- EM.cpp:266-323 ---------------------------------------------------------------------------
-template <bool SERIAL>
+template <bool SERIAL, bool WG>
 __global__ void __launch_bounds__(256) k_mask_init(MaskKernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     float* s0 = reinterpret_cast<float*>(smem);                       // [W][4], EM.cpp:270-274
@@ -137,7 +145,7 @@ __global__ void __launch_bounds__(256) k_mask_init(MaskKernelArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const WaveLds w = wave_lds(smem + a.table_bytes, a, wave);
+    const WaveLds w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
     float q = *a.q;
     float N1 = 0.0f;                                                  // EM.cpp:507, running over the processed sequences
     for (uint32_t seq = blockIdx.x * wpb + wave; seq < a.sv.count; seq += gridDim.x * wpb) {
@@ -246,7 +254,7 @@ __global__ void __launch_bounds__(256) k_mask_bits(MaskKernelArgs a) {
 }
 
 // ---- EM.cpp:395-433 ---------------------------------------------------------------------------
-template <bool S_IN_LDS>
+template <bool S_IN_LDS, bool WG>
 __global__ void __launch_bounds__(256) k_mask_e(MaskKernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t W = a.W, Ys = a.Y + 1u;
@@ -259,7 +267,7 @@ __global__ void __launch_bounds__(256) k_mask_e(MaskKernelArgs a) {
     __shared__ double stat[4][3];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const WaveLds w = wave_lds(smem + a.table_bytes, a, wave);
+    const WaveLds w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
     const float q = *a.q;
     double llh = 0.0, sum_r = 0.0, nseq = 0.0;
     for (uint32_t seq = blockIdx.x * wpb + wave; seq < a.sv.count; seq += gridDim.x * wpb) {
@@ -301,6 +309,7 @@ __global__ void __launch_bounds__(256) k_mask_e(MaskKernelArgs a) {
 }
 
 // ---- EM.cpp:452-461, columns [j0, j1) ---------------------------------------------------------
+template <bool WG>
 __global__ void __launch_bounds__(256) k_mask_m(MaskKernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t W = a.W, Y = a.Y, j0 = a.j0, j1 = a.j1;
@@ -309,7 +318,7 @@ __global__ void __launch_bounds__(256) k_mask_m(MaskKernelArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const WaveLds w = wave_lds(smem + a.table_bytes, a, wave);
+    const WaveLds w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
     for (uint32_t seq = blockIdx.x * wpb + wave; seq < a.sv.count; seq += gridDim.x * wpb) {
         if (a.sv.mask && !a.sv.mask[seq]) continue;
         const uint32_t L = a.sv.len[seq], LW1 = L - W + 1u;
@@ -349,13 +358,20 @@ size_t mask_wave_bytes(uint32_t max_len) {
         BAMM_HIP(hipGetLastError());                                                                \
     } while (0)
 
+// LDS of a launch: the block's table, and the waves' arrays unless they live in the global scratch
+static size_t mask_lds(const MaskKernelArgs& a, uint32_t threads) {
+    return a.table_bytes + (a.wave_scratch ? 0 : (size_t)(threads / 64u) * a.wave_bytes);
+}
+
 int launch_mask_init(const MaskKernelArgs& a, bool serial, uint32_t blocks, uint32_t threads, hipStream_t st) {
-    const size_t lds = a.table_bytes + (size_t)(threads / 64u) * a.wave_bytes;
+    const bool wg = a.wave_scratch != nullptr;
     if (serial) {
         blocks = 1; threads = 64;
-        BAMM_MASK_LAUNCH(k_mask_init<true>, a.table_bytes + a.wave_bytes, a);
+        if (wg) BAMM_MASK_LAUNCH((k_mask_init<true, true>), mask_lds(a, threads), a);
+        else BAMM_MASK_LAUNCH((k_mask_init<true, false>), mask_lds(a, threads), a);
     } else {
-        BAMM_MASK_LAUNCH(k_mask_init<false>, lds, a);
+        if (wg) BAMM_MASK_LAUNCH((k_mask_init<false, true>), mask_lds(a, threads), a);
+        else BAMM_MASK_LAUNCH((k_mask_init<false, false>), mask_lds(a, threads), a);
     }
     return BAMM_OK;
 }
@@ -379,15 +395,17 @@ int launch_mask_bits(const MaskKernelArgs& a, uint32_t blocks, hipStream_t st) {
 }
 
 int launch_mask_e(const MaskKernelArgs& a, bool s_in_lds, uint32_t blocks, uint32_t threads, hipStream_t st) {
-    const size_t lds = a.table_bytes + (size_t)(threads / 64u) * a.wave_bytes;
-    if (s_in_lds) BAMM_MASK_LAUNCH(k_mask_e<true>, lds, a);
-    else BAMM_MASK_LAUNCH(k_mask_e<false>, lds, a);
+    const size_t lds = mask_lds(a, threads);
+    const bool wg = a.wave_scratch != nullptr;
+    if (s_in_lds) { if (wg) BAMM_MASK_LAUNCH((k_mask_e<true, true>), lds, a); else BAMM_MASK_LAUNCH((k_mask_e<true, false>), lds, a); }
+    else { if (wg) BAMM_MASK_LAUNCH((k_mask_e<false, true>), lds, a); else BAMM_MASK_LAUNCH((k_mask_e<false, false>), lds, a); }
     return BAMM_OK;
 }
 
 int launch_mask_m(const MaskKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
-    const size_t lds = a.table_bytes + (size_t)(threads / 64u) * a.wave_bytes;
-    BAMM_MASK_LAUNCH(k_mask_m, lds, a);
+    const size_t lds = mask_lds(a, threads);
+    if (a.wave_scratch != nullptr) BAMM_MASK_LAUNCH(k_mask_m<true>, lds, a);
+    else BAMM_MASK_LAUNCH(k_mask_m<false>, lds, a);
     return BAMM_OK;
 }
 

@@ -19,6 +19,8 @@
 // lanes; the three order-dependent sums are walked by lane 0 over per-wave LDS arrays (four values per
 // LDS round trip) -- ~10k cycles per sequence and wave, which 4096 resident waves turn into a
 // millisecond per million sequences.  Nothing here is on the per-iteration path.
+// Sequences beyond ~10 000 positions (16 bytes of per-wave arrays per position exceed the LDS): the same kernel
+// with the arrays in a global scratch region per wave (WG) -- the reference has no limit (Motif.cpp:228-311).
 
 #include "device_utils.h"
 
@@ -33,6 +35,7 @@ __device__ __forceinline__ void seed_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <bool WG>
 __global__ void __launch_bounds__(1024) k_seed_pwm(SeedKernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t W = a.W, K = a.K, Y = a.Y;
@@ -48,7 +51,9 @@ __global__ void __launch_bounds__(1024) k_seed_pwm(SeedKernelArgs a) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t waves_per_block = blockDim.x >> 6;
     const uint32_t total_waves = gridDim.x * waves_per_block;
-    unsigned char* wbase = smem + a.table_bytes + a.count_bytes + (size_t)wave * a.wave_bytes;
+    unsigned char* wbase;
+    if constexpr (WG) wbase = a.wave_scratch + ((size_t)blockIdx.x * waves_per_block + wave) * a.wave_bytes;
+    else wbase = smem + a.table_bytes + a.count_bytes + (size_t)wave * a.wave_bytes;
     const uint32_t n4 = (a.max_len * 4u + 4u + 15u) & ~15u, n8 = (a.max_len * 8u + 8u + 15u) & ~15u;
     uint32_t* ybuf = reinterpret_cast<uint32_t*>(wbase);                    // [max_len]   kmer_ mod 4^(K+1)
     float* rf = reinterpret_cast<float*>(wbase + n4);                       // [max_len+1] r
@@ -149,23 +154,57 @@ size_t seed_wave_bytes(uint32_t max_len) {
     return 2 * n4 + n8;
 }
 
-int launch_seed_pwm(SeedKernelArgs a, uint32_t num_cus, hipStream_t st) {
+namespace {
+struct SeedPlan { uint32_t table_bytes, count_bytes, wave_bytes, waves, blocks; size_t lds; bool global; };
+
+SeedPlan seed_plan(const SeedKernelArgs& a, uint32_t num_cus) {
     const size_t kLds = 160 * 1024;
-    a.table_bytes = (uint32_t)(((size_t)4 * a.W * sizeof(float) + 15) & ~size_t(15));
-    a.wave_bytes = (uint32_t)seed_wave_bytes(a.max_len);
+    SeedPlan p{};
+    p.table_bytes = (uint32_t)(((size_t)4 * a.W * sizeof(float) + 15) & ~size_t(15));
+    const size_t wave_bytes = seed_wave_bytes(a.max_len);
+    p.wave_bytes = (uint32_t)wave_bytes;
     const size_t want_counts = ((size_t)a.vsize * sizeof(int) + 15) & ~size_t(15);
-    a.count_bytes = want_counts <= 48 * 1024 ? (uint32_t)want_counts : 0u;
-    if ((size_t)a.table_bytes + a.count_bytes + a.wave_bytes > kLds) a.count_bytes = 0u;   // long sequences: counts straight to HBM
-    const size_t fixed = (size_t)a.table_bytes + a.count_bytes;
-    if (fixed + a.wave_bytes > kLds) {
-        set_error("PWM seeding: a sequence of %u positions does not fit the per-wave LDS arrays", a.max_len);
+    p.count_bytes = want_counts <= 48 * 1024 ? (uint32_t)want_counts : 0u;
+    if ((size_t)p.table_bytes + p.count_bytes + wave_bytes > kLds) p.count_bytes = 0u;   // long sequences: counts straight to HBM
+    p.global = (size_t)p.table_bytes + p.count_bytes + wave_bytes > kLds;
+    const uint32_t cus = num_cus ? num_cus : 256u;
+    if (p.global) {
+        // per-wave arrays in global memory: the block's counts are back in LDS, at most 4 GiB of arrays in all
+        p.count_bytes = want_counts <= 48 * 1024 ? (uint32_t)want_counts : 0u;
+        const size_t max_waves = std::max<size_t>(1, (size_t(4) << 30) / wave_bytes);
+        p.waves = (uint32_t)std::min<size_t>(4, max_waves);
+        p.blocks = (uint32_t)std::max<size_t>(1, std::min<size_t>({(size_t)cus, (a.sv.count + p.waves - 1u) / p.waves, max_waves / p.waves}));
+        p.lds = (size_t)p.table_bytes + p.count_bytes;
+    } else {
+        const size_t fixed = (size_t)p.table_bytes + p.count_bytes;
+        p.waves = (uint32_t)std::min<size_t>(16, (kLds - fixed) / wave_bytes);
+        p.lds = fixed + (size_t)p.waves * wave_bytes;
+        p.blocks = std::max(1u, std::min(cus, (a.sv.count + p.waves - 1u) / p.waves));
+    }
+    return p;
+}
+}  // namespace
+
+size_t seed_global_scratch_bytes(const SeedKernelArgs& a, uint32_t num_cus) {
+    const SeedPlan p = seed_plan(a, num_cus);
+    return p.global ? (size_t)p.blocks * p.waves * seed_wave_bytes(a.max_len) : 0;
+}
+
+int launch_seed_pwm(SeedKernelArgs a, uint32_t num_cus, hipStream_t st) {
+    if (seed_wave_bytes(a.max_len) > 0xffffffffull) {
+        set_error("PWM seeding: a sequence of %u positions exceeds the per-wave arrays' 4 GiB", a.max_len);
         return BAMM_ERR_UNSUPPORTED;
     }
-    const uint32_t waves = (uint32_t)std::min<size_t>(16, (kLds - fixed) / a.wave_bytes);
-    const size_t lds = fixed + (size_t)waves * a.wave_bytes;
-    const uint32_t blocks = std::max(1u, std::min(num_cus ? num_cus : 256u, (a.sv.count + waves - 1u) / waves));
-    if (int rc = allow_lds(reinterpret_cast<const void*>(&k_seed_pwm), lds)) return rc;
-    hipLaunchKernelGGL(k_seed_pwm, dim3(blocks), dim3(waves * 64u), lds, st, a);
+    const SeedPlan p = seed_plan(a, num_cus);
+    a.table_bytes = p.table_bytes; a.count_bytes = p.count_bytes; a.wave_bytes = p.wave_bytes;
+    if (p.global) {
+        if (a.wave_scratch == nullptr) { set_error("PWM seeding: no scratch for the per-wave arrays"); return BAMM_ERR_ARG; }
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_seed_pwm<true>), p.lds)) return rc;
+        hipLaunchKernelGGL(k_seed_pwm<true>, dim3(p.blocks), dim3(p.waves * 64u), p.lds, st, a);
+    } else {
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_seed_pwm<false>), p.lds)) return rc;
+        hipLaunchKernelGGL(k_seed_pwm<false>, dim3(p.blocks), dim3(p.waves * 64u), p.lds, st, a);
+    }
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;
 }

@@ -629,16 +629,14 @@ int main(int nargs, char* args[]) {
                 if (devs[d].comm && bamm_em_set_comm(ems[d], devs[d].comm)) die_abi("EM communicator");
             }
             // every refusal that depends on the data is decided from GLOBAL quantities before any collective starts
-            // (a rank that refused alone would leave its peers in ncclAllReduce): EM::mask's per-wave LDS plan
+            // (a rank that refused alone would leave its peers in ncclAllReduce): EM::mask lists a sequence's windows
+            // as 16-bit indices and needs one count column of 4^(K+1) u64 cells in LDS (bamm_em_mask, csrc/abi.cpp)
             if (o.advanceEM && sharded) {
                 uint32_t longest = 0;
                 for (uint64_t n = 0; n < (uint64_t)kept_len.size(); n++) longest = std::max(longest, kept_len[n]);
-                // the plan of bamm_em_mask (csrc/abi.cpp, mask.hip): per wave two f32 and one u16 per position + a bit mask,
-                // next to one count column of 4^(K+1) u64 cells, within 160 KiB
-                auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-                const size_t wave_bytes = 2 * up16((size_t)longest * 4) + up16((size_t)longest * 2) + up16(((size_t)longest / 32 + 2) * 4);
-                if (longest > 65535u || wave_bytes + up16((size_t(1) << (2 * (motif.K + 1))) * 8) > 160u * 1024u) die("Error: --advanceEM keeps a sequence's windows in the LDS of one wavefront (about 16 000 positions at most); "
+                if (longest > 65535u) die("Error: --advanceEM lists a sequence's windows as 16-bit indices (65 535 positions at most); "
                                           "the longest sequence here has " + std::to_string(longest) + ".");
+                if ((size_t(1) << (2 * (motif.K + 1))) * 8 > 160u * 1024u) die("Error: --advanceEM needs one column of the count table in LDS (order 6 at most).");
             }
             // one std::thread per rank, not an OpenMP team (which may come back smaller than asked for and leave ranks
             // out of the collective); a rank that still fails aborts every communicator so that its peers return

@@ -147,8 +147,10 @@ int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
  * any number of EM handles -- CV folds pass a mask instead of copying (FDR.cpp:49-57).
  * Any length: sequences up to BAMM_MAX_SEQ_POSITIONS go through the register-resident kernels, longer
  * ones through a window-by-window path with identical results (EM passes, getR, the scorer);
- * bamm_seed_from_pwm and bamm_em_mask keep a per-wave LDS plan and refuse sets whose longest
- * sequence exceeds it (about 10 000 / 16 000 positions) with BAMM_ERR_UNSUPPORTED.              */
+ * bamm_seed_from_pwm and bamm_em_mask keep per-wave arrays over one sequence: in LDS up to about
+ * 10 000 / 16 000 positions, in a global scratch region per wave beyond (same arithmetic, slower);
+ * bamm_em_mask refuses sequences beyond 65 535 positions (16-bit window lists) and orders > 6 with
+ * BAMM_ERR_UNSUPPORTED.                                                                          */
 int  bamm_seqs_upload(bamm_ctx* ctx, const bamm_packed* p, uint64_t begin, uint64_t end,
                       bamm_seqs** out);
 int  bamm_seqs_destroy(bamm_seqs* s);

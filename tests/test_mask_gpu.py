@@ -15,7 +15,10 @@ from tests.test_parity_gpu import make_em
 pytestmark = pytest.mark.gpu
 
 CASES = [d for d in SMALL_CASES if d["W"] >= 2] + [
-    dict(name="m_long", N=6, L0=6100, W=12, K=2, ss=True, ragged=2000, n_frac=0.0005)]      # M = 80..128
+    dict(name="m_long", N=6, L0=6100, W=12, K=2, ss=True, ragged=2000, n_frac=0.0005),      # M = 80..128
+    # beyond the per-wave LDS arrays (~16 000 positions at k = 2): the arrays live in a global scratch region per wave
+    dict(name="m_xlong", N=5, L0=14000, W=10, K=2, ragged=9000, n_frac=0.0002),
+    dict(name="m_xlong_k4", N=4, L0=30000, W=8, K=4, ss=True, ragged=12000)]
 
 
 @pytest.mark.parametrize("oq", [False, True], ids=["fixq", "optq"])

@@ -59,8 +59,11 @@ def mt19937_canonical(n):
 
 @pytest.mark.parametrize("spec", [dict(name="s_k2", N=300, L0=120, W=11, K=2, n_frac=0.01, ragged=40),
                                   dict(name="s_k1_ss", N=200, L0=90, W=7, K=1, ss=True, ragged=85),
-                                  dict(name="s_long", N=7, L0=3000, W=15, K=2, ragged=1090, n_frac=0.0005)],
-                         ids=["k2_ds_N", "k1_ss_short", "k2_ds_L8181"])
+                                  dict(name="s_long", N=7, L0=3000, W=15, K=2, ragged=1090, n_frac=0.0005),
+                                  # beyond the per-wave LDS arrays (~10 000 positions): the arrays live in global scratch
+                                  dict(name="s_xlong", N=9, L0=9000, W=12, K=2, ragged=4000, n_frac=0.0002),
+                                  dict(name="s_xlong_ss", N=5, L0=40000, W=9, K=1, ss=True, ragged=25000)],
+                         ids=["k2_ds_N", "k1_ss_short", "k2_ds_L8181", "k2_ds_L26001", "k1_ss_L65000"])
 def test_seed_from_pwm_matches_oracle(spec, gpu_ctx, orc):
     """The ABI entry on its own: uniform variates from the documented recipe, counts turned into a
     model by the oracle-side formulas, against orc_init_from_pwm."""
