@@ -61,6 +61,13 @@ __device__ __forceinline__ void acc_add(long long* cell, long long v) {
 // q = 1, NaN odds from a degenerate model: the fp64 sums carry them, an integer cannot): bits 40.. of the word.  The
 // update turns a non-zero count back into NaN for llh, which is what the reference's float sum would hold.
 constexpr long long kStatBadUnit = 1ll << 40;
+// A sequence's log-likelihood and sum of responsibilities are rounded to the accumulator's units (2^-24, 2^-30) BEFORE
+// they are summed: fp64 sums of such values are exact (while below 2^29 / 2^23 per block: some 10^7 sequences), so a
+// block's integer contribution is the exact sum of its sequences' and the int64 totals -- hence llh, q and every
+// model that follows -- do not depend on how the sequences are split over waves, blocks or ranks.
+// (x + C) - C with C = 1.5 * 2^(52 - bits): the first add rounds to nearest-even at 2^-bits, the second is exact.
+__device__ __forceinline__ double stat_round_llh(double x) { return (x + 402653184.0) - 402653184.0; }      // 1.5 * 2^28
+__device__ __forceinline__ double stat_round_sumr(double x) { return (x + 6291456.0) - 6291456.0; }          // 1.5 * 2^22
 __device__ __forceinline__ double stat_nseq(long long word) { return (double)(word & (kStatBadUnit - 1ll)); }
 __device__ __forceinline__ bool stat_bad(long long word) { return (word >> 40) != 0ll; }
 // a block's three statistics (threads 0..2 call this with their own k)

@@ -590,8 +590,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         for (int m = 0; m < M; m++) U[m] = U[m] * invZs; // EM.cpp:185-187
         // EM.cpp:195.  v_log_f32 (log2, 1 ulp of its result) times ln 2: as close to logf(Z) as Z itself is
         // known (Z carries half an ulp of its own); the sum runs in fp64
-        llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);
-        sumr_acc += (double)invZ;                        // sum_i r[i] = 1 - (1-q)/Z  (EM.cpp:509-513), finished below
+        llh_acc += stat_round_llh((double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f));
+        sumr_acc += stat_round_sumr((double)one_minus_q * (double)invZ);   // sum_i r[i] = 1 - (1-q)/Z  (EM.cpp:509-513), finished below
         seq_cnt++;
 
         if (WRITE_R) {                                   // EM::getR layout: r[L-W-i], i = p-W+1
@@ -692,7 +692,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     lds_drain();
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
-        stat_lds[wave * 3 + 1] = (double)seq_cnt - (double)one_minus_q * sumr_acc;
+        stat_lds[wave * 3 + 1] = (double)seq_cnt - sumr_acc;
         stat_lds[wave * 3 + 2] = (double)seq_cnt;
     }
     __syncthreads();

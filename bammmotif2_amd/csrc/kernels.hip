@@ -219,8 +219,8 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
         const float invZs = ACCUM ? invZ * a.fix_scale : invZ;
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZs; // EM.cpp:185-187 (r/Z within 1 ulp)
-        llh_acc += (double)logf(Z);                      // EM.cpp:195
-        sumr_acc += 1.0 - (double)one_minus_q / (double)Z;  // = sum_i r[i]  (EM.cpp:509-513)
+        llh_acc += stat_round_llh((double)logf(Z));      // EM.cpp:195
+        sumr_acc += 1.0 - stat_round_sumr((double)one_minus_q / (double)Z);  // = sum_i r[i]  (EM.cpp:509-513)
         seq_cnt++;
 
         if (WRITE_R && a.list_r != nullptr) {
@@ -437,8 +437,8 @@ __global__ void __launch_bounds__(THREADS) k_e_slice(EmKernelArgs a, uint32_t j0
             const float invZ = 1.0f / Z;
 #pragma unroll
             for (int m = 0; m < M; m++) U[m] = U[m] * invZ;
-            llh_acc += (double)logf(Z);
-            sumr_acc += 1.0 - (double)one_minus_q / (double)Z;
+            llh_acc += stat_round_llh((double)logf(Z));
+            sumr_acc += 1.0 - stat_round_sumr((double)one_minus_q / (double)Z);
             seq_cnt++;
         }
 #pragma unroll

@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(256) k_long_em(EmKernelArgs a, int accum, int 
             zpart += (double)(window_product(s, a.s, i, W, Y, LW1) * pos_i);     // EM.cpp:180
         const float Z = one_minus_q + (float)block_sum(zpart, sh);               // EM.cpp:154,181
         const float invZ = 1.0f / Z;
-        llh_acc += (double)logf(Z);                        // EM.cpp:195
-        sumr_acc += 1.0 - (double)one_minus_q / (double)Z; // = sum_i r[i]  (EM.cpp:509-513)
+        llh_acc += stat_round_llh((double)logf(Z));        // EM.cpp:195
+        sumr_acc += 1.0 - stat_round_sumr((double)one_minus_q / (double)Z); // = sum_i r[i]  (EM.cpp:509-513)
         seq_cnt++;
         if (!accum && !write_r) continue;
         float* ro = write_r ? a.r_out + (a.sv.pos_off[seq] - a.r_base) : nullptr;

@@ -37,6 +37,10 @@ __device__ __forceinline__ void acc_add(long long* cell, long long v) {      // 
     (void)__hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// as device_utils.h: a sequence's statistics rounded to the accumulator's units before they are summed (exact sums)
+__device__ __forceinline__ double stat_round_llh(double x) { return (x + 402653184.0) - 402653184.0; }      // 1.5 * 2^28
+__device__ __forceinline__ double stat_round_sumr(double x) { return (x + 6291456.0) - 6291456.0; }          // 1.5 * 2^22
+
 __device__ __forceinline__ float mask_wave_sum(float x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -294,8 +298,8 @@ __global__ void __launch_bounds__(256) k_mask_e(MaskKernelArgs a) {
         const float nf = (1.0f - q) + mask_wave_sum(part);           // :399,417
         if (lane == 0 && !(cnt && w.lst[0] == 0u)) a.r[base] = a.r[base] / nf;   // :421 (a listed slot 0 holds 0)
         for (uint32_t e = (uint32_t)lane; e < cnt; e += 64u) a.r[base + w.lst[e]] = w.f[e] / nf;   // :422-424
-        llh += (double)logf(nf);                                     // :432
-        sum_r += (double)((nf - (1.0f - q)) / nf);
+        llh += stat_round_llh((double)logf(nf));                     // :432; rounded per sequence as in the EM kernels
+        sum_r += stat_round_sumr((double)((nf - (1.0f - q)) / nf));
         nseq += 1.0;
         wave_lds_sync();
     }

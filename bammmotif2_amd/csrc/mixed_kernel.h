@@ -329,8 +329,8 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         const float invZs = ACCUM ? invZ * (a.fix_scale * 256.0f) : invZ;    // 2^8: the fixed-point split below starts there
 #pragma unroll
         for (int m = 0; m < M; m++) U[m] = U[m] * invZs;     // EM.cpp:185-187
-        llh_acc += (double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f);          // EM.cpp:195
-        sumr_acc += (double)invZ;
+        llh_acc += stat_round_llh((double)(__builtin_amdgcn_logf(Z) * 0.693147180559945309f));          // EM.cpp:195
+        sumr_acc += stat_round_sumr((double)one_minus_q * (double)invZ);                 // 1 - sum_i r[i]  (EM.cpp:509-513)
         seq_cnt++;
 
         if (WRITE_R) {                                       // EM::getR layout: r[L-W-i], i = p-W+1
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     __syncthreads();
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
-        stat_lds[wave * 3 + 1] = (double)seq_cnt - (double)one_minus_q * sumr_acc;
+        stat_lds[wave * 3 + 1] = (double)seq_cnt - sumr_acc;
         stat_lds[wave * 3 + 2] = (double)seq_cnt;
     }
     __syncthreads();
