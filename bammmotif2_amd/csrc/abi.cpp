@@ -1154,6 +1154,11 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     // launches of one pass: every length bucket, split into the sequences the grouped-column kernel
     // takes (no exception, or all of them within its virtual rows) and the rest
     const bool want_grouped = !sliced && prm->K <= 3u && c->use_grouped;
+    // A shard of a sharded set plans its kernels as the whole set would: which rows a sequence is multiplied through
+    // (mixed or uniform) decides the last bit of its responsibilities, so the choice follows the GLOBAL size the caller
+    // names (n_seqs_bound / n_seqs_global; this shard's own count when it names neither) -- a bucket's share of it is
+    // estimated from this shard's -- and the model does not depend on the number of ranks.
+    const double world_factor = seqs->n ? std::max(1.0, (double)std::max<uint64_t>(prm->n_seqs_bound, prm->n_seqs_global) / (double)seqs->n) : 1.0;
     for (auto& b : seqs->buckets) {
         if (b.mclass == kLongClass || global_tables) {       // beyond the length classes / tables beyond LDS: long_seq.hip
             EmBucket eb;
@@ -1176,7 +1181,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
         }
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
-            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, (uint64_t)b.count * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
+            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, (uint64_t)((double)b.count * world_factor) * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge

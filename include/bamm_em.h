@@ -174,7 +174,10 @@ typedef struct bamm_em_params {
                               * ranks; sizes the unit of the integer count accumulator (2^-40
                               * up to 4M sequences, coarser beyond: the int64 sums never
                               * overflow).  0 = n_seqs_global, else this handle's own count.
-                              * Ranks that all-reduce together must agree on it.               */
+                              * Ranks that all-reduce together must agree on it.  A shard also
+                              * plans its kernels from it (as the whole set would: the rows a
+                              * window is multiplied through decide the last bit of r), so that
+                              * the model does not depend on the number of ranks.               */
 } bamm_em_params;
 
 void bamm_em_default_params(bamm_em_params* p);

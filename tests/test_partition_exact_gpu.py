@@ -4,8 +4,9 @@ on how the sequences are split over waves, blocks or ranks (sequences
 Counts were exact integers from round 1 on; llh and sum_r used to be fp64 sums per wave and block, rounded to the
 accumulator's units once per block, so their last bits followed the partition.  Each sequence's contribution is now
 rounded to those units BEFORE it is summed (device_utils.h: stat_round_llh / stat_round_sumr), which makes every sum
-exact.  Holds as long as a sequence goes through the same kernel flavour on either side (the flavour is pinned here;
-uniform and mixed rows multiply a window's odds in different groupings and differ in the last bit of r).
+exact.  Holds as long as a sequence goes through the same kernel flavour on either side: uniform and mixed rows
+multiply a window's odds in different groupings and differ in the last bit of r, which is why a shard plans its
+kernels from the global size the caller names (n_seqs_bound), not from its own.
 Reference lines: EM.cpp:195 (llh), EM.cpp:509-513 (sum of r for q), EM.cpp:236-242 (counts)."""
 import ctypes as C
 
@@ -18,8 +19,9 @@ from bammmotif2_amd import synth
 pytestmark = pytest.mark.gpu
 
 SHAPES = [
-    dict(N=9000, L0=200, W=20, K=2, n_frac=0.003, ragged=50, tune=dict(group_layout=3)),     # uniform rows + per-column bucket
-    dict(N=50000, L0=200, W=20, K=2, tune=dict(group_layout=8)),                              # mixed rows
+    dict(N=9000, L0=200, W=20, K=2, n_frac=0.003, ragged=50, tune=dict()),                  # uniform rows + per-column bucket
+    dict(N=50000, L0=200, W=20, K=2, tune=dict()),                                           # mixed rows: planned from the GLOBAL size
+    dict(N=50000, L0=200, W=20, K=2, tune=dict(group_layout=3)),                              # uniform rows at that size
     dict(N=6000, L0=150, W=15, K=1, ss=True, ragged=40, tune=dict()),
     dict(N=4000, L0=200, W=20, K=3, ragged=30, tune=dict()),
     dict(N=2500, L0=400, W=24, K=4, ragged=80, n_frac=0.002, tune=dict()),                   # column-sliced path
@@ -45,7 +47,7 @@ def accumulator(ctx, hip, pk, begin, end, shape, vbg, A, v0, launch=(0, 0)):
     return h
 
 
-@pytest.mark.parametrize("shape", SHAPES, ids=[f"K{d['K']}_W{d['W']}_N{d['N']}" for d in SHAPES])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"K{d['K']}_W{d['W']}_N{d['N']}_{i}" for i, d in enumerate(SHAPES)])
 def test_accumulator_is_the_same_integers_for_any_partition(shape, gpu_ctx):
     hip = C.CDLL("libamdhip64.so")
     N, W, K = shape["N"], shape["W"], shape["K"]
