@@ -27,3 +27,10 @@ int launch_em_mix(int mclass, bool accum, bool write_r, const GrpKernelArgs& a, 
 }
 
 }  // namespace bamm
+
+#ifdef BAMM_PHASE_CLOCK
+// debug builds only: the phase clocks of the last k_em_mix launch of this translation unit ([256 blocks][16], 100 MHz ticks)
+extern "C" int bamm_debug_phase_clock(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bamm::g_phase_clock), 256 * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     constexpr uint32_t Y = 64u, Ys = 65u;                      // K = 2
     if (ga.e.stop != nullptr && *ga.e.stop != 0u) return;    // optimize(): the stop rule fired in an earlier pass
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    BAMM_PHASE(0);
     const EmKernelArgs& a = ga.e;
     const GrpGeom& g = ga.g;
     const uint32_t W = a.W, T = g.T, B = g.mixB;             // T = B + A groups
@@ -94,6 +95,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
                 staged = true;
             }
         }
+        BAMM_PHASE(1);                                       // the fused update is done
         if (!staged)
             for (uint32_t i = threadIdx.x; i < W * Ys; i += THREADS) s1w[i] = a.s[i];
         for (uint32_t i = threadIdx.x; i < (R5T - R5N) * rs5; i += THREADS) sg5[R5N * rs5 + i] = 1.0f;
@@ -130,6 +132,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         }
     }
 
+    BAMM_PHASE(2);                                           // tables built, counts zeroed
     const float q = (ACCUM && ga.fused) ? q_fused : *a.q;
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles: (row, group)
@@ -422,7 +425,9 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
 
     // ---- block epilogue (the statistics take the narrow odds table's place: every wave must be past its last sequence)
     lds_drain();
+    BAMM_PHASE(3);                                           // wave 0 is through its sequences
     __syncthreads();
+    BAMM_PHASE(4);                                           // ... and the block's slowest wave
     if (lane == 0) {
         stat_lds[wave * 3 + 0] = llh_acc;
         stat_lds[wave * 3 + 1] = (double)seq_cnt - sumr_acc;
@@ -455,6 +460,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             }
         }
         __syncthreads();
+        BAMM_PHASE(5);                                       // the log is folded
         for (uint32_t o = threadIdx.x; o < W * Y; o += THREADS) {           // o = y*W + j: consecutive global cells
             const uint32_t yy = o / W, j = o - yy * W;
             unsigned long long acc = n1[j * Y + yy] + (j < n1c ? n1p[j * Y + yy] : 0ull);
@@ -490,6 +496,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         for (uint32_t w = 0; w < WAVES; w++) acc += stat_lds[w * 3 + threadIdx.x];
         acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
     }
+    BAMM_PHASE(6);                                           // marginalised, atomics issued (thread 0's)
 }
 
 template <int M, int A, int NQ, int THREADS>

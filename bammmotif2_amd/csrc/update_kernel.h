@@ -14,6 +14,7 @@
 //     of that slot finished with the kernel before: stream order).
 #pragma once
 #include "device_utils.h"
+#include "phase_clock.h"
 
 namespace bamm {
 namespace {
@@ -73,7 +74,9 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
     }
     if (writer && a.acc_zero != nullptr)                             // the ring slot two passes ahead
         for (uint32_t i = tid; i < YK * W + 3u; i += nt) a.acc_zero[i] = 0ll;
+    BAMM_PHASE(8);
     __syncthreads();
+    BAMM_PHASE(9);
     // ---- phase B: n[k][y][j] = (((0 + c_0) + c_1) + c_2) + c_3 over the four rows c_d = n[k+1][d * 4^(k+1) + y][j] of the
     // next order, themselves sums of four, down to n_K: nested loops over the K - k levels (at most four: the
     // tables fit LDS for K <= 4 only), each level summed from 0.0f upwards as the reference's += does
@@ -114,7 +117,9 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
             nk[i] = s0;
         }
     }
+    BAMM_PHASE(10);
     __syncthreads();
+    BAMM_PHASE(11);
     // ---- phase C: the v chain of a cell (y, j) of order k, from order 0 up (Motif.h:100-135)
     //   v[0][y0][j] = (n[0][y0][j] + A[0][j] * vbg[0][y0]) / (sum_y' n[0][y'][j] + A[0][j])
     //   v[kk][ykk][j] = j < kk ? v[kk-1][ykk mod 4^kk][j]
@@ -156,6 +161,7 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
         if (s_lds != nullptr) s_lds[(size_t)j * Ys + YK] = 1.0f;
         else if (writer) a.s[(size_t)j * Ys + YK] = 1.0f;
     }
+    BAMM_PHASE(12);
     // v_diff (EM.cpp:102-108): wave sums, then the wave results.  Only who needs it: the writer (status, trace)
     // and, inside optimize(), every block (the stop rule decides whether the block runs its pass)
     double v_diff = 0.0;
