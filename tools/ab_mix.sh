@@ -13,7 +13,8 @@ one() { python3 bench.py "${@:2}" --no-cpu-baseline --no-extras 2>/dev/null | py
 run() {
   one "$1 1M passes 21-220" --nseq 1000000 --steps 200 --warmup 20; one "$1 1M passes 21-220" --nseq 1000000 --steps 200 --warmup 20
   one "$1 1M passes 6-25  " --nseq 1000000 --steps 20 --warmup 5; one "$1 1M passes 6-25  " --nseq 1000000 --steps 20 --warmup 5
-  one "$1 125k            " --nseq 125000 --steps 200 --warmup 20
+  one "$1 125k            " --nseq 125000 --steps 200 --warmup 20; one "$1 125k            " --nseq 125000 --steps 200 --warmup 20
+  one "$1 50k             " --nseq 50000 --steps 300 --warmup 30; one "$1 50k             " --nseq 50000 --steps 300 --warmup 30
   one "$1 k=1             " --nseq 1000000 --order 1 --steps 100 --warmup 20
   one "$1 k=3             " --nseq 1000000 --order 3 --steps 100 --warmup 20
 }
