@@ -328,19 +328,23 @@ int bamm_unpack_y(const bamm_packed* p, uint32_t K, uint32_t* y_out) {
         return BAMM_ERR_ARG;
     }
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
-    uint64_t o = 0;
-    for (uint64_t n = 0; n < p->n_seqs; n++) {
-        const uint32_t* w = p->words + p->word_off[n];
-        uint32_t roll = 0;
-        for (uint32_t i = 0; i < p->len[n]; i++) {
-            const uint32_t base = (w[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
-            roll = (roll << 2) | base;
-            y_out[o + i] = roll & maskY;
+    std::vector<uint64_t> pos0(p->n_seqs + 1, 0);             // first output cell of every sequence
+    for (uint64_t n = 0; n < p->n_seqs; n++) pos0[n + 1] = pos0[n] + p->len[n];
+    const uint32_t T = std::max<uint32_t>(1, std::min<uint64_t>(host_threads(), p->n_seqs / 1024 + 1));
+    parallel_ranges(p->n_seqs, T, [&](uint32_t, uint64_t n0, uint64_t n1) {      // 80 M cells at 200k x 401: 0.13 s on one thread
+        for (uint64_t n = n0; n < n1; n++) {
+            const uint32_t* w = p->words + p->word_off[n];
+            uint32_t* out = y_out + pos0[n];
+            uint32_t roll = 0;
+            for (uint32_t i = 0; i < p->len[n]; i++) {
+                const uint32_t base = (w[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
+                roll = (roll << 2) | base;
+                out[i] = roll & maskY;
+            }
+            for (uint64_t e = p->exc_off[n]; e < p->exc_off[n + 1]; e++)
+                out[p->exc_pos[e]] = p->exc_kmer[e] & maskY;
         }
-        for (uint64_t e = p->exc_off[n]; e < p->exc_off[n + 1]; e++)
-            y_out[o + p->exc_pos[e]] = p->exc_kmer[e] & maskY;
-        o += p->len[n];
-    }
+    });
     return BAMM_OK;
 }
 

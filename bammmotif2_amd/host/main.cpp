@@ -8,6 +8,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <memory>
 #include <thread>
 #include <sys/stat.h>
 
@@ -382,6 +383,10 @@ int main(int nargs, char* args[]) {
     size_t negN = 0;                        // negatives the reference would hold (all of them, sampled or not)
     std::vector<uint32_t> neg_cv_len;       // lengths of the folds' subset (every cvFold-th negative)
     std::vector<uint64_t> neg_off{0};
+    std::vector<uint32_t> neg_len;          // all negatives: only sampled for --scoreSeqset
+    std::thread neg_thread;                 // samples, packs and uploads the negatives beside the main run
+    std::string neg_err;
+    double neg_t_sample = 0, neg_t_pack = 0;
     std::vector<uint32_t> kept_len;
     // The plan: which GPU slot does what (FDR.cpp:37-127, mainBaMM.cpp:131-147).
     //   * the main EM run is sharded over its group of slots, one all-reduce of the count table per iteration: RCCL when
@@ -468,47 +473,61 @@ int main(int nargs, char* args[]) {
             stage(distinct ? "RCCL communicator over the GPUs" : "host-staged communicator over the contexts");
         }
         if (o.score || o.FDR) {
-            // negative set sampled from the s-mer statistics of the (kept) positives, mainBaMM.cpp:97-116
+            // negative set sampled from the s-mer statistics of the (kept) positives, mainBaMM.cpp:97-116.  The sampler
+            // (host, all cores), the packing and the upload run on a thread of their own BESIDE the seeding and the main
+            // EM run, which need none of it; the first consumer -- the folds, --scoreSeqset -- waits (ensure_negatives).
             size_t mFold = o.mFold;
             const size_t minSeqN = 5000;
             if (posN < minSeqN) mFold = minSeqN / posN + (minSeqN % posN ? 1 : 0);
-            std::vector<uint32_t> ys(use->total_len ? use->total_len : 1);
-            if (bamm_unpack_y(use, (uint32_t)o.sOrder, ys.data())) die_abi("unpack");
-            std::vector<uint64_t> uoff(use->n_seqs + 1, 0);
-            for (uint64_t n = 0; n < use->n_seqs; n++) uoff[n + 1] = uoff[n] + use->len[n];
-            negN = (size_t)use->n_seqs * mFold;
+            const size_t n_pos = use->n_seqs;
+            negN = n_pos * mFold;
             // the folds of --FDR score every cvFold-th negative and nothing else (FDR.cpp:58-60): without --scoreSeqset
             // only those are generated, packed and uploaded (the others still consume their draws of the stream)
             const size_t stride = (o.FDR && !o.score) ? cvF : 0;
-            if (sample_negatives(ys.data(), uoff.data(), use->n_seqs, (uint32_t)o.sOrder, mFold, o.genericNeg, neg_codes, neg_off, err, stride)) die(err);
-            stage("negative set: sample (host, rand() stream of the reference)");
-            bamm_packed* npk = nullptr;
-            if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) die_abi("packing negatives");
-            if (stride > 1) {                                // what was sampled IS the folds' subset
-                for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_cv_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
-                for (size_t d = 0; d < ndev; d++)
-                    if (runs_folds(d) && bamm_seqs_upload(devs[d].ctx, npk, 0, npk->n_seqs, &devs[d].neg_cv)) die_abi("upload negatives");
-            } else {
-                if (bamm_seqs_upload(devs[0].ctx, npk, 0, npk->n_seqs, &devs[0].neg)) die_abi("upload negatives");
-                if (o.FDR) {                                 // the folds' subset as a set of its own, on the slots that run folds
-                    std::vector<uint64_t> sub_off{0};
-                    ByteVec sub_codes;
-                    for (size_t i = 0; i + cvF <= negN; i += cvF) {
-                        sub_codes.insert(sub_codes.end(), neg_codes.begin() + (ptrdiff_t)neg_off[i], neg_codes.begin() + (ptrdiff_t)neg_off[i + 1]);
-                        sub_off.push_back(sub_codes.size());
-                        neg_cv_len.push_back((uint32_t)(neg_off[i + 1] - neg_off[i]));
-                    }
-                    bamm_packed* spk = nullptr;
-                    if (bamm_pack_codes(sub_codes.data(), sub_off.data(), sub_off.size() - 1, 1, &spk)) die_abi("packing negatives");
-                    for (size_t d = 0; d < ndev; d++)
-                        if (runs_folds(d) && bamm_seqs_upload(devs[d].ctx, spk, 0, spk->n_seqs, &devs[d].neg_cv)) die_abi("upload negatives");
-                    bamm_packed_free(spk);
+            neg_thread = std::thread([&, use, filtered, n_pos, mFold, stride] {
+                auto fail_abi = [&](const char* what) { neg_err = std::string("Error: ") + what + ": " + bamm_last_error(); };
+                auto t0 = std::chrono::high_resolution_clock::now();
+                std::string serr;
+                {
+                    std::vector<uint32_t, DefaultInitAlloc<uint32_t>> ys(use->total_len ? use->total_len : 1);   // every cell is written
+                    std::vector<uint64_t> uoff(n_pos + 1, 0);
+                    int rc = bamm_unpack_y(use, (uint32_t)o.sOrder, ys.data());
+                    for (uint64_t n = 0; n < n_pos; n++) uoff[n + 1] = uoff[n] + use->len[n];
+                    if (filtered) bamm_packed_free(filtered);     // the thread is the last reader of the kept positives' packing
+                    if (rc) return fail_abi("unpack");
+                    if (sample_negatives(ys.data(), uoff.data(), n_pos, (uint32_t)o.sOrder, mFold, o.genericNeg, neg_codes, neg_off, serr, stride)) { neg_err = serr; return; }
                 }
-            }
-            bamm_packed_free(npk);
-            stage("negative set: pack + upload");
+                auto t1 = std::chrono::high_resolution_clock::now();
+                neg_t_sample = std::chrono::duration<double>(t1 - t0).count();
+                bamm_packed* npk = nullptr;
+                if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) return fail_abi("packing negatives");
+                if (stride > 1) {                                // what was sampled IS the folds' subset
+                    for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_cv_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
+                    for (size_t d = 0; d < ndev; d++)
+                        if (runs_folds(d) && bamm_seqs_upload(devs[d].ctx, npk, 0, npk->n_seqs, &devs[d].neg_cv)) return fail_abi("upload negatives");
+                } else {
+                    if (bamm_seqs_upload(devs[0].ctx, npk, 0, npk->n_seqs, &devs[0].neg)) return fail_abi("upload negatives");
+                    if (o.FDR) {                                 // the folds' subset as a set of its own, on the slots that run folds
+                        std::vector<uint64_t> sub_off{0};
+                        ByteVec sub_codes;
+                        for (size_t i = 0; i + cvF <= negN; i += cvF) {
+                            sub_codes.insert(sub_codes.end(), neg_codes.begin() + (ptrdiff_t)neg_off[i], neg_codes.begin() + (ptrdiff_t)neg_off[i + 1]);
+                            sub_off.push_back(sub_codes.size());
+                            neg_cv_len.push_back((uint32_t)(neg_off[i + 1] - neg_off[i]));
+                        }
+                        bamm_packed* spk = nullptr;
+                        if (bamm_pack_codes(sub_codes.data(), sub_off.data(), sub_off.size() - 1, 1, &spk)) return fail_abi("packing negatives");
+                        for (size_t d = 0; d < ndev; d++)
+                            if (runs_folds(d) && bamm_seqs_upload(devs[d].ctx, spk, 0, spk->n_seqs, &devs[d].neg_cv)) return fail_abi("upload negatives");
+                        bamm_packed_free(spk);
+                    }
+                }
+                bamm_packed_free(npk);
+                neg_t_pack = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t1).count();
+            });
+        } else if (filtered) {
+            bamm_packed_free(filtered);
         }
-        if (filtered) bamm_packed_free(filtered);
     }
     // scorer over a resident set: MOPS scores (concatenated), ZOOPS maxima
     auto score_set = [&](bamm_ctx* ctx, bamm_seqs* set, const std::vector<uint32_t>& lens, const Motif& m, std::vector<float>& mops,
@@ -527,8 +546,16 @@ int main(int nargs, char* args[]) {
         zoops.resize(lens.size());
         return 0;
     };
-    std::vector<uint32_t> neg_len;                           // all negatives: only sampled for --scoreSeqset
-    if (o.score) for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
+    // main thread only, before the first consumer of the negative set (the folds, --scoreSeqset)
+    auto ensure_negatives = [&]() {
+        if (!neg_thread.joinable()) return;
+        neg_thread.join();
+        if (!neg_err.empty()) die(neg_err);
+        if (o.score) for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
+        if (timing) std::cerr << "[timing-beside] negative set: sample (host, rand() stream of the reference) " << neg_t_sample
+                              << " s, pack + upload " << neg_t_pack << " s, on a thread of their own beside the stages above" << std::endl;
+        stage("negative set: wait for the sampler thread");
+    };
     // kept positives: FASTA codes / headers in the same order as the resident set
     std::vector<std::string> kept_headers;
     std::vector<uint8_t> kept_codes;
@@ -613,6 +640,7 @@ int main(int nargs, char* args[]) {
         const std::string mbase = o.basename + "_motif_" + std::to_string(n + 1);
         if (o.saveInitial && motif_write(o.out_dir, o.basename + "_init_motif_" + std::to_string(n + 1), motif, err)) die(err);
         std::thread fold_thread;                             // overlap mode: this motif's folds train while its main run does
+        if (overlap) ensure_negatives();                     // the folds score negatives
         if (overlap) fold_thread = std::thread([&, n] { run_folds(n, fold_results[n]); });
         struct FoldJoin { std::thread& t; ~FoldJoin() { if (t.joinable()) t.join(); } } fold_join{fold_thread};
         if (o.EM) {
@@ -737,6 +765,7 @@ int main(int nargs, char* args[]) {
         }
         if (motif_write(o.out_dir, mbase, motif, err)) die(err);
         stage("write model (+ .counts/.positions)");
+        if (o.score) ensure_negatives();
         if (o.score) {                                       // mainBaMM.cpp:171-236
             if (o.verbose) std::cout << std::endl << "*************************" << std::endl << "*    Score Sequences    *" << std::endl << "*************************" << std::endl << std::endl;
             Motif sm = motif;
@@ -759,6 +788,7 @@ int main(int nargs, char* args[]) {
         }
     }
 
+    ensure_negatives();
     if (o.FDR) {                                             // mainBaMM.cpp:243-265, FDR.cpp:28-145
         if (o.verbose) std::cout << std::endl << "***********************" << std::endl << "*   BaMM validation   *" << std::endl << "***********************" << std::endl;
         const size_t cv = o.cvFold, P = kept_len.size();

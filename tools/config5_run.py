@@ -47,6 +47,9 @@ gpu = sum(float(s) for n, s in stages if "EM" in n or "GPU" in n)
 print("  stage                                                          seconds")
 for n, s in stages:
     print("  %-62s %8.3f" % (n, float(s)))
+for l in r.stderr.splitlines():
+    if l.startswith("[timing-beside]"):
+        print("  beside the stages above:", l[len("[timing-beside] "):])
 print("  GPU stages (EM runs, fold EMs + scoring) %.3f s of %.3f s in all; the rest is host work" % (gpu, sum(float(s) for _, s in stages)))
 print("\n".join(l for l in r.stdout.splitlines() if "Runtime" in l))
 if r.returncode:
