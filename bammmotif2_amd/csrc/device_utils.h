@@ -79,6 +79,13 @@ __device__ __forceinline__ void acc_add_stat(long long* acc, uint32_t cells, uin
     }
     acc_add(acc + cells + k, __double2ll_rn(scaled));
 }
+// a 64-bit value from another lane of the quad (DPP quad_perm control CTRL: 0xB1 = lanes 1,0,3,2; 0x4E = lanes 2,3,0,1)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long quad_perm_u64(unsigned long long x) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)x, CTRL, 0xf, 0xf, true);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_mov_dpp((int)(uint32_t)(x >> 32), CTRL, 0xf, 0xf, true);
+    return ((unsigned long long)hi << 32) | lo;
+}
 // 128-bit LDS gather.  hipcc splits a float4 LDS load whose components are consumed under
 // different (even wave-uniform) conditions into b32/b64 pieces, which costs 2-4x the LDS cycles
 // (tools/lds_bench2.hip), so the read is issued by hand; lds_wait() retires all of them and

@@ -439,6 +439,7 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         // logged virtual-row sums -> single-column bins [j][y], which take the wide odds table's place
         for (uint32_t i = threadIdx.x; i < W * Y; i += THREADS) n1[i] = 0ull;
         __syncthreads();
+        BAMM_PHASE(7);                                       // statistics parked, bins zeroed
         constexpr uint32_t NB = 8;
         for (uint32_t e0 = 0; e0 < nlog; e0 += 64u * NB) {
             unsigned long long acc[NB];
@@ -461,33 +462,62 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         }
         __syncthreads();
         BAMM_PHASE(5);                                       // the log is folded
-        for (uint32_t o = threadIdx.x; o < W * Y; o += THREADS) {           // o = y*W + j: consecutive global cells
-            const uint32_t yy = o / W, j = o - yy * W;
-            unsigned long long acc = n1[j * Y + yy] + (j < n1c ? n1p[j * Y + yy] : 0ull);
-            // rows whose position c carries yy: c digits above the 3-mer, G-1-c below it are free
-            if (j < 3u * B) {
+        // Marginalisation in units of 16 table rows, every lane of every read instruction at work: a cell of a wide group
+        // (64 rows carry its 3-mer) is four units on the four lanes of a quad, summed across the quad with two DPP adds; a
+        // narrow cell is one unit; the wide units come first and fill whole rounds of the block, so no wave runs both
+        // kinds (one item per cell made every wave issue 16 + 64 reads per round with 60 / 40 % of its lanes: the LDS
+        // pipe's 2 us per round).  Every lane starts its sixteen rows elsewhere ((lane + lane / 4) mod 16): at equal
+        // steps the lanes' rows differ in digits that do not reach the bank, rotated they spread over all of them.
+        // Integer sums: any order gives the same total.  The totals go to the bins and from there out in the
+        // accumulator's order (a scattered atomic instruction costs the L2 one operation per cache line it touches).
+        constexpr uint32_t kWideUnits = 4u * (uint32_t)A * 4u * Y;           // [w][c][y][quarter]
+        const uint32_t narrow_cells = 3u * B * Y;
+        const uint32_t rot = ((uint32_t)lane + ((uint32_t)lane >> 2)) & 15u;
+        for (uint32_t u = threadIdx.x; u < kWideUnits + narrow_cells; u += THREADS) {
+            unsigned long long acc = 0ull;
+            uint32_t j, yy;
+            bool owner = true;
+            unsigned long long v[16];
+            if (u < kWideUnits) {                                               // quad-uniform: THREADS and kWideUnits are multiples of 4
+                const uint32_t cell = u >> 2, quarter = u & 3u;
+                yy = cell & (Y - 1u);
+                const uint32_t wc = cell >> 6, w = wc >> 2, c = wc & 3u;
+                j = 3u * B + 4u * w + c;
+                const unsigned long long* tab = cnt6 + (size_t)((uint32_t)A - 1u - w) * R6T;
+                const uint32_t lowd = 2u * (3u - c), lmask = (1u << lowd) - 1u;
+#pragma unroll
+                for (uint32_t rr = 0; rr < 16u; rr++) {
+                    const uint32_t r = quarter * 16u + ((rr + rot) & 15u), h = r >> lowd, l = r & lmask;
+                    v[rr] = tab[((((h << 6) | yy) << lowd) | l) & 4095u];
+                }
+#pragma unroll
+                for (uint32_t rr = 0; rr < 16u; rr++) acc += v[rr];
+                acc += quad_perm_u64<0xB1>(acc);                                 // lanes 1,0,3,2
+                acc += quad_perm_u64<0x4E>(acc);                                 // lanes 2,3,0,1
+                owner = quarter == 0u;
+            } else {
+                const uint32_t cell = u - kWideUnits;
+                yy = cell & (Y - 1u);
+                j = cell >> 6;
                 const uint32_t tt = j / 3u, c = j - 3u * tt;
                 const unsigned long long* tab = cnt5 + (size_t)(B - 1u - tt) * R5T;
                 const uint32_t lowd = 2u * (2u - c), lmask = (1u << lowd) - 1u;
-                unsigned long long part[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
-                for (uint32_t r = 0; r < 16u; r++) {
-                    const uint32_t h = r >> lowd, l = r & lmask;
-                    part[r & 3u] += tab[((((h << 6) | yy) << lowd) | l) & 1023u];
+                for (uint32_t rr = 0; rr < 16u; rr++) {
+                    const uint32_t r = (rr + rot) & 15u, h = r >> lowd, l = r & lmask;
+                    v[rr] = tab[((((h << 6) | yy) << lowd) | l) & 1023u];
                 }
-                acc += (part[0] + part[1]) + (part[2] + part[3]);
-            } else {
-                const uint32_t jj = j - 3u * B, w = jj >> 2, c = jj & 3u;
-                const unsigned long long* tab = cnt6 + (size_t)((uint32_t)A - 1u - w) * R6T;
-                const uint32_t lowd = 2u * (3u - c), lmask = (1u << lowd) - 1u;
-                unsigned long long part[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll 8
-                for (uint32_t r = 0; r < 64u; r++) {
-                    const uint32_t h = r >> lowd, l = r & lmask;
-                    part[r & 3u] += tab[((((h << 6) | yy) << lowd) | l) & 4095u];
-                }
-                acc += (part[0] + part[1]) + (part[2] + part[3]);
+#pragma unroll
+                for (uint32_t rr = 0; rr < 16u; rr++) acc += v[rr];
             }
+            if (owner) n1[j * Y + yy] += acc + (j < n1c ? n1p[j * Y + yy] : 0ull);     // the cell's total, in its bin
+        }
+        BAMM_PHASE(13);
+        __syncthreads();
+        BAMM_PHASE(14);
+        for (uint32_t o = threadIdx.x; o < W * Y; o += THREADS) {               // o = y*W + j: consecutive global cells
+            const uint32_t yy = o / W, j = o - yy * W;
+            const unsigned long long acc = n1[j * Y + yy];
             if (acc) acc_add(a.acc + o, (long long)acc);
         }
     }

@@ -18,7 +18,7 @@ L0, W, K = 200, 20, 2
 pwm = synth.make_pwm(W, 1234)
 ctx = bm.Context(0)
 names = {0: "entry", 8: "  update: loads landed (thread 0)", 9: "  update: barrier A", 10: "  update: lower orders", 11: "  update: barrier B", 12: "  update: chains",
-         1: "update done", 2: "tables built", 3: "wave 0 done", 4: "block done", 5: "log folded", 6: "marginalised + atomics"}
+         1: "update done", 2: "tables built", 3: "wave 0 done", 4: "block done", 7: "  bins zeroed", 5: "log folded", 13: "  sums in the bins", 14: "  barrier", 6: "marginalised + atomics issued"}
 for N in (4096, 125000):
     codes, off = synth.make_sequences(N, L0, pwm, 1234)
     pk = bm.PackedSeqs.from_codes(codes, off, False, seed=42)
