@@ -742,12 +742,16 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                 constexpr uint32_t NR = 1u << (2u * (uint32_t)(G - 1));
                 const uint32_t lowd = 2u * ((uint32_t)G - 1u - c), lmask = (1u << lowd) - 1u;
                 unsigned long long part[4] = {0ull, 0ull, 0ull, 0ull};
+                // (every lane starts its rows elsewhere: at equal steps the lanes' rows differ in digits that do not reach
+                // the bank; integer sums, any order gives the same total)
+                const uint32_t rot = ((uint32_t)lane + ((uint32_t)lane >> 2)) & (NR < 16u ? NR - 1u : 15u);
 #pragma unroll
-                for (uint32_t r = 0; r < NR; r++) {
+                for (uint32_t r0 = 0; r0 < NR; r0++) {
+                    const uint32_t r = (r0 & ~15u) | ((r0 + rot) & (NR < 16u ? NR - 1u : 15u));
                     const uint32_t h = r >> lowd, l = r & lmask;
                     // the (K+G)-mer has exactly c digits above y_c, so the mask is a no-op
                     const uint32_t row = ((((h << (2u * (a.K + 1u))) | yy) << lowd) | l) & (g.Rf - 1u);
-                    for (uint32_t cc = 0; cc < C; cc++) part[r & 3u] += tab[(((size_t)row << logC) + cc) * Ts];
+                    for (uint32_t cc = 0; cc < C; cc++) part[r0 & 3u] += tab[(((size_t)row << logC) + cc) * Ts];
                 }
                 acc += (part[0] + part[1]) + (part[2] + part[3]);
             }
