@@ -24,6 +24,19 @@ struct UpdateOut {
     bool fired;     // the stop rule fired (every thread; false when a.stop == nullptr)
 };
 
+// sum of the 4^D leaves under `row` in the reference's nesting (EM.cpp:247-254): each level adds its four children in
+// ascending order, from 0.0f; the loads of a cell are independent and issued together
+template <int D>
+__device__ __forceinline__ float update_count_tree(const float* nK, uint32_t W, uint32_t j, uint32_t row, uint32_t stride) {
+    if constexpr (D == 0) return nK[(size_t)row * W + j];
+    else {
+        float s = 0.0f;
+#pragma unroll
+        for (uint32_t d = 0; d < 4; d++) s += update_count_tree<D - 1>(nK, W, j, row + d * stride, stride * 4u);
+        return s;
+    }
+}
+
 // CONSUME: the standalone kernel's semantics -- the accumulator is zeroed as it is read.  Fused callers leave it
 //          (other blocks are still reading) and the writer clears a.acc_zero instead.
 // s_lds:   nullable; receives the next pass's odds table [W][Y+1] INSTEAD of a.s: the caller's prologue builds its grouped
@@ -56,6 +69,13 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
     const bool want_diff = writer || a.stop != nullptr;              // block-uniform
 
     // ---- phase A
+    // the old model's top order for v_diff: at most two cells per thread (update_fits_lds), requested with everything
+    // else instead of inside the chains (a global round trip in phase C: 1 us)
+    float vo0 = 0.0f, vo1 = 0.0f;
+    if (want_diff) {
+        if (tid < YK * W) vo0 = v_old[voff(K) + tid];
+        if (tid + nt < YK * W) vo1 = v_old[voff(K) + tid + nt];
+    }
     if (tid == 0) stat3[3] = 0.0;
     const float q_in = *a.q;                                         // issued with the other loads of the update, used last
     const float llh_before = (a.stop != nullptr && a.llh_prev_from_status) ? *a.llh_in : a.llh_prev;
@@ -80,42 +100,25 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
     // ---- phase B: n[k][y][j] = (((0 + c_0) + c_1) + c_2) + c_3 over the four rows c_d = n[k+1][d * 4^(k+1) + y][j] of the
     // next order, themselves sums of four, down to n_K: nested loops over the K - k levels (at most four: the
     // tables fit LDS for K <= 4 only), each level summed from 0.0f upwards as the reference's += does
-    for (uint32_t k = 0; k < K; k++) {
-        const uint32_t Yk = 1u << (2 * (k + 1)), depth = K - k;
-        float* nk = n + voff(k);
-        for (uint32_t i = tid; i < Yk * W; i += nt) {
-            const uint32_t y = i / W, j = i % W;
-            float s0 = 0.0f;
-            for (uint32_t d1 = 0; d1 < 4; d1++) {
-                const uint32_t r1 = y + d1 * Yk;
-                float s1;
-                if (depth == 1u) s1 = nK[(size_t)r1 * W + j];
-                else {
-                    s1 = 0.0f;
-                    for (uint32_t d2 = 0; d2 < 4; d2++) {
-                        const uint32_t r2 = r1 + d2 * Yk * 4u;
-                        float s2;
-                        if (depth == 2u) s2 = nK[(size_t)r2 * W + j];
-                        else {
-                            s2 = 0.0f;
-                            for (uint32_t d3 = 0; d3 < 4; d3++) {
-                                const uint32_t r3 = r2 + d3 * Yk * 16u;
-                                float s3;
-                                if (depth == 3u) s3 = nK[(size_t)r3 * W + j];
-                                else {
-                                    s3 = 0.0f;
-                                    for (uint32_t d4 = 0; d4 < 4; d4++) s3 += nK[(size_t)(r3 + d4 * Yk * 64u) * W + j];
-                                }
-                                s2 += s3;
-                            }
-                        }
-                        s1 += s2;
-                    }
-                }
-                s0 += s1;
+    // (all lower orders as ONE index space, a cell per thread and round: order after order the first threads walked
+    // 16 + 4 dependent reads while the others waited -- 1.6 us of the fused update's 6, tools/phase_clock.py)
+    for (uint32_t i = tid; i < (uint32_t)voff(K); i += nt) {
+        uint32_t k = 0;
+        while (i >= voff(k + 1)) k++;
+        const uint32_t c = i - (uint32_t)voff(k), y = c / W, j = c % W;
+        const uint32_t Yk = 1u << (2 * (k + 1));
+        float r;
+        if constexpr (!CONSUME) {                                    // fused into a sequence kernel: planned for K <= 2 only
+            r = (K - k == 1u) ? update_count_tree<1>(nK, W, j, y, Yk) : update_count_tree<2>(nK, W, j, y, Yk);
+        } else {
+            switch (K - k) {
+                case 1: r = update_count_tree<1>(nK, W, j, y, Yk); break;
+                case 2: r = update_count_tree<2>(nK, W, j, y, Yk); break;
+                case 3: r = update_count_tree<3>(nK, W, j, y, Yk); break;
+                default: r = update_count_tree<4>(nK, W, j, y, Yk); break;
             }
-            nk[i] = s0;
         }
+        n[i] = r;
     }
     BAMM_PHASE(10);
     __syncthreads();
@@ -148,7 +151,8 @@ __device__ __forceinline__ UpdateOut model_update_lds(const UpdateArgs& a, unsig
         for (uint32_t i = tid; i < Yk1 * W; i += nt) {
             const uint32_t y = i / W, j = i % W;
             const float nv = v_cell(k, y, j);
-            if (k == K && want_diff) diff += (double)fabsf(nv - v_old[voff(K) + i]);   // before the store: k_update updates v in place
+            if (k == K && want_diff)                                 // the old value was read in phase A: k_update updates v in place
+                diff += (double)fabsf(nv - (i < nt ? vo0 : (i < 2u * nt ? vo1 : v_old[voff(K) + i])));
             if (writer) { a.v[voff(k) + i] = nv; a.n[voff(k) + i] = n[voff(k) + i]; }
             if (k == K) {
                 const float sv = nv / b[y % Yb];                     // Motif.cpp:485-494
