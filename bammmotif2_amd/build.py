@@ -109,8 +109,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+FLAGS_STAMP = os.path.join(OBJDIR, "flags.txt")
+
+
+def _flags_changed() -> bool:
+    """The library in the tree was built with other compiler flags than this process would use (tools/phase_clock.py
+    appends -DBAMM_PHASE_CLOCK): as stale as a changed source -- nobody benchmarks an instrumented build by accident."""
+    try:
+        return open(FLAGS_STAMP).read() != " ".join(FLAGS)
+    except OSError:
+        return os.path.exists(LIB) and os.path.isdir(OBJDIR) and bool(os.listdir(OBJDIR))   # built before the stamp existed
+
+
 def is_stale() -> bool:
-    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _flags_changed()
 
 
 @contextlib.contextmanager
@@ -140,6 +152,7 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build the gfx950 extension")
     os.makedirs(OBJDIR, exist_ok=True)
+    force = force or _flags_changed()                        # every object again, not only the ones whose source moved
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), _obj(s)
@@ -165,6 +178,8 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
+    with open(FLAGS_STAMP, "w") as fh:
+        fh.write(" ".join(FLAGS))
     return LIB
 
 

@@ -744,11 +744,21 @@ int run_update(bamm_em* em, bool q_window) {
     return launch_update(u, em->ctx->stream);
 }
 
+// A collective that was already enqueued when a peer aborted the communicator completes with whatever it had: what
+// was computed from it is not a model.  Every read-out that follows a stream synchronisation says so.
+int comm_still_sound(const bamm_em* em) {
+    if (em->comm && comm_aborted(em->comm)) {
+        set_error("the communicator was aborted while passes were in flight: the handle's model is not valid");
+        return BAMM_ERR_COMM;
+    }
+    return BAMM_OK;
+}
+
 int fetch_status(bamm_em* em) {
     BAMM_HIP(hipSetDevice(em->ctx->device));
     BAMM_HIP(hipMemcpyAsync(em->h_status, em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
-    return BAMM_OK;
+    return comm_still_sound(em);
 }
 
 // In front of the first pass that all-reduces over a communicator (every rank is in that call, on a thread or a
@@ -1156,9 +1166,13 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     const bool want_grouped = !sliced && prm->K <= 3u && c->use_grouped;
     // A shard of a sharded set plans its kernels as the whole set would: which rows a sequence is multiplied through
     // (mixed or uniform) decides the last bit of its responsibilities, so the choice follows the GLOBAL size the caller
-    // names (n_seqs_bound / n_seqs_global; this shard's own count when it names neither) -- a bucket's share of it is
-    // estimated from this shard's -- and the model does not depend on the number of ranks.
-    const double world_factor = seqs->n ? std::max(1.0, (double)std::max<uint64_t>(prm->n_seqs_bound, prm->n_seqs_global) / (double)seqs->n) : 1.0;
+    // names (n_seqs_bound / n_seqs_global; this shard's own count when it names neither) and nothing about the shard:
+    // every length class of a set of `plan_n` sequences is planned as a launch of that many (a class that holds a small
+    // part of a large set pays the larger tables' few microseconds per launch; an estimate of the class's global share
+    // from this shard's own mix of lengths could differ between ranks next to the threshold).  The other input of the
+    // plan, whether most sequences of a class carry exceptions, is the shard's own: a property of the data that holds
+    // for every shard alike on double-stranded sets (each sequence has its strand junction) and on clean single-stranded ones.
+    const uint64_t plan_n = std::max<uint64_t>(std::max<uint64_t>(prm->n_seqs_bound, prm->n_seqs_global), seqs->n);
     for (auto& b : seqs->buckets) {
         if (b.mclass == kLongClass || global_tables) {       // beyond the length classes / tables beyond LDS: long_seq.hip
             EmBucket eb;
@@ -1181,7 +1195,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
         }
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
-            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, (uint64_t)((double)b.count * world_factor) * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
+            grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, plan_n * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge
@@ -1669,7 +1683,7 @@ static int copy_out(bamm_em* em, float* dst, const float* src, size_t count) {
     BAMM_HIP(hipSetDevice(em->ctx->device));
     BAMM_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
-    return BAMM_OK;
+    return comm_still_sound(em);
 }
 
 int bamm_em_get_v(bamm_em* em, float* v) { return copy_out(em, v, em ? em->d_v : nullptr, em ? em->vsz : 0); }

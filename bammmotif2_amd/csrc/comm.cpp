@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 
@@ -40,6 +41,12 @@ struct LocalGroup {
 };
 
 struct bamm_comm {
+    // `mu` orders every use of `comm` against bamm_comm_abort / bamm_comm_destroy: ncclCommAbort frees the communicator,
+    // so exactly one thread may call it, and nobody may enqueue on the handle afterwards (failing ranks abort ALL the
+    // communicators of their group, from several threads at once).  An enqueue never waits for a peer -- the kernel
+    // does -- so an aborting thread waits for the lock at most as long as one ncclAllReduce call takes to return.
+    std::mutex mu;
+    std::atomic<bool> aborted{false};       // set first by bamm_comm_abort: later calls fail with BAMM_ERR_COMM
     ncclComm_t comm = nullptr;
     bamm_ctx* ctx = nullptr;
     uint32_t rank = 0, world = 1;
@@ -126,14 +133,18 @@ static int local_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipS
 }
 
 int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st) {
+    if (c->aborted.load(std::memory_order_acquire)) { set_error("the communicator was aborted"); return BAMM_ERR_COMM; }
     if (c->local) return local_allreduce_i64(c, dev_ptr, n_words, st);
     const Rccl* r = rccl();
     if (!r) return BAMM_ERR_COMM;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!c->comm) { set_error("the communicator was aborted"); return BAMM_ERR_COMM; }
     const ncclResult_t rc = r->AllReduce(dev_ptr, dev_ptr, n_words, ncclInt64, ncclSum, c->comm, st);
     return rc == ncclSuccess ? BAMM_OK : fail(r, "ncclAllReduce", rc);
 }
 
 bamm_ctx* comm_ctx(const bamm_comm* c) { return c->ctx; }
+bool comm_aborted(const bamm_comm* c) { return c->aborted.load(std::memory_order_acquire); }
 
 }  // namespace bamm
 
@@ -196,17 +207,52 @@ int bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, 
 
 int bamm_comm_abort(bamm_comm* c) {
     if (!c) return BAMM_OK;
+    c->aborted.store(true, std::memory_order_release);       // whatever happens below: this rank's later calls fail
     if (c->local) {
         { std::lock_guard<std::mutex> lock(c->local->mu); c->local->aborted = true; }
         c->local->cv.notify_all();
         return BAMM_OK;
     }
     const Rccl* r = rccl();
-    if (r && c->comm) {
-        (void)hipSetDevice(ctx_device(c->ctx));
-        (void)r->CommAbort(c->comm);                         // also frees the communicator
+    ncclComm_t mine = nullptr;
+    {   // take the handle out under the lock: of any number of threads aborting this communicator one gets it
+        std::lock_guard<std::mutex> lock(c->mu);
+        mine = c->comm;
         c->comm = nullptr;
     }
+    if (r && mine) {
+        (void)hipSetDevice(ctx_device(c->ctx));
+        (void)r->CommAbort(mine);                            // also frees the communicator
+    }
+    return BAMM_OK;
+}
+
+int bamm_comm_time_allreduce(bamm_comm* c, uint64_t n_words, uint32_t iters, float* us_per_call) {
+    if (!c || !us_per_call || n_words == 0 || iters == 0) { set_error("bamm_comm_time_allreduce: bad argument"); return BAMM_ERR_ARG; }
+    *us_per_call = 0.0f;
+    BAMM_HIP(hipSetDevice(ctx_device(c->ctx)));
+    hipStream_t st = ctx_stream(c->ctx);
+    long long* d = nullptr;
+    BAMM_HIP(hipMalloc((void**)&d, n_words * sizeof(long long)));
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = BAMM_OK;
+    hipError_t e = hipMemsetAsync(d, 0, n_words * sizeof(long long), st);
+    if (e == hipSuccess) e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    const uint32_t warm = std::min(iters, 20u);
+    for (uint32_t i = 0; i < warm && e == hipSuccess && !rc; i++) rc = comm_allreduce_i64(c, d, (size_t)n_words, st);
+    if (e == hipSuccess && !rc) e = hipEventRecord(a, st);
+    for (uint32_t i = 0; i < iters && e == hipSuccess && !rc; i++) rc = comm_allreduce_i64(c, d, (size_t)n_words, st);
+    if (e == hipSuccess && !rc) e = hipEventRecord(b, st);
+    if (e == hipSuccess && !rc) e = hipEventSynchronize(b);
+    float ms = 0.0f;
+    if (e == hipSuccess && !rc) e = hipEventElapsedTime(&ms, a, b);
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("bamm_comm_time_allreduce: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+    *us_per_call = ms * 1e3f / (float)iters;
     return BAMM_OK;
 }
 
@@ -268,9 +314,15 @@ int bamm_comm_destroy(bamm_comm* c) {
         return BAMM_OK;
     }
     const Rccl* r = rccl();
-    if (r && c->comm) {
+    ncclComm_t mine = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        mine = c->comm;
+        c->comm = nullptr;
+    }
+    if (r && mine) {
         (void)hipSetDevice(ctx_device(c->ctx));
-        (void)r->CommDestroy(c->comm);
+        (void)r->CommDestroy(mine);
     }
     delete c;
     return BAMM_OK;

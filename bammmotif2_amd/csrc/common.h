@@ -49,6 +49,7 @@ int ctx_device(const bamm_ctx* c);
 hipStream_t ctx_stream(const bamm_ctx* c);
 int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st);   // ncclAllReduce(ncclInt64, ncclSum)
 bamm_ctx* comm_ctx(const bamm_comm* c);
+bool comm_aborted(const bamm_comm* c);      // bamm_comm_abort was called on it (by any thread)
 
 // positions-per-lane classes the sequence kernels are instantiated for (L <= 64*M)
 constexpr int kNumMClasses = 23;

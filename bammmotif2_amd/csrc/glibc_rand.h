@@ -4,11 +4,14 @@
 // (seq_generator/SeqGenerator.cpp:35,222-341) -- so reproducing its bytes means reproducing the stream, and doing
 // that on more than one thread (or on the device) means starting in the middle of it: the generator is linear,
 // jump(n) multiplies the state by t^n mod (t^31 - t^28 - 1) in ~2 log2(n) polynomial products.
-// Users check the restatement against the running libc's srand()/rand() before relying on it (start()).
+// The restatement is relied on only if the running libc's srand()/rand() IS this generator: checked once per process
+// (libc_is_this_generator(): sequential draws and a jump against libc's own stream), never again -- so that threads
+// beside the main one do not touch libc's process-global state on the fast path.
 #pragma once
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace bamm {
 
@@ -63,15 +66,31 @@ struct GlibcRandStream {
         }
         i = 0;
     }
-    // srand(sd) happened just before (or happens here): trust the restatement only if its first draws are libc's
+    // Is libc's rand() this generator?  Decided once per process under a lock: 64 sequential draws from srand(42), then
+    // the stream entered at draw 100 000 by jump() against libc's own 100 000th..100 063rd draws.  Leaves libc freshly
+    // seeded with 42 the one time it runs.
+    static bool libc_is_this_generator() {
+        static std::once_flag once;
+        static bool same = false;
+        std::call_once(once, [] {
+            GlibcRandStream g, j;
+            g.seed(42u);
+            j.seed(42u);
+            j.jump(100000);
+            srand(42u);
+            bool ok = true;
+            for (int k = 0; k < 64; k++) ok &= rand() == g.next_fast();
+            for (int k = 64; k < 100000; k++) (void)rand();
+            for (int k = 0; k < 64; k++) ok &= rand() == j.next_fast();
+            srand(42u);
+            same = ok;
+        });
+        return same;
+    }
+    // the stream as srand(sd) leaves it; `fast` = the restatement may stand in for libc (else next() draws from rand(),
+    // which the caller has seeded)
     void start(uint32_t sd = 42u) {
-        seed(sd);
-        fast = true;
-        int mine[8];
-        for (int k = 0; k < 8; k++) mine[k] = next_fast();
-        srand(sd);
-        for (int k = 0; k < 8; k++) if (rand() != mine[k]) fast = false;
-        srand(sd);
+        fast = libc_is_this_generator();
         seed(sd);
     }
 };

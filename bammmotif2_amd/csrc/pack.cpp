@@ -203,6 +203,23 @@ int bamm_pack_kmer_ptrs(const uint64_t* const* kmer_ptrs, const uint64_t* L, uin
 static int pack_codes_impl(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand, bool seeded,
                            uint32_t seed, bamm_packed** out);
 
+int bamm_rand_stream_draws(uint32_t seed, uint64_t skip, int use_jump, uint32_t count, int32_t* out, int* matches_libc) {
+    if (!out && count) { set_error("bamm_rand_stream_draws: null output"); return BAMM_ERR_ARG; }
+    if (matches_libc) *matches_libc = GlibcRandStream::libc_is_this_generator() ? 1 : 0;
+    if (use_jump < 0) {
+        srand(seed);
+        for (uint64_t k = 0; k < skip; k++) (void)rand();
+        for (uint32_t k = 0; k < count; k++) out[k] = rand();
+        return BAMM_OK;
+    }
+    GlibcRandStream g;
+    g.seed(seed);
+    if (use_jump) g.jump(skip);
+    else for (uint64_t k = 0; k < skip; k++) (void)g.next_fast();
+    for (uint32_t k = 0; k < count; k++) out[k] = g.next_fast();
+    return BAMM_OK;
+}
+
 int bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
                     bamm_packed** out) {
     return pack_codes_impl(codes, off, n_seqs, single_strand, false, 0u, out);
@@ -265,6 +282,10 @@ static int pack_codes_impl(const uint8_t* codes, const uint64_t* off, uint64_t n
         if (seeded) srand(seed);
         for (uint64_t d = 0; d < doff[n_seqs]; d++) draws[d] = (uint8_t)(rand() % 4);
     }
+    // one postcondition for both seeded paths (include/bamm_em.h): libc's stream stands at srand(seed), not advanced --
+    // the reference's later consumers of the stream all reseed (SeqGenerator.cpp:35, FDR.cpp:153); a caller that does
+    // continue the one stream behind the positives uses bamm_pack_codes, which draws from libc's rand() itself
+    if (seeded) srand(seed);
 
     struct Local { std::vector<uint32_t> epos, ekmer, eclean; uint64_t n0 = 0, n1 = 0; };
     std::vector<Local> loc(T);

@@ -221,6 +221,12 @@ class Comm:
         check(self.lib.bamm_comm_info(self.h, C.byref(r), C.byref(w), C.byref(v)))
         return dict(rank=r.value, world=w.value, rccl_version=v.value)
 
+    def time_allreduce(self, n_words: int, iters: int = 200) -> float:
+        """Microseconds per bare all-reduce of n_words int64 words (collective: every rank calls it)."""
+        us = C.c_float()
+        check(self.lib.bamm_comm_time_allreduce(self.h, n_words, iters, C.byref(us)))
+        return float(us.value)
+
     def close(self):
         if self.h:
             self.lib.bamm_comm_destroy(self.h)

@@ -235,9 +235,11 @@ int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, ui
         err = "Error: the sequence-specific negative sampler is written for -s 2 (SeqGenerator.cpp:112-186); use --genericNeg";
         return 1;
     }
-    srand(42);                                         // SeqGenerator.cpp:35
     NegSampler g(s_order);
-    g.stream.start();
+    g.stream.start();                                  // SeqGenerator.cpp:35: the stream as srand(42) leaves it
+    // libc itself is touched only where its rand() is not the restated generator (then the draws below come from it, one
+    // thread): this function runs on a thread beside the main one in the CLI, and libc's stream is process-global
+    if (!g.stream.fast) srand(42);
     g.kmer_frequency(y_s, off, n_seqs);
     // Every negative consumes exactly L draws of the one rand() stream, in order, so where each positive
     // sequence's draws start is known up front.  With the restated generator (stream.fast) the stream

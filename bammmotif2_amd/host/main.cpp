@@ -30,11 +30,17 @@ using namespace bammhost;
 
 namespace {
 
+// Threads beside main(): exit() runs the static destructors of the HIP runtime, the OpenMP runtime and this program under
+// whatever is still running, so die() -- called on the main thread only; the side threads report through strings -- joins
+// every one of them first.  All three do bounded work (no collective: the sharded ranks are joined where they start).
 std::thread g_hip_warmup;                  // brings the HIP runtime up while the FASTA file is read (main)
+std::thread g_neg_thread;                  // samples, packs and uploads the negatives beside the main run
+std::thread g_fold_thread;                 // overlap mode: a motif's folds train while its main run does
 
 [[noreturn]] void die(const std::string& msg) {
-    if (g_hip_warmup.joinable()) g_hip_warmup.join();          // never exit() under a thread that is inside the HIP runtime
     std::cerr << msg << std::endl;
+    for (std::thread* t : {&g_hip_warmup, &g_neg_thread, &g_fold_thread})
+        if (t->joinable() && t->get_id() != std::this_thread::get_id()) t->join();
     exit(1);
 }
 
@@ -384,7 +390,8 @@ int main(int nargs, char* args[]) {
     std::vector<uint32_t> neg_cv_len;       // lengths of the folds' subset (every cvFold-th negative)
     std::vector<uint64_t> neg_off{0};
     std::vector<uint32_t> neg_len;          // all negatives: only sampled for --scoreSeqset
-    std::thread neg_thread;                 // samples, packs and uploads the negatives beside the main run
+    std::thread& neg_thread = g_neg_thread; // samples, packs and uploads the negatives beside the main run (joined by die() too)
+    struct NegJoin { std::thread& t; ~NegJoin() { if (t.joinable()) t.join(); } } neg_join{neg_thread};
     std::string neg_err;
     double neg_t_sample = 0, neg_t_pack = 0;
     std::vector<uint32_t> kept_len;
@@ -639,7 +646,7 @@ int main(int nargs, char* args[]) {
         Motif motif = seeds.motifs[n];                       // deep copy (mainBaMM.cpp:121)
         const std::string mbase = o.basename + "_motif_" + std::to_string(n + 1);
         if (o.saveInitial && motif_write(o.out_dir, o.basename + "_init_motif_" + std::to_string(n + 1), motif, err)) die(err);
-        std::thread fold_thread;                             // overlap mode: this motif's folds train while its main run does
+        std::thread& fold_thread = g_fold_thread;            // overlap mode: this motif's folds train while its main run does (joined by die() too)
         if (overlap) ensure_negatives();                     // the folds score negatives
         if (overlap) fold_thread = std::thread([&, n] { run_folds(n, fold_results[n]); });
         struct FoldJoin { std::thread& t; ~FoldJoin() { if (t.joinable()) t.join(); } } fold_join{fold_thread};

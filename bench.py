@@ -72,6 +72,10 @@ def parse():
                     help="in-process form only: --gpus N ranks as N contexts on device 0 with the host-staged sum of "
                          "bamm_comm_init_local instead of RCCL (self-test of the N>1 logic on a 1-GPU box; never "
                          "used for reported numbers)")
+    ap.add_argument("--timing-every", type=int, default=1,
+                    help="HIP events around every n-th pass of the timed call (1 = every pass: `avg_kernel_ms` then covers the "
+                         "whole timed region and cannot exceed `ms_per_step`; a pair takes a few us of stream time)")
+    ap.add_argument("--allreduce-iters", type=int, default=200, help="N > 1: bare all-reduces of the accumulator timed for `attribution`")
     ap.add_argument("--no-fused-update", action="store_true",
                     help="a k_update launch after every pass instead of the update fused into the next pass's kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -294,6 +298,22 @@ def report(args, wl, world, dt, kernel_ms, launches, local_positions, local_wind
     return out
 
 
+def attribution(step_us, kernel_us, allreduce_us, args):
+    """Where a sharded iteration's time goes, so that a scaling shortfall can be read off the first multi-GPU run: the
+    sequence kernel (HIP events around it, every pass of the timed call), the bare collective (a loop of all-reduces of
+    the accumulator alone, timed after the run), and the rest -- launch gaps, the fused update's prologue, waiting for the
+    slowest rank.  Per rank and the max over ranks; `fixed_us` = step - kernel - allreduce from the maxima."""
+    k = max(kernel_us)
+    ar = [a for a in allreduce_us if a is not None]
+    a = max(ar) if ar else None
+    return {"step_us": step_us, "kernel_us": k, "allreduce_us": a,
+            "fixed_us": step_us - k - (a or 0.0),
+            "kernel_us_per_rank": list(kernel_us), "allreduce_us_per_rank": list(allreduce_us),
+            "allreduce_is": f"{args.allreduce_iters} back-to-back all-reduces of the accumulator on the kernels' stream, HIP events "
+                            "around the loop (bamm_comm_time_allreduce); inside an iteration the collective also waits for the slowest rank's kernel",
+            "kernel_is": "HIP events around the sequence kernel(s) of every pass of the timed call (the fused model update is its prologue)"}
+
+
 def from_seed_extras(bm, ctx, seqs, wl, args, sync):
     """Beside the steady-state figure: what a run from the seed pays (the first passes are slower: few
     responsibilities are exactly zero yet), as iterate() and as optimize() (EM.cpp:81-128: the stopping rule looks
@@ -352,7 +372,7 @@ def main_inprocess(args, result_fd):
         ss = bm.SeqSet(ctx, packed, b, e)
         em = bm.EM(ctx, ss, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=args.steps + args.warmup + 8,
                    n_seqs_bound=args.nseq)
-        em.set_kernel_timing(max(2, min(8, args.steps // 16)))
+        em.set_kernel_timing(args.timing_every)
         ctxs.append(ctx); seqs.append(ss); ems.append(em)
     comms = []
     allreduce_kind = "none"
@@ -373,7 +393,7 @@ def main_inprocess(args, result_fd):
         ranks.append({**info, "device": devices[r], "device_name": ctxs[r].device_name(), "n_seqs": seqs[r].n_seqs})
 
     gate = threading.Barrier(N)
-    dts, errors = [0.0] * N, [None] * N
+    dts, errors, ar_us = [0.0] * N, [None] * N, [None] * N
 
     def worker(r):
         try:
@@ -385,6 +405,9 @@ def main_inprocess(args, result_fd):
             ctxs[r].sync()
             dts[r] = time.perf_counter() - t0
             gate.wait()
+            if comms and not args.local_ranks:               # outside the timed region: what the bare collective costs
+                ar_us[r] = comms[r].time_allreduce(4 ** (K + 1) * W + 3, args.allreduce_iters)
+                gate.wait()
         except BaseException as e:                           # a rank that fails alone would leave the others in the collective
             errors[r] = e
             gate.abort()
@@ -410,6 +433,8 @@ def main_inprocess(args, result_fd):
     llh, _, _ = ems[0].trace()
     name, mixed = kernel_label(ems[0], K)
     extras = {"ranks_agree_bitwise": agree, "ms_per_step_per_rank": [d / args.steps * 1e3 for d in dts]}
+    if comms:
+        extras["attribution"] = attribution(dt / args.steps * 1e6, [k[0] / max(k[1], 1) * 1e3 for k in kernel], ar_us, args)
     if N == 1 and not comms and not args.no_extras:
         extras.update(from_seed_extras(bm, ctxs[0], seqs[0], wl, args, ctxs[0].sync))
     lp = int(seqs[0].off[-1])
@@ -541,9 +566,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around every `every`-th pass: at least 16 samples of the sequence kernel over the timed
-    # region, at most one pair per two passes (a pair takes ~6 us of stream time)
-    em.set_kernel_timing(max(2, min(8, args.steps // 16)))
+    # HIP events around the sequence kernel(s) of every pass of the timed call (--timing-every 1): the kernel time covers
+    # the whole timed region, so its average cannot exceed ms_per_step
+    em.set_kernel_timing(args.timing_every)
     with torch.cuda.stream(tstream):       # the context's stream is torch's current one for the callback
         em.iterate(args.warmup)
         barrier()
@@ -558,6 +583,9 @@ def main():
 
     kernel_ms, launches = em.kernel_time()
     extras = {}
+    my_ar_us = None
+    if use_dist and keep and isinstance(keep[0], bm.Comm):
+        my_ar_us = keep[0].time_allreduce(4 ** (K + 1) * W + 3, args.allreduce_iters)      # collective, outside the timed region
     if world == 1 and not use_dist and not args.no_extras:
         with torch.cuda.stream(tstream):
             extras = from_seed_extras(bm, ctx, seqs, wl, args, torch.cuda.synchronize)
@@ -566,7 +594,8 @@ def main():
     llh, vdiff, _ = em.trace()
     kernel_name, mixed = kernel_label(em, K)
     # what proves the N ranks: every rank's communicator view, gathered on rank 0
-    me = {**rank_info, "device": local_rank, "device_name": ctx.device_name(), "n_seqs": seqs.n_seqs}
+    me = {**rank_info, "device": local_rank, "device_name": ctx.device_name(), "n_seqs": seqs.n_seqs,
+          "kernel_us": kernel_ms / max(launches, 1) * 1e3, "allreduce_us": my_ar_us}
     ranks = [me]
     if use_dist and world > 1:
         gathered = [None] * world
@@ -574,6 +603,10 @@ def main():
         ranks = gathered
         if sorted(g["rank"] for g in ranks) != list(range(world)) or any(g["world"] != world for g in ranks):
             raise SystemExit(f"bench.py: the ranks do not form a world of {world}: {ranks}")
+    if use_dist:
+        extras["attribution"] = attribution(dt / args.steps * 1e6, [g["kernel_us"] for g in ranks], [g["allreduce_us"] for g in ranks], args)
+        slow = max(ranks, key=lambda g: g["kernel_us"])                # the roofline line prices the slowest rank's kernel
+        kernel_ms, launches = slow["kernel_us"] * 1e-3 * max(launches, 1), max(launches, 1)
     if rank == 0:
         out = report(args, wl, world, dt, kernel_ms, launches, local_positions, local_windows, kernel_name, mixed,
                      float(llh[-1]) if len(llh) else None, allreduce_kind, extras, ranks,

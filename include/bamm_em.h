@@ -93,8 +93,10 @@ int  bamm_pack_codes(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs,
 /* the same when the libc stream starts at srand(seed) (the reference seeds once, mainBaMM.cpp:22, and its positives
  * are read first): glibc's generator is restated and checked against the running libc, so the draws are taken on all
  * host threads (each jumps to its share of the one stream) instead of one after the other; falls back to
- * srand(seed) + rand() where the check fails.  Same result as srand(seed); bamm_pack_codes(...).  libc's stream is
- * left freshly seeded, not advanced.                                                                          */
+ * srand(seed) + rand() where the check fails.  Same packing as srand(seed); bamm_pack_codes(...).  Postcondition on
+ * either path: libc's stream stands at srand(seed), NOT advanced past the draws (the reference's later consumers all
+ * reseed: SeqGenerator.cpp:35, FDR.cpp:153); a caller that continues the one stream behind the positives uses
+ * bamm_pack_codes, which draws from libc's rand() itself.                                                       */
 int  bamm_pack_codes_seeded(const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
                             uint32_t seed, bamm_packed** out);
 /* host threads the packing helpers may use (0 = a default of at most 8); the result never depends
@@ -175,9 +177,10 @@ typedef struct bamm_em_params {
                               * up to 4M sequences, coarser beyond: the int64 sums never
                               * overflow).  0 = n_seqs_global, else this handle's own count.
                               * Ranks that all-reduce together must agree on it.  A shard also
-                              * plans its kernels from it (as the whole set would: the rows a
-                              * window is multiplied through decide the last bit of r), so that
-                              * the model does not depend on the number of ranks.               */
+                              * plans its kernels from it and from nothing else about its size
+                              * (as the whole set would: the rows a window is multiplied through
+                              * decide the last bit of r), so that the model does not depend on
+                              * the number of ranks or on how lengths are spread over them.     */
 } bamm_em_params;
 
 void bamm_em_default_params(bamm_em_params* p);
@@ -253,10 +256,22 @@ int  bamm_comm_init_rank(bamm_ctx* ctx, const void* id, uint32_t rank, uint32_t 
 int  bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, bamm_comm** out /* [n] */);
 int  bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rccl_version);
 /* a rank that fails calls this on its communicator (any thread): the collectives its peers are blocked in return
- * BAMM_ERR_COMM instead of waiting for it for ever (ncclCommAbort; the local kind wakes its waiters).  The handle
- * stays valid for bamm_comm_destroy only.                                                                        */
+ * BAMM_ERR_COMM instead of waiting for it for ever (ncclCommAbort; the local kind wakes its waiters).  Safe to call
+ * from several threads at once on the same handle (one of them aborts, the others return).  The handle stays valid
+ * for bamm_comm_destroy only; every later collective on it, and every result read from an EM handle that was using it,
+ * fails with BAMM_ERR_COMM.                                                                                       */
 int  bamm_comm_abort(bamm_comm* c);
 int  bamm_comm_destroy(bamm_comm* c);
+/* a bare loop of `iters` all-reduces of `n_words` int64 words on the context's stream (20 untimed ones first), timed with
+ * HIP events: microseconds per call.  Collective: every rank of the communicator calls it with the same arguments.  What
+ * a sharded iteration pays for its one collective (bench.py reports it beside the kernel time for N > 1).           */
+int  bamm_comm_time_allreduce(bamm_comm* c, uint64_t n_words, uint32_t iters, float* us_per_call);
+/* `count` consecutive draws of glibc's rand() stream as srand(seed) leaves it, starting behind its first `skip` draws:
+ * from the restated generator (csrc/glibc_rand.h) entered by jump-ahead (use_jump != 0) or stepped `skip` times, or --
+ * use_jump < 0 -- from libc's own srand(seed) / rand() (which this then advances).  *matches_libc (may be NULL): whether the
+ * process-wide check found libc's rand() to be this generator.  How the N draws of Sequence.cpp:38 and the negative
+ * sampler (SeqGenerator.cpp:188-348) enter the one stream in the middle, on host threads and on the device.     */
+int  bamm_rand_stream_draws(uint32_t seed, uint64_t skip, int use_jump, uint32_t count, int32_t* out, int* matches_libc);
 /* HIP devices visible to the process (0 and BAMM_ERR_NO_DEVICE when there is none)                               */
 int  bamm_device_count(int* n);
 

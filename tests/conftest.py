@@ -36,3 +36,15 @@ def gpu_ctx(lib):
     ctx.set_tuning(scratch_poison=1)
     yield ctx
     ctx.close()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The observed parity margins of a GPU session (tests/margins.py) as a table under gpurun_out/."""
+    from tests import margins
+    if not margins.ROWS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_margins.txt"), "w") as fh:
+        fh.write("max |a - b| / (|b| + atol / rtol) per comparison of the -m gpu suite: `observed <= allowed` is the assertion\n")
+        fh.write(margins.table())

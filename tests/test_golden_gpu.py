@@ -4,17 +4,44 @@ import pytest
 
 import bammmotif2_amd as bm
 from tests import golden_util as gu
+from tests import margins
 
 pytestmark = pytest.mark.gpu
 NAMES = gu.fixture_names()
+# The K = 2, W = 20, both-strands fixtures additionally run with the table layout forced: 8 = the mixed 5-mer / 6-mer
+# rows of k_em_mix -- the kernel bench.py times; the planner takes it by itself only from 40 000 sequences up --
+# and 3 = k_em_grp's uniform rows, so that both meet the reference's own vectors and not only the oracle.
+BENCH_SHAPE = ("small_k2_config2_shape", "large_g4_1k", "large_g4_10k")
+PARAMS = [(n, -1) for n in NAMES] + [(n, lay) for n in BENCH_SHAPE if n in NAMES for lay in (8, 3)]
+FLAT = 1e-5            # BASELINE.json: learned conditional probabilities within 1e-5 relative
+QUIET_REFERENCE = 3e-6  # fixtures on which the reference's own fp32 accumulation stays below this are held to FLAT
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_hip_path_matches_reference_golden(name, gpu_ctx, orc):
+def flavour_of(em, layout):
+    grouped, other, _ = em.plan()
+    mixed = em.plan_mixed()
+    kern = "k_em_mix" if mixed and mixed == grouped else "k_em_grp" if grouped and not mixed else \
+        "k_em_mix+k_em_grp" if grouped else "k_em_seq/sliced"
+    if grouped and other:
+        kern += "+k_em_seq"
+    return f"{kern} ({'planner' if layout < 0 else 'layout %d' % layout})"
+
+
+@pytest.mark.parametrize("name,layout", PARAMS, ids=[f"{n}-{'planner' if l < 0 else 'layout%d' % l}" for n, l in PARAMS])
+def test_hip_path_matches_reference_golden(name, layout, gpu_ctx, orc):
     c, g = gu.load(name)
     pk = bm.PackedSeqs.from_codes(c.codes, c.in_off, c.ss, seed=42)
     ss = bm.SeqSet(gpu_ctx, pk)
-    em = bm.EM(gpu_ctx, ss, c.K, c.W, g["vbg"], c.A, c.v0, c.q, bg_order=c.bg_order)
+    gpu_ctx.set_tuning(group_layout=layout)
+    try:
+        em = bm.EM(gpu_ctx, ss, c.K, c.W, g["vbg"], c.A, c.v0, c.q, bg_order=c.bg_order)
+    finally:
+        gpu_ctx.set_tuning(group_layout=-1)
+    fl = flavour_of(em, layout)
+    if layout == 8:
+        assert em.plan()[0] > 0 and em.plan_mixed() == em.plan()[0], "the forced layout did not select k_em_mix"
+    elif layout == 3:
+        assert em.plan()[0] > 0 and em.plan_mixed() == 0
     n_iter = max(int(k.split("_")[1]) for k in g if k.startswith("v_") and k[2:].isdigit()) + 1
     nr = int(g["r_seqs"])
     # How far is the reference itself from exact arithmetic on this input?  Its fp32 CAS/serial
@@ -23,37 +50,38 @@ def test_hip_path_matches_reference_golden(name, gpu_ctx, orc):
     v64, _, _, _ = orc.em_step_f64(kmer, off, c.K, c.W, c.bg_order, g["vbg"], c.A, c.v0, c.q)
     ref_noise = None
     if "v_0" in g:
-        ref_noise = float(np.max(np.abs(g["v_0"] - v64) / np.abs(v64)))
+        ref_noise = margins.rel(g["v_0"], v64, 1.0)
+        margins.ROWS.append((name, "reference itself", "v pass 1", "fp64 restatement", ref_noise, float("nan"), 0.0))
+    quiet = ref_noise is not None and ref_noise < QUIET_REFERENCE
     for it in range(n_iter):
         em.EStep()
         if it == 0:
             if "s_0" in g:
                 assert np.array_equal(em.getS(), g["s_0"])             # same inputs -> bit-exact odds
-            np.testing.assert_allclose(em.getR(0, nr), g["r_0"], rtol=1e-5, atol=1e-12)
-        np.testing.assert_allclose(em.getLLH(), g[f"llh_{it}"], rtol=1e-5, atol=5e-7 * c.N)
+            margins.check(name, fl, "r pass 1", em.getR(0, nr), g["r_0"], 1e-5, 1e-12)
+        margins.check(name, fl, f"llh pass {it + 1}", em.getLLH(), g[f"llh_{it}"], 1e-5, 5e-7 * c.N)
         em.MStep()
         if it == 0:
-            gpu_noise = float(np.max(np.abs(em.getV() - v64) / np.abs(v64)))
-            assert gpu_noise <= 2e-6, gpu_noise                         # the HIP path sits on the fp64 answer
+            gpu_noise = margins.check(name, fl, "v pass 1", em.getV(), v64, 2e-6, against="fp64 restatement")   # the HIP path sits on the fp64 answer
             if ref_noise is not None:
                 assert gpu_noise <= ref_noise + 1e-7
         if f"v_{it}" in g:
-            # BASELINE.json: learned conditional probabilities within 1e-5 relative; beyond that
-            # only as far as the reference's own accumulation noise on this input explains
-            tol = 1e-5 + 2.0 * (ref_noise or 0.0) * (it + 1)
-            np.testing.assert_allclose(em.getV(), g[f"v_{it}"], rtol=tol, atol=1e-9)
+            # the flat bar wherever the reference's own accumulation noise on this input is small; beyond that only
+            # as far as that noise, measured above on this very input, explains
+            tol = FLAT if quiet else FLAT + 2.0 * (ref_noise or 0.0) * (it + 1)
+            margins.check(name, fl, f"v pass {it + 1}", em.getV(), g[f"v_{it}"], tol, 1e-9)
         if f"n_{it}" in g:
-            np.testing.assert_allclose(em.getCounts(), g[f"n_{it}"], rtol=2e-5 + 4.0 * (ref_noise or 0.0), atol=1e-5)
+            margins.check(name, fl, f"n pass {it + 1}", em.getCounts(), g[f"n_{it}"], 2e-5 + 4.0 * (ref_noise or 0.0), 1e-5)
     if "p_final" in g:
-        np.testing.assert_allclose(bm.calculate_p(em.getV(), g["vbg"], c.bg_order, c.K, c.W), g["p_final"],
-                                   rtol=5e-5 + 10.0 * (ref_noise or 0.0), atol=1e-12)
+        margins.check(name, fl, "p final", bm.calculate_p(em.getV(), g["vbg"], c.bg_order, c.K, c.W), g["p_final"],
+                      5e-5 + 10.0 * (ref_noise or 0.0), 1e-12)
     last_v = g[f"v_{n_iter - 1}"]
     _, zoops, z = bm.logodds(gpu_ctx, ss, c.K, c.W, c.bg_order, last_v, g["vbg"], want_mops=False)
     np.testing.assert_allclose(zoops, g["zoops"], rtol=0, atol=5e-5)
     assert np.mean(z == g["z"]) > 0.999        # an exact tie can move with libm's last bit
     em.close()
     for oq in (0, 1):
-        if f"opt{oq}_v" not in g:
+        if f"opt{oq}_v" not in g or layout >= 0:
             continue
         em = bm.EM(gpu_ctx, ss, c.K, c.W, g["vbg"], c.A, c.v0, c.q, bg_order=c.bg_order, optimizeQ=bool(oq))
         it = em.optimize()

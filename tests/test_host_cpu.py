@@ -206,3 +206,35 @@ def test_seeded_packing_equals_the_libc_stream():
             assert np.array_equal(pa.words, pb.words)
             assert np.array_equal(pa.unpack_y(10), pb.unpack_y(10))
             pa.free(); pb.free()
+
+
+def test_rand_stream_jump_ahead_equals_stepping_and_libc(lib):
+    """csrc/glibc_rand.h: the negative sampler and the N draws enter glibc's one rand() stream in the middle
+    (GlibcRandStream::jump multiplies the state by t^n mod (t^31 - t^28 - 1)).  jump(n) against n single steps and against
+    libc's own srand()/rand() for several n and seeds; beyond 2^32, where stepping is out of reach, jumps must compose:
+    jump(a) then b steps == jump(a + b)."""
+    import ctypes as C
+
+    def draws(seed, skip, mode, count=16):
+        out = (C.c_int32 * count)()
+        m = C.c_int()
+        assert lib.bamm_rand_stream_draws(seed, skip, mode, count, out, C.byref(m)) == 0
+        return list(out), bool(m.value)
+
+    first, same = draws(42, 0, 1)
+    assert same, "libc's rand() is not the restated generator on this host (the host paths then draw from libc, serially)"
+    assert first == draws(42, 0, -1)[0]
+    for seed in (42, 1, 20260101):
+        for n in (1, 2, 30, 31, 33, 34, 35, 343, 344, 1000, 65537, 1_000_003):
+            j, _ = draws(seed, n, 1)
+            assert j == draws(seed, n, 0)[0], (seed, n)
+            assert j == draws(seed, n, -1)[0], (seed, n)
+    # beyond 2^32: the stream entered at a + b directly and at a, then b steps further (b small enough to step through)
+    for a, b in ((2 ** 32 + 12345, 100_000), (2 ** 40 + 7, 31), (3 * 2 ** 33, 1)):
+        direct, _ = draws(42, a + b, 1, 24)
+        chained, _ = draws(42, a, 1, 24 + b if b <= 64 else 24)
+        if b <= 64:
+            assert direct == chained[b:b + 24], (a, b)
+        # jump(a + b) against jump(b) applied to the state jump(a) left: the library's own composition
+        lo, _ = draws(42, a + b - 8, 1, 32)
+        assert lo[8:] == direct, (a, b)

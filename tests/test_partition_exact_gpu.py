@@ -70,3 +70,34 @@ def test_accumulator_is_the_same_integers_for_any_partition(shape, gpu_ctx):
             total += accumulator(gpu_ctx, hip, pk, b, e, shape, vbg, A, v0)
         assert np.array_equal(total[cells:], whole[cells:]), (cuts, total[cells:], whole[cells:])
         assert np.array_equal(total, whole), cuts
+
+
+def test_shards_with_unlike_length_mixes_plan_like_the_whole_set(gpu_ctx):
+    """Next to the planner's threshold (mixed rows from 40 000 sequences of 200 bp or the equivalent up): two length
+    classes, the set sorted by length, so that one shard holds all of the long class and the other all of the short one.
+    An estimate of a class's global size from the shard's own mix would put the long class above the threshold on its
+    shard and below it on the whole set; the plan follows the global size alone, so the flavours -- and the integers --
+    are those of the whole set."""
+    hip = C.CDLL("libamdhip64.so")
+    W, K = 20, 2
+    pwm = synth.make_pwm(W, 5)
+    c_long, o_long = synth.make_sequences(30000, 200, pwm, 5, 0.5)        # 7 positions per lane
+    c_short, o_short = synth.make_sequences(30000, 130, pwm, 6, 0.5)      # 5 positions per lane
+    codes = np.concatenate([c_long, c_short])
+    off = np.concatenate([o_long, o_short[1:] + o_long[-1]])
+    N = 60000
+    pk = bm.PackedSeqs.from_codes(codes, off, False, seed=42)
+    vbg = pk.bg_model(2, np.array([1.0, 10.0, 10.0], np.float32))
+    A = synth.alpha_matrix(synth.default_alpha(K), W)
+    v0 = synth.bamm_from_pwm((0.7 * pwm + 0.075).astype(np.float32), K)
+    shape = dict(N=N, W=W, K=K, tune=dict())
+    plans = []
+    for b, e in ((0, N), (0, 30000), (30000, N)):
+        ss = bm.SeqSet(gpu_ctx, pk, b, e)
+        em = bm.EM(gpu_ctx, ss, K, W, vbg, A, v0, 0.3, n_seqs_bound=N)
+        plans.append((em.plan()[0], em.plan_mixed()))
+        em.close(); ss.close()
+    assert plans[0] == (N, N) and plans[1] == (30000, 30000) and plans[2] == (30000, 30000), plans
+    whole = accumulator(gpu_ctx, hip, pk, 0, N, shape, vbg, A, v0)
+    total = accumulator(gpu_ctx, hip, pk, 0, 30000, shape, vbg, A, v0) + accumulator(gpu_ctx, hip, pk, 30000, N, shape, vbg, A, v0)
+    assert np.array_equal(total, whole)

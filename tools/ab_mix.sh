@@ -21,7 +21,10 @@ run() {
 timeout -k 10 600 python3 -m pytest tests/test_grouped_gpu.py tests/test_fuzz_gpu.py tests/test_fused_update_gpu.py tests/test_golden_gpu.py -x -q -m gpu 2>&1 | tail -3
 run new
 mkdir -p /tmp/new
+# whatever ends the script (a timeout, Ctrl-C, a failed build): the tree's own files and library come back
+restore() { for f in /tmp/new/*; do [ -f "$f" ] && cp "$f" bammmotif2_amd/csrc/$(basename "$f"); done
+            python3 -c "from bammmotif2_amd import build as b; b.build_library()" > /dev/null 2>&1; }
+trap restore EXIT
 for f in tools/.old/*; do b=$(basename $f); cp bammmotif2_amd/csrc/$b /tmp/new/$b; cp $f bammmotif2_amd/csrc/$b; done
 python3 -c "from bammmotif2_amd import build as b; b.build_library()" > /dev/null 2>&1
 run old
-for f in tools/.old/*; do b=$(basename $f); cp /tmp/new/$b bammmotif2_amd/csrc/$b; done

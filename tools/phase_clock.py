@@ -8,7 +8,19 @@ import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bammmotif2_amd import build
+import atexit
 build.FLAGS.append("-DBAMM_PHASE_CLOCK")
+
+
+def _restore():
+    """Leave the tree as it was found: the instrumented library stores to global memory at every phase boundary, and
+    whatever runs next on this box must not time it (build.py also keeps the flags a library was built with and treats
+    another set as stale)."""
+    build.FLAGS.remove("-DBAMM_PHASE_CLOCK")
+    build.build_library()
+
+
+atexit.register(_restore)
 t0 = time.time(); build.build_library(force=True); print(f"instrumented build: {time.time() - t0:.0f} s", flush=True)
 import bammmotif2_amd as bm
 from bammmotif2_amd import synth
