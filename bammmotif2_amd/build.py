@@ -122,7 +122,11 @@ def _flags_changed() -> bool:
 
 
 def is_stale() -> bool:
-    return _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _flags_changed()
+    """The library is older than a source or header, was built with other flags, or -- where the objects are at hand -- some
+    object is older than its source (a source edited WHILE a build ran: the link that followed is newer than the edit)."""
+    if _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _flags_changed():
+        return True
+    return any(os.path.exists(_obj(s)) and _stale(_obj(s), [os.path.join(CSRC, s)] + HEADERS) for s in SOURCES)
 
 
 @contextlib.contextmanager

@@ -13,6 +13,12 @@
 
 #include "common.h"
 
+// the longest length class (positions per lane) whose grouped kernels are built with the fused-update prologue and the
+// all-reduce tail (grouped_kernel.h carries the same default)
+#ifndef BAMM_FUSE_MAX_M
+#define BAMM_FUSE_MAX_M 16
+#endif
+
 using namespace bamm;
 
 static bool flush_idle_scratch(int device);
@@ -94,6 +100,8 @@ struct bamm_ctx {
     uint32_t list_threshold_pct = 45;   // sliced path: a pass takes lists when fewer than this share of the windows was non-zero in the pass before
     uint32_t group_size = 0;            // 0 = planner's choice
     int group_layout = -1;              // -1 = planner's choice
+    bool use_peer_allreduce = false;    // the pass's all-reduce inside the sequence kernels over peer-mapped inboxes (default off)
+    uint32_t peer_timeout_ms = 2000;    // how long a block waits for a peer's sums before it gives up (BAMM_ERR_COMM)
     int num_cus = 0;
     std::string name;
     // Scratch that is as large as the sequence set (dense r, the lists between the E pass and the M slices, the fix
@@ -308,6 +316,11 @@ struct bamm_em {
     void* allreduce_user = nullptr;
     bamm_comm* comm = nullptr;                  // native RCCL all-reduce (bamm_em_set_comm)
     bool comm_verified = false;                 // verify_comm() ran with the peers
+    // in-kernel all-reduce (PeerArgs): the last block of every accumulating pass exchanges the GPU's totals with the peers
+    // and leaves the sum in the accumulator, in place -- no collective launch behind the pass
+    bool peer_on = false;                       // agreed with every rank in verify_comm()
+    uint32_t* d_peer_words = nullptr;           // [0] ticket, [1] err
+    std::string peer_note;                      // why peer_on is false although asked for
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     uint32_t events_used = 0;
     uint32_t timing_every = 8, pass_no = 0;     // bamm_em_set_kernel_timing
@@ -521,6 +534,14 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
     if (fuse) {                                              // the previous pass's update runs in this launch's prologue
         ga.fused = 1u; ga.upd = *fuse; ga.upd_off = em->fuse_upd_off; ga.s_block = em->d_s_block;
     }
+    if (em->peer_on && accum && !write_r) {                  // in-kernel all-reduce in the launch's tail (the pass's only launch)
+        comm_peer_args(em->comm, &ga.peer);
+        ga.peer.words = (uint32_t)em->cells + 3u;
+        ga.peer.ticket = em->d_peer_words; ga.peer.err = em->d_peer_words + 1;
+        ga.peer.timeout_ticks = (unsigned long long)em->ctx->peer_timeout_ms * 100000ull;      // 100 MHz wall clock
+        ga.peer.seq = comm_peer_next_seq(em->comm);          // the ranks count their passes in step
+        ga.peer.slot = (uint32_t)(ga.peer.seq % 3ull);
+    }
     return launch_em_grp(eb.mclass, accum, write_r, ga, eb.blocks, threads, st);
 }
 
@@ -671,6 +692,7 @@ int allreduce_words(bamm_em* em, void* dev_ptr, size_t n_words) {
 }
 
 int run_allreduce(bamm_em* em) {
+    if (em->peer_on) return BAMM_OK;                         // the pass's own launch summed over the ranks (launch_fused, peer_allreduce_tail)
     if (em->comm) return comm_allreduce_i64(em->comm, em->d_acc, em->cells + 3, em->ctx->stream);
     if (!em->allreduce) return BAMM_OK;
     int rc = em->allreduce(em->allreduce_user, em->d_acc, em->cells + 3, (void*)em->ctx->stream);
@@ -751,6 +773,14 @@ int comm_still_sound(const bamm_em* em) {
         set_error("the communicator was aborted while passes were in flight: the handle's model is not valid");
         return BAMM_ERR_COMM;
     }
+    if (em->peer_on && em->d_peer_words) {                   // the stream is idle: did a block give up waiting for a peer?
+        uint32_t w[2] = {0, 0};
+        BAMM_HIP(hipMemcpy(w, em->d_peer_words, sizeof w, hipMemcpyDeviceToHost));
+        if (w[1] != 0u) {
+            set_error("in-kernel all-reduce: the sums of rank %u did not arrive within the deadline (peer_timeout_ms); the handle's model is not valid", w[1] - 1u);
+            return BAMM_ERR_COMM;
+        }
+    }
     return BAMM_OK;
 }
 
@@ -769,20 +799,23 @@ int verify_comm(bamm_em* em) {
     if (!em->comm || em->comm_verified) return BAMM_OK;
     uint32_t world = 1;
     (void)bamm_comm_info(em->comm, nullptr, &world, nullptr);
+    long long want_peer = 0;                                 // ranks whose context asks for the in-kernel all-reduce
     if (world > 1) {
-        long long h[3] = {(long long)em->seqs->n, (long long)em->fix_shift, (long long)em->fix_shift * (long long)em->fix_shift};
+        long long h[4] = {(long long)em->seqs->n, (long long)em->fix_shift, (long long)em->fix_shift * (long long)em->fix_shift,
+                          em->ctx->use_peer_allreduce ? 1 : 0};
         long long* d = nullptr;
         int rc = use_device(em->ctx);
-        if (!rc) rc = dev_alloc(&d, 3);
+        if (!rc) rc = dev_alloc(&d, 4);
         if (rc) return rc;
         hipStream_t st = em->ctx->stream;
         hipError_t e = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) rc = comm_allreduce_i64(em->comm, d, 3, st);
+        if (e == hipSuccess) rc = comm_allreduce_i64(em->comm, d, 4, st);
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
         (void)hipFree(d);
         if (rc) return rc;
         if (e != hipSuccess) { set_error("accumulator-unit check over the communicator: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+        want_peer = h[3];
         if ((long long)world * h[2] != h[1] * h[1]) {
             set_error("the ranks' accumulator units differ (bamm_em_params.n_seqs_bound must be the same on every rank)");
             return BAMM_ERR_ARG;
@@ -794,6 +827,46 @@ int verify_comm(bamm_em* em) {
                       "bamm_em_params.n_seqs_bound on every rank", h[0], world, em->fix_shift);
             return BAMM_ERR_ARG;
         }
+    }
+    // in-kernel all-reduce, when the context asks for it: every rank must be able to (a pass of ONE launch of the mixed-row
+    // kernel, which is built with the tail) and must have mapped every peer's inbox -- the ranks vote, a single refusal keeps
+    // all of them on RCCL
+    em->peer_on = false;
+    if (world > 1 && want_peer == (long long)world) {        // (asked for on every rank: the set-up below is a collective)
+        constexpr uint32_t kStride = 2056;                   // entries per (slot, source): 2048 top-order cells + 3 statistics, padded
+        // (k_em_mix carries the tail: K = 2, both strands, the widths the planner gives mixed rows -- the bench / config 2 / 3 / 5
+        // shapes; in k_em_grp the same code cost the single-GPU pass 0.8 % and was taken out again)
+        const bool can = em->ebuckets.size() == 1u && em->ebuckets[0].grouped && (em->ebuckets[0].layout & 8u) != 0u &&
+                         world <= kPeerMaxWorld && em->cells + 3u <= kStride && !em->allreduce;
+        int ready = 0;
+        // (every rank goes through the set-up, able or not: it is a collective; the vote inside it counts mapped inboxes)
+        int rc = comm_peer_setup(em->comm, kStride, &ready);
+        if (rc) return rc;
+        long long vote[1] = {(ready && can) ? 1 : 0};
+        long long* d = nullptr;
+        if ((rc = use_device(em->ctx)) || (rc = dev_alloc(&d, 1))) return rc;
+        hipStream_t st = em->ctx->stream;
+        hipError_t e = hipMemcpyAsync(d, vote, sizeof vote, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) rc = comm_allreduce_i64(em->comm, d, 1, st);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(vote, d, sizeof vote, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
+        (void)hipFree(d);
+        if (rc) return rc;
+        if (e != hipSuccess) { set_error("in-kernel all-reduce vote: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+        if (vote[0] == (long long)world) {
+            if (!em->d_peer_words) {
+                if ((rc = dev_alloc(&em->d_peer_words, 2))) return rc;
+                BAMM_HIP(hipMemsetAsync(em->d_peer_words, 0, 2 * sizeof(uint32_t), st));
+            }
+            em->peer_on = true;
+            em->peer_note.clear();
+        } else {
+            em->peer_note = !ready ? std::string("inboxes: ") + comm_peer_why(em->comm)
+                          : !can ? "this handle's pass is not one launch of the mixed-row kernel (K = 2, both strands, W = 13, 14, 16, 17 or 20, one length class)"
+                                 : "another rank could not";
+        }
+    } else if (em->ctx->use_peer_allreduce) {
+        em->peer_note = world > 1 ? "not every rank's context asked for it" : "one rank: nothing to reduce";
     }
     em->comm_verified = true;
     return BAMM_OK;
@@ -910,6 +983,11 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
     else if (k == "adaptive_lists") c->use_adaptive_lists = value != 0;
     else if (k == "update_blocks") c->use_update_blocks = value != 0;
     else if (k == "scratch_poison") c->scratch_poison = value != 0;
+    else if (k == "peer_allreduce") c->use_peer_allreduce = value != 0;
+    else if (k == "peer_timeout_ms") {
+        if (value < 1 || value > 600000) { set_error("peer_timeout_ms must be 1..600000"); return BAMM_ERR_ARG; }
+        c->peer_timeout_ms = (uint32_t)value;
+    }
     else if (k == "scratch_cache_mb") {
         if (value < 0) { set_error("scratch_cache_mb must be >= 0"); return BAMM_ERR_ARG; }
         c->scratch_cap_bytes = (size_t)value << 20;
@@ -1038,6 +1116,7 @@ int bamm_em_destroy(bamm_em* em) {
     for (uint32_t* p : em->owned_idx) (void)hipFree(p);
     if (em->h_status) (void)hipHostFree(em->h_status);
     (void)hipFree(em->d_stop);
+    (void)hipFree(em->d_peer_words);
     for (hipEvent_t e : em->opt_events) if (e) (void)hipEventDestroy(e);
     for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     bamm_seqs_destroy(em->seqs);
@@ -1279,7 +1358,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     if (!sliced && c->use_fused_update && update_fits_lds(prm->K, prm->W) && prm->K <= 2u) {
         size_t best = em->ebuckets.size();
         for (size_t i = 0; i < em->ebuckets.size(); i++)
-            if (em->ebuckets[i].grouped && kMClasses[em->ebuckets[i].mclass] <= 16 &&          // the classes built with the fused prologue
+            if (em->ebuckets[i].grouped && kMClasses[em->ebuckets[i].mclass] <= BAMM_FUSE_MAX_M &&   // the classes built with the fused prologue
                 (best == em->ebuckets.size() || em->ebuckets[i].count > em->ebuckets[best].count)) best = i;
         if (best < em->ebuckets.size()) {
             std::swap(em->ebuckets[0], em->ebuckets[best]);
@@ -1813,6 +1892,14 @@ int bamm_em_plan_mixed(bamm_em* em, uint64_t* mixed_seqs) {
     uint64_t m = 0;
     for (auto& b : em->ebuckets) if (b.grouped && (b.layout & 8u)) m += b.count;
     *mixed_seqs = m;
+    return BAMM_OK;
+}
+
+int bamm_em_comm_mode(bamm_em* em, int* mode, char* note, size_t note_cap) {
+    if (!em || !mode) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    if (int vrc = verify_comm(em)) return vrc;                // collective on first use, like the first pass would be
+    *mode = em->peer_on ? 2 : ((em->comm || em->allreduce) ? 1 : 0);
+    if (note && note_cap) snprintf(note, note_cap, "%s", em->peer_note.c_str());
     return BAMM_OK;
 }
 

@@ -10,6 +10,7 @@
 // copy -- the loader hands back the library that is already mapped under the same SONAME.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -52,6 +53,14 @@ struct bamm_comm {
     uint32_t rank = 0, world = 1;
     LocalGroup* local = nullptr;            // non-null: host-staged sum inside this process
     long long* h_sum = nullptr;             // pinned, local kind
+    // in-kernel all-reduce (common.h: PeerArgs): this rank's inbox and the peers' as mapped on this device
+    bool peer_tried = false, peer_ready = false;
+    uint32_t peer_stride = 0;
+    void* peer_inbox = nullptr;
+    void* peer_map[kPeerMaxWorld] = {};
+    bool peer_ipc[kPeerMaxWorld] = {};      // opened with hipIpcOpenMemHandle (another process's memory)
+    unsigned long long peer_seq = 0;        // sequence number of the last pushing pass (the ranks count in step)
+    std::string peer_why;                   // why the inboxes could not be set up
 };
 
 namespace {
@@ -145,6 +154,127 @@ int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t 
 
 bamm_ctx* comm_ctx(const bamm_comm* c) { return c->ctx; }
 bool comm_aborted(const bamm_comm* c) { return c->aborted.load(std::memory_order_acquire); }
+
+// words summed over the communicator through a device buffer (set-up traffic: votes, pointers, IPC handles)
+static int sum_words(bamm_comm* c, long long* h, size_t n) {
+    hipStream_t st = ctx_stream(c->ctx);
+    long long* d = nullptr;
+    BAMM_HIP(hipSetDevice(ctx_device(c->ctx)));
+    BAMM_HIP(hipMalloc((void**)&d, n * sizeof(long long)));
+    hipError_t e = hipMemcpyAsync(d, h, n * sizeof(long long), hipMemcpyHostToDevice, st);
+    int rc = BAMM_OK;
+    if (e == hipSuccess) rc = comm_allreduce_i64(c, d, n, st);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(h, d, n * sizeof(long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
+    (void)hipFree(d);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("communicator set-up traffic: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+    return BAMM_OK;
+}
+
+static void peer_release(bamm_comm* c) {
+    for (uint32_t r = 0; r < kPeerMaxWorld; r++) {
+        if (c->peer_map[r] && c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_map[r]);
+        c->peer_map[r] = nullptr; c->peer_ipc[r] = false;
+    }
+    if (c->peer_inbox) (void)hipFree(c->peer_inbox);
+    c->peer_inbox = nullptr;
+    c->peer_ready = false;
+}
+
+// Collective (every rank calls it, once per communicator; later calls return the first outcome): inboxes of
+// 3 x world x stride_words entries of 16 bytes in fine-grained device memory, mapped into every peer -- the pointer itself for
+// ranks of this process (peer access enabled between their devices), an IPC handle for ranks in other processes;
+// both travel over the communicator's own all-reduce (each rank fills its row of a zeroed table: the sum is the
+// all-gather).  The ranks then vote: the inboxes are used only if EVERY rank mapped all of them.  A refusal is not an
+// error: *ready = 0, comm_peer_why() says why, and the caller stays on the RCCL collective.
+int comm_peer_setup(bamm_comm* c, uint32_t stride_words, int* ready) {
+    *ready = 0;
+    if (c->peer_tried) {
+        *ready = (c->peer_ready && stride_words <= c->peer_stride) ? 1 : 0;
+        return BAMM_OK;
+    }
+    c->peer_tried = true;
+    const uint32_t world = c->world, me = c->rank;
+    if (world < 2u || world > kPeerMaxWorld) { c->peer_why = "the in-kernel all-reduce serves 2..8 ranks"; return BAMM_OK; }
+    BAMM_HIP(hipSetDevice(ctx_device(c->ctx)));
+    const size_t words = (size_t)3 * world * stride_words * 2;       // an entry = 16 bytes
+    bool ok = true;
+    std::string why;
+    hipIpcMemHandle_t handle;
+    memset(&handle, 0, sizeof handle);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    if (hipExtMallocWithFlags((void**)&c->peer_inbox, words * sizeof(long long), hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        ok = false; why = "fine-grained device memory could not be allocated";
+        c->peer_inbox = nullptr;
+    }
+    if (ok && hipMemset(c->peer_inbox, 0, words * sizeof(long long)) != hipSuccess) { ok = false; why = "hipMemset of the inbox failed"; }
+    bool have_handle = false;
+    if (ok) {
+        have_handle = hipIpcGetMemHandle(&handle, c->peer_inbox) == hipSuccess;
+        if (!have_handle) (void)hipGetLastError();           // only needed by ranks in other processes (checked below)
+    }
+    // row r of the table: [pid, device, pointer, handle present, 8 words of IPC handle, stride]
+    constexpr size_t ROW = 13;
+    std::vector<long long> tab((size_t)world * ROW, 0);
+    long long* mine = tab.data() + (size_t)me * ROW;
+    mine[0] = (long long)getpid(); mine[1] = ctx_device(c->ctx); mine[2] = (long long)(uintptr_t)c->peer_inbox;
+    mine[3] = have_handle ? 1 : 0;
+    memcpy(mine + 4, &handle, sizeof handle);
+    mine[12] = stride_words;
+    int rc = sum_words(c, tab.data(), tab.size());
+    if (rc) { peer_release(c); return rc; }
+    for (uint32_t r = 0; r < world && ok; r++) {
+        const long long* row = tab.data() + (size_t)r * ROW;
+        if (row[12] != (long long)stride_words) { ok = false; why = "the ranks ask for inboxes of different sizes"; break; }
+        if (r == me) continue;
+        if (row[2] == 0) { ok = false; why = "a peer has no inbox"; break; }
+        if (row[0] == (long long)getpid()) {                 // a rank of this process: its pointer is valid here
+            if ((int)row[1] != ctx_device(c->ctx)) {
+                const hipError_t e = hipDeviceEnablePeerAccess((int)row[1], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ok = false; why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
+                (void)hipGetLastError();
+            }
+            c->peer_map[r] = (void*)(uintptr_t)row[2];
+        } else {
+            if (!row[3]) { ok = false; why = "a peer in another process could not export its inbox (hipIpcGetMemHandle)"; break; }
+            hipIpcMemHandle_t h;
+            memcpy(&h, row + 4, sizeof h);
+            void* p = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); ok = false; why = std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e); break; }
+            c->peer_map[r] = p;
+            c->peer_ipc[r] = true;
+        }
+    }
+    long long vote[1] = {ok ? 1 : 0};
+    rc = sum_words(c, vote, 1);
+    if (rc) { peer_release(c); return rc; }
+    if (vote[0] != (long long)world) {
+        c->peer_why = ok ? "a peer could not map the inboxes" : why;
+        peer_release(c);
+        return BAMM_OK;
+    }
+    c->peer_stride = stride_words;
+    c->peer_ready = true;
+    *ready = 1;
+    return BAMM_OK;
+}
+
+const char* comm_peer_why(const bamm_comm* c) { return c->peer_why.c_str(); }
+
+// the device-side view for one launch; the caller fills the slots / sequence numbers / ticket / err
+void comm_peer_args(const bamm_comm* c, PeerArgs* p) {
+    *p = PeerArgs{};
+    p->world = c->world; p->rank = c->rank; p->stride = c->peer_stride; p->inbox = c->peer_inbox;
+    for (uint32_t r = 0; r < c->world; r++) p->peer[r] = c->peer_map[r];
+}
+
+unsigned long long comm_peer_next_seq(bamm_comm* c) {
+    if ((uint32_t)(++c->peer_seq) == 0u) ++c->peer_seq;       // the low 32 bits tag the entries: never the zero of a fresh inbox
+    return c->peer_seq;
+}
 
 }  // namespace bamm
 
@@ -303,6 +433,8 @@ int bamm_comm_destroy(bamm_comm* c) {
     if (!c) return BAMM_OK;
     if (c->local) {
         LocalGroup* g = c->local;
+        (void)hipSetDevice(ctx_device(c->ctx));
+        peer_release(c);
         (void)hipHostFree(c->h_sum);
         bool last;
         { std::lock_guard<std::mutex> lock(g->mu); last = --g->refs == 0; }
@@ -320,10 +452,9 @@ int bamm_comm_destroy(bamm_comm* c) {
         mine = c->comm;
         c->comm = nullptr;
     }
-    if (r && mine) {
-        (void)hipSetDevice(ctx_device(c->ctx));
-        (void)r->CommDestroy(mine);
-    }
+    (void)hipSetDevice(ctx_device(c->ctx));
+    peer_release(c);
+    if (r && mine) (void)r->CommDestroy(mine);
     delete c;
     return BAMM_OK;
 }

@@ -50,6 +50,11 @@ hipStream_t ctx_stream(const bamm_ctx* c);
 int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st);   // ncclAllReduce(ncclInt64, ncclSum)
 bamm_ctx* comm_ctx(const bamm_comm* c);
 bool comm_aborted(const bamm_comm* c);      // bamm_comm_abort was called on it (by any thread)
+struct PeerArgs;
+int comm_peer_setup(bamm_comm* c, uint32_t stride_words, int* ready);   // collective; *ready = 0 is a refusal, not an error
+const char* comm_peer_why(const bamm_comm* c);
+void comm_peer_args(const bamm_comm* c, PeerArgs* p);
+unsigned long long comm_peer_next_seq(bamm_comm* c);
 
 // positions-per-lane classes the sequence kernels are instantiated for (L <= 64*M)
 constexpr int kNumMClasses = 23;
@@ -123,6 +128,30 @@ struct GrpGeom {
     uint32_t mixA, mixB, off_sg6, off_ng6;
 };
 
+// ---- the pass's all-reduce in the tail of the sequence kernel, over peer-mapped memory (update_kernel.h:
+// peer_allreduce_tail; comm.cpp: comm_peer_setup) ----
+// Every rank owns an INBOX in its own HBM, fine-grained, mapped into every peer: [3 slots][world sources][stride] entries
+// of 16 bytes, an entry = one int64 word as two 8-byte halves {32 bits of data | the pass's 32-bit sequence number}.
+// The last block of the pass's launch to finish reads the GPU's totals back from the accumulator, stores them into its
+// buffer of every peer's inbox (system-scope 8-byte stores over xGMI), collects the peers' entries from its own inbox
+// as they arrive (a half is valid when it carries the sequence number: no fence, no separate flag; every poll is bounded
+// by a wall-clock deadline) and leaves totals + peers in the accumulator: integer sums, the same on every rank.  The
+// kernel boundary hands the all-reduced accumulator to what follows -- no collective launch, no host code.
+constexpr uint32_t kPeerMaxWorld = 8;
+struct PeerArgs {
+    uint32_t world, rank;        // world <= 1: off
+    uint32_t stride;             // entries per (slot, source) buffer
+    uint32_t words;              // words all-reduced: Y*W + 3
+    uint32_t slot;               // seq % 3
+    unsigned long long seq;      // this pass's sequence number (the ranks count in step; its low 32 bits tag the entries; never 0)
+    unsigned long long timeout_ticks;   // of the 100 MHz wall clock
+    void* inbox;                 // this rank's
+    void* peer[kPeerMaxWorld];   // peer[d]: rank d's inbox as mapped on this device (peer[rank] unused)
+    uint32_t* ticket;            // a zeroed device word: the blocks of the launch draw tickets, the last one all-reduces and resets it
+    uint32_t* err;               // device word: 0 = fine, else 1 + the rank whose entries did not arrive in time; a non-zero
+                                 // word makes every later launch of the handle a no-op (the host turns it into BAMM_ERR_COMM)
+};
+
 struct UpdateArgs {
     uint32_t K, W, Kbg;          // Kbg = min(bg_order, K)
     long long* acc;              // [Y*W + 3]: n_K in [y][j] (units of count_unit), llh, sum_r (fixed point), n_seqs;
@@ -186,6 +215,7 @@ struct GrpKernelArgs {
     uint32_t upd_off;            // LDS byte offset of the update's scratch (update_lds_bytes), inside the count tables
     float*   s_block;            // [blocks][W * (Y + 1)]: every block's copy of the odds table for its fix lanes
     UpdateArgs upd;
+    PeerArgs peer;               // in-kernel all-reduce (world <= 1: off)
 };
 
 // geometry for (K, W) with `waves` waves per block, M positions per lane; false when the kernel does not apply

@@ -50,6 +50,11 @@
 #include <algorithm>
 #include <cstdlib>
 
+// the longest length class (positions per lane) whose kernels carry the fused model update in their prologue
+#ifndef BAMM_FUSE_MAX_M
+#define BAMM_FUSE_MAX_M 16
+#endif
+
 namespace bamm {
 namespace {
 
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // in this block's global copy for the fix lanes.  Inside optimize() a fired stop rule ends the block here.
     [[maybe_unused]] float q_fused = 0.0f;
     bool fused_now = false;
-    if constexpr (ACCUM && !FIXG && M <= 16) {               // up to 1024 positions: beyond that a launch dwarfs the update's 6 us
+    if constexpr (ACCUM && !FIXG && M <= BAMM_FUSE_MAX_M) {  // up to 1024 positions: beyond that a launch dwarfs the update's 6 us
         if (ga.fused) {
             const UpdateOut uo = model_update_lds<false>(ga.upd, lds_raw + ga.upd_off, reinterpret_cast<float*>(lds_raw + g.off_s1),
                                                          blockIdx.x == 0);

@@ -43,6 +43,12 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     constexpr uint32_t R6N = 4096u, R6V0 = R6N + 1u, R6T = R6V0 + V;
     constexpr uint32_t Y = 64u, Ys = 65u;                      // K = 2
     if (ga.e.stop != nullptr && *ga.e.stop != 0u) return;    // optimize(): the stop rule fired in an earlier pass
+    if constexpr (ACCUM) {                                   // in-kernel all-reduce: an earlier launch gave up waiting for a peer
+        const __attribute__((address_space(4))) GrpKernelArgs* kq =
+            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        if (kq->peer.world > 1u && *kq->peer.err != 0u) return;
+    }
     extern __shared__ __align__(16) unsigned char lds_raw[];
     BAMM_PHASE(0);
     const EmKernelArgs& a = ga.e;
@@ -527,6 +533,18 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
         acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
     }
     BAMM_PHASE(6);                                           // marginalised, atomics issued (thread 0's)
+    if constexpr (ACCUM) {
+        // in-kernel all-reduce: the last block to get here sums the GPUs' totals.  Its arguments are read from the
+        // kernel-argument segment HERE (opaque pointer: the scalar loads cannot be hoisted above the sequence loop, where
+        // every live SGPR is one more spill -- 44 -> 100 spilled SGPRs and +3 % on the pass when they were ordinary arguments)
+        const __attribute__((address_space(4))) GrpKernelArgs* kq =
+            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        if (kq->peer.world > 1u) {
+            __syncthreads();                                 // the LDS is nobody's any more
+            peer_allreduce_tail(&kq->peer, kq->e.acc, reinterpret_cast<uint32_t*>(lds_raw));
+        }
+    }
 }
 
 template <int M, int A, int NQ, int THREADS>

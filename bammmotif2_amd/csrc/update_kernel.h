@@ -24,6 +24,85 @@ struct UpdateOut {
     bool fired;     // the stop rule fired (every thread; false when a.stop == nullptr)
 };
 
+// ---- the pass's all-reduce in the TAIL of the sequence kernel (common.h: PeerArgs) ----
+// An inbox entry carries one int64 word of a peer's totals as two self-validating 8-byte halves {32 bits of data, the
+// pass's 32-bit sequence number}: an aligned 8-byte store is single-copy atomic, so a reader that finds the sequence
+// number in a half has that half's data -- no fence between data and flag, on either side (RCCL's LL protocol).
+struct alignas(16) PeerEntry { unsigned long long lo, hi; };
+
+typedef const __attribute__((address_space(4))) PeerArgs* PeerArgsK;   // in the kernel-argument segment: scalar loads where used
+
+__device__ __forceinline__ PeerEntry* peer_buffer(void* inbox, uint32_t world, uint32_t stride, uint32_t slot, uint32_t src) {
+    return reinterpret_cast<PeerEntry*>(inbox) + ((size_t)slot * world + src) * stride;
+}
+
+// Called by EVERY thread of EVERY block at the end of the pass's (one) sequence launch, after the block's atomics into
+// the accumulator were issued; `lds`: 16 bytes of LDS nobody else uses any more.
+//   1. a block waits until its own atomics have been performed (they run at the device's coherence point) and draws a
+//      ticket; the block that draws the last one knows the accumulator holds this GPU's totals;
+//   2. it reads them back (device-scope loads), stores them into its buffer of every peer's inbox as self-validating
+//      entries (system-scope stores over xGMI) ...
+//   3. ... and collects the peers' entries from its own inbox as they arrive, every poll bounded by the wall-clock
+//      deadline: totals + peers -> the accumulator, in place.  The kernel boundary hands the all-reduced accumulator to
+//      whatever follows on the stream (the next pass's fused update, k_update), as RCCL's in-place all-reduce would.
+// A deadline that passes raises p.err: this launch leaves the accumulator as it is, every later launch of the handle
+// returns at entry, and the host reports BAMM_ERR_COMM at its next synchronisation.
+// (the arguments stay where they are, in the kernel-argument segment: a copy in registers across the sequence loop costs the
+// loop spilled SGPRs, a local copy of the struct costs the kernel scratch memory for the peer[] array)
+__device__ __forceinline__ void peer_allreduce_tail(PeerArgsK pk, long long* acc, uint32_t* lds) {
+    struct { uint32_t world, rank, stride, words, slot; unsigned long long seq, timeout_ticks; void* inbox; uint32_t* ticket; uint32_t* err; } p;
+    p.world = pk->world; p.rank = pk->rank; p.stride = pk->stride; p.words = pk->words; p.slot = pk->slot; p.seq = pk->seq;
+    p.timeout_ticks = pk->timeout_ticks; p.inbox = pk->inbox; p.ticket = pk->ticket; p.err = pk->err;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's accumulator atomics are performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds[0] = (t + 1u == gridDim.x) ? 1u : 0u;
+        lds[1] = 0u;                                         // a lane's deadline passed
+    }
+    __syncthreads();
+    if (lds[0] == 0u) return;
+    const unsigned long long tag = (unsigned long long)(uint32_t)p.seq << 32;
+    const unsigned long long t0 = wall_clock64();
+    // (peer[] is indexed by compile-time constants only: a run-time index into a kernel-argument array makes the
+    // compiler copy it to scratch memory, and a kernel with scratch pays for it on every launch)
+    for (uint32_t i = threadIdx.x; i < p.words; i += blockDim.x) {          // everything out first: the peers are waiting for it
+        const unsigned long long x = (unsigned long long)__hip_atomic_load(acc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long lo = tag | (x & 0xffffffffull), hi = tag | (x >> 32);
+#pragma unroll
+        for (uint32_t d = 0; d < kPeerMaxWorld; d++)
+            if (d < p.world && d != p.rank) {
+                PeerEntry* e = peer_buffer(pk->peer[d], p.world, p.stride, p.slot, p.rank) + i;
+                __hip_atomic_store(&e->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&e->hi, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+    }
+    for (uint32_t i = threadIdx.x; i < p.words; i += blockDim.x) {          // ... then the peers' words, as they arrive
+        unsigned long long sum = (unsigned long long)__hip_atomic_load(acc + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool late = false;
+        for (uint32_t r = 0; r < p.world && !late; r++) {
+            if (r == p.rank) continue;
+            const PeerEntry* e = peer_buffer(p.inbox, p.world, p.stride, p.slot, r) + i;
+            unsigned long long a, b;
+            for (;;) {
+                a = __hip_atomic_load(&e->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                b = __hip_atomic_load(&e->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((a >> 32) == (tag >> 32) && (b >> 32) == (tag >> 32)) break;
+                if (wall_clock64() - t0 > p.timeout_ticks) { late = true; lds[1] = 1u + r; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sum += (a & 0xffffffffull) | (b << 32);
+        }
+        // every word is its own lane's: nobody reads acc[i] again in this launch
+        if (!late) __hip_atomic_store(acc + i, (long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (lds[1] != 0u) __hip_atomic_store(p.err, lds[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // the next launch follows in stream order
+    }
+}
+
 // sum of the 4^D leaves under `row` in the reference's nesting (EM.cpp:247-254): each level adds its four children in
 // ascending order, from 0.0f; the loads of a cell are independent and issued together
 template <int D>

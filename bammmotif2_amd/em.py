@@ -358,6 +358,14 @@ class EM:
         check(self.lib.bamm_em_set_comm(self.h, comm.h if comm is not None else None))
         self._comm = comm
 
+    def comm_mode(self):
+        """(mode, note): 0 = no reduction over ranks, 1 = one collective per pass, 2 = inside the sequence kernels over
+        peer-mapped inboxes (Context.set_tuning(peer_allreduce=1) on every rank); collective on first use."""
+        m = C.c_int()
+        buf = C.create_string_buffer(512)
+        check(self.lib.bamm_em_comm_mode(self.h, C.byref(m), buf, 512))
+        return int(m.value), buf.value.decode()
+
     def getV(self) -> np.ndarray:
         out = np.zeros(v_size(self.K, self.W), np.float32)
         check(self.lib.bamm_em_get_v(self.h, out))

@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -171,6 +172,27 @@ def lds_roofline(tj, avg_kernel_s):
     return out
 
 
+def lds_roofline_sliced(tj):
+    """Column-sliced path (k >= 4): the E pass (k_em_seq) and the M slices (k_m_list) each against the rate an LDS-only loop
+    of their own instruction mix reaches (tools/lds_c4_bench.hip), from the PMC summary of the same command: LDS
+    wave-instructions per launch (SQ_INSTS_LDS) over the kernel's average duration (rocprofv3 --kernel-trace --stats; both
+    averages run over the same dispatches, the pass's idle flavour included on both sides).  None without such a profile."""
+    per, ceil = tj.get("per_kernel") or {}, tj.get("lds_c4_bench") or {}
+    out = {}
+    for key, tag, peak in (("e_pass", "k_em_seq", ceil.get("e_pass_wave_instr_per_s")), ("m_list", "k_m_list", ceil.get("m_list_wave_instr_per_s"))):
+        k = next((v for n, v in per.items() if tag in n), None)
+        if not k or not k.get("lds_wave_instr_per_launch") or not k.get("avg_duration_us") or not peak:
+            continue
+        rate = k["lds_wave_instr_per_launch"] / (k["avg_duration_us"] * 1e-6)
+        out[key] = {"wave_instr_per_s": rate, "wave_instr_per_launch": k["lds_wave_instr_per_launch"], "avg_duration_us": k["avg_duration_us"],
+                    "peak_from_lds_bench": peak, "frac": rate / peak}
+    if not out:
+        return None
+    out["peak_is"] = ceil.get("what")
+    out["frac"] = min(v["frac"] for v in out.values() if isinstance(v, dict))      # the kernel furthest from its ceiling
+    return out
+
+
 def workload(args):
     """The synthetic set of SURVEY.md 8(d) (seed 1234) and the seed model, packed once on the host."""
     import bammmotif2_amd as bm
@@ -216,7 +238,8 @@ def pmc_summary(local_positions, K, avg_kernel_s):
             if tj.get("positions_per_launch") == local_positions and tj.get("order", 2) == K:
                 src = {"file": os.path.relpath(tpath, ROOT), "measured_at_commit": tj.get("commit"),
                        "how": "rocprofv3 --pmc passes of `python bench.py` (tools/pmc_run.sh), not this run"}
-                return tj.get("hbm_bytes_per_launch"), lds_roofline(tj, avg_kernel_s), src
+                lds = lds_roofline_sliced(tj) if K >= 4 else lds_roofline(tj, avg_kernel_s)
+                return tj.get("hbm_bytes_per_launch"), lds, src
         except Exception:
             pass
     return None, None, None
@@ -257,8 +280,16 @@ def report(args, wl, world, dt, kernel_ms, launches, local_positions, local_wind
                    "n_seqs": args.nseq, "seq_len": L0, "W": W, "k": K,
                    "parallelism": f"sequences sharded over {world} GPU(s), 1 all-reduce of "
                                   f"{4 ** (K + 1) * W + 3} int64 words per iteration" if world > 1 else "1 GPU"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": pmc_src,
+        # fused path: SURVEY's algorithmic bytes over the kernel time.  Sliced path (k >= 4): the bytes that MOVED (PMC) over
+        # the kernel time -- SURVEY's 8.3 GB there is a dense round trip of r the path no longer makes (lists between E and
+        # M), dividing it by the time would flatter; the algorithmic figure stays beside it under its own name
+        "roofline": {"bound": "hbm",
+                     "achieved": (traffic / avg_kernel_s / 1e9) if (sliced and traffic) else achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ((traffic / avg_kernel_s / 1e9) if (sliced and traffic) else achieved) / HBM_PEAK_GBS,
+                     "frac_is": ("moved bytes (PMC traffic of the committed profile) / this run's kernel time / peak" if (sliced and traffic) else
+                                 "algorithmic bytes / kernel time / peak"),
+                     "algorithmic_achieved": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": pmc_src,
                      "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "algorithmic_bytes_rule": ("0.5 B/position + 8 B/window (sequence read by the E and the M pass, "
@@ -312,6 +343,43 @@ def attribution(step_us, kernel_us, allreduce_us, args):
             "allreduce_is": f"{args.allreduce_iters} back-to-back all-reduces of the accumulator on the kernels' stream, HIP events "
                             "around the loop (bamm_comm_time_allreduce); inside an iteration the collective also waits for the slowest rank's kernel",
             "kernel_is": "HIP events around the sequence kernel(s) of every pass of the timed call (the fused model update is its prologue)"}
+
+
+def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_max):
+    """After the headline (which always runs the RCCL collective): the same timed region with the pass's all-reduce INSIDE
+    the sequence kernels (include/bamm_em.h: bamm_em_comm_mode 2, default off) -- a number beside the headline, or the
+    reason there is none.  barrier(): all ranks; sync(): this rank's stream; reduce_max(x): max over ranks."""
+    W, K = wl["W"], wl["K"]
+    em = None
+    try:
+        ctx.set_tuning(peer_allreduce=1)
+        em = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=args.steps + args.warmup + 8,
+                   n_seqs_bound=args.nseq)
+        em.set_comm(comm)
+        mode, note = em.comm_mode()                          # collective: the ranks vote
+        if mode != 2:
+            return {"ms_per_step_peer_allreduce": "unavailable: " + (note or "mode %d" % mode)}
+        em.set_kernel_timing(args.timing_every)
+        em.iterate(args.warmup); sync(); barrier()
+        t0 = time.perf_counter()
+        em.iterate(args.steps); sync(); barrier()
+        dt = reduce_max(time.perf_counter() - t0)
+        k_ms, k_n = em.kernel_time()
+        v = em.getV()                                        # raises BAMM_ERR_COMM if a block waited in vain
+        return {"ms_per_step_peer_allreduce": dt / args.steps * 1e3,
+                "peer_allreduce": {"kernel_us": reduce_max(k_ms / max(k_n, 1) * 1e3), "model_sha": hashlib.sha256(v.tobytes()).hexdigest()[:16],
+                                   "what": "every pass but the call's last hands its sums to the peers from the kernel's own epilogue (last block, "
+                                           "system-scope stores into peer-mapped inboxes), the next pass's block prologue waits for the flags and sums; "
+                                           "kernel_us then includes the wait for the slowest rank"}}
+    except Exception as e:                                   # an extra never costs the headline
+        return {"ms_per_step_peer_allreduce": "unavailable: " + repr(e)}
+    finally:
+        try:
+            ctx.set_tuning(peer_allreduce=0)
+            if em is not None:
+                em.close()
+        except Exception:
+            pass
 
 
 def from_seed_extras(bm, ctx, seqs, wl, args, sync):
@@ -394,6 +462,7 @@ def main_inprocess(args, result_fd):
 
     gate = threading.Barrier(N)
     dts, errors, ar_us = [0.0] * N, [None] * N, [None] * N
+    peer_out, peer_tmp = [None] * N, [0.0] * N
 
     def worker(r):
         try:
@@ -408,6 +477,14 @@ def main_inprocess(args, result_fd):
             if comms and not args.local_ranks:               # outside the timed region: what the bare collective costs
                 ar_us[r] = comms[r].time_allreduce(4 ** (K + 1) * W + 3, args.allreduce_iters)
                 gate.wait()
+            if comms and N > 1 and not args.no_extras:
+                def rmax(x, r=r):
+                    peer_tmp[r] = x
+                    gate.wait()
+                    m = max(peer_tmp)
+                    gate.wait()
+                    return m
+                peer_out[r] = peer_allreduce_extra(bm, ctxs[r], seqs[r], comms[r], wl, args, gate.wait, ctxs[r].sync, rmax)
         except BaseException as e:                           # a rank that fails alone would leave the others in the collective
             errors[r] = e
             gate.abort()
@@ -435,6 +512,11 @@ def main_inprocess(args, result_fd):
     extras = {"ranks_agree_bitwise": agree, "ms_per_step_per_rank": [d / args.steps * 1e3 for d in dts]}
     if comms:
         extras["attribution"] = attribution(dt / args.steps * 1e6, [k[0] / max(k[1], 1) * 1e3 for k in kernel], ar_us, args)
+    if peer_out[0] is not None:
+        extras.update(peer_out[0])
+        shas = {(p.get("peer_allreduce") or {}).get("model_sha") for p in peer_out}
+        if len(shas) > 1:
+            extras["ms_per_step_peer_allreduce"] = "unavailable: the ranks' models differ after the in-kernel all-reduce"
     if N == 1 and not comms and not args.no_extras:
         extras.update(from_seed_extras(bm, ctxs[0], seqs[0], wl, args, ctxs[0].sync))
     lp = int(seqs[0].off[-1])
@@ -603,6 +685,17 @@ def main():
         ranks = gathered
         if sorted(g["rank"] for g in ranks) != list(range(world)) or any(g["world"] != world for g in ranks):
             raise SystemExit(f"bench.py: the ranks do not form a world of {world}: {ranks}")
+    if use_dist and world > 1 and keep and isinstance(keep[0], bm.Comm) and not args.no_extras:
+        def rmax(x):
+            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        with torch.cuda.stream(tstream):
+            extras.update(peer_allreduce_extra(bm, ctx, seqs, keep[0], wl, args, barrier, torch.cuda.synchronize, rmax))
+        shas = [None] * world
+        dist.all_gather_object(shas, (extras.get("peer_allreduce") or {}).get("model_sha"))
+        if len(set(shas)) > 1:
+            extras["ms_per_step_peer_allreduce"] = "unavailable: the ranks' models differ after the in-kernel all-reduce"
     if use_dist:
         extras["attribution"] = attribution(dt / args.steps * 1e6, [g["kernel_us"] for g in ranks], [g["allreduce_us"] for g in ranks], args)
         slow = max(ranks, key=lambda g: g["kernel_us"])                # the roofline line prices the slowest rank's kernel

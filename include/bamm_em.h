@@ -272,6 +272,18 @@ int  bamm_comm_time_allreduce(bamm_comm* c, uint64_t n_words, uint32_t iters, fl
  * process-wide check found libc's rand() to be this generator.  How the N draws of Sequence.cpp:38 and the negative
  * sampler (SeqGenerator.cpp:188-348) enter the one stream in the middle, on host threads and on the device.     */
 int  bamm_rand_stream_draws(uint32_t seed, uint64_t skip, int use_jump, uint32_t count, int32_t* out, int* matches_libc);
+/* How this handle's passes are summed over the ranks: 0 = not at all (no communicator, no callback), 1 = one collective
+ * per pass (RCCL, the host-staged group, or the caller's callback), 2 = inside the sequence kernels over peer-mapped
+ * inboxes (bamm_ctx_set_tuning "peer_allreduce" = 1 on EVERY rank's context before the handle is created; default off).
+ * Mode 2: the last block of a pass's launch to finish stores the GPU's totals into every peer's inbox (fine-grained device
+ * memory, mapped through the process or hipIpc*; 8-byte entries that carry the pass's sequence number, so no fence and
+ * no separate flag), collects the peers' entries as they arrive and leaves the sum in the accumulator, in place: no
+ * collective launch behind the pass.  Same integers, same model.  Every poll is bounded ("peer_timeout_ms", default
+ * 2000): a block that waits in vain raises a device flag that turns the handle's later launches into no-ops, and the
+ * next result read from the handle fails with BAMM_ERR_COMM.  Applies to handles whose pass is ONE launch of the
+ * mixed-row kernel (K = 2, both strands, W = 13, 14, 16, 17 or 20, one length class: the shapes of BASELINE configs
+ * 2, 3 and 5) on 2..8 ranks; the ranks vote, and one that cannot keeps all of them on mode 1 (`note` then says why).  Collective on first use: every rank calls it (or starts its first pass). */
+int  bamm_em_comm_mode(bamm_em* em, int* mode, char* note, size_t note_cap);
 /* HIP devices visible to the process (0 and BAMM_ERR_NO_DEVICE when there is none)                               */
 int  bamm_device_count(int* n);
 

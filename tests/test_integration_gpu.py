@@ -48,11 +48,11 @@ def test_reference_em_class_on_the_gpu_reproduces_the_goldens(name, R):
         if it == 0:
             assert np.array_equal(S.motif_s(m, c.K, c.W), g["s_0"])                    # Motif.cpp:485-494, bit-exact
         fl = "reference EM class over the C ABI"
-        margins.check(name, fl, f"r pass {it + 1}", S.em_r(e)[:rlen], g[f"r_{it}"], 2e-5 * (it + 1), 1e-12)
+        margins.check(name, fl, f"r pass {it + 1}", S.em_r(e)[:rlen], g[f"r_{it}"], 1e-5, 1e-12)
         np.testing.assert_allclose(np.float32(S.R.ref_em_llh(e)), g[f"llh_{it}"], rtol=1e-5)
         S.R.ref_em_mstep(e)
-        margins.check(name, fl, f"n pass {it + 1}", S.em_n(e, c.K, c.W), g[f"n_{it}"], 2e-5 * (it + 1), 1e-6)
-        margins.check(name, fl, f"v pass {it + 1}", S.motif_v(m), g[f"v_{it}"], 1e-5 * (it + 1), 1e-9)   # 1e-5 per step of drift
+        margins.check(name, fl, f"n pass {it + 1}", S.em_n(e, c.K, c.W), g[f"n_{it}"], 1e-5, 1e-6)
+        margins.check(name, fl, f"v pass {it + 1}", S.motif_v(m), g[f"v_{it}"], 1e-5, 1e-9)   # flat: observed <= 2.2e-6 over three passes
     S.R.ref_em_optimize_q(e)
     np.testing.assert_allclose(np.float32(S.R.ref_em_q(e)), g["q_after_optimize_q"], rtol=1e-5)
     # the full loop, stopping rule included (EM.cpp:62-137); the model lands in the caller's Motif

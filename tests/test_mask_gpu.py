@@ -35,16 +35,16 @@ def test_mask_three_passes_match_oracle(spec, f, oq, gpu_ctx, orc):
     assert em.last_mask["listed"] == res["listed"]                                   # EM.cpp:345-356
     assert np.float32(em.getQ()) == np.float32(res["q"])                             # EM.cpp:321 chain
     name, fl = f"mask {c.name} f={f} optQ={int(oq)}", "mask kernels"
-    margins.check(name, fl, "n pass 3", em.getCounts(), res["n"], 2e-5, 1e-7, against="fp32 restatement")
-    margins.check(name, fl, "v pass 3", em.getV(), res["v"], 2e-5, 1e-9, against="fp32 restatement")
+    margins.check(name, fl, "n pass 3", em.getCounts(), res["n"], 1e-5, 1e-7, against="fp32 restatement")
+    margins.check(name, fl, "v pass 3", em.getV(), res["v"], 1e-5, 1e-9, against="fp32 restatement")
     llh, vd, _ = em.trace()
     # the reference's llh is a sequential fp32 sum over the sequences: ~1e-7 per term
     np.testing.assert_allclose(llh, res["trace_llh"], rtol=1e-5, atol=max(1e-5, 3e-7 * c.N))
     np.testing.assert_allclose(vd, res["trace_vdiff"], rtol=1e-3, atol=1e-6)
     r = em.getR()
-    # incl. the r_[n][0] decay (:421).  r is a product of W odds of a model that already carries the
-    # reference's fp32 accumulation noise of two passes (the 2e-5 of the line above, per factor much less)
-    margins.check(name, fl, "r pass 3", r, res["r"], 2e-5 * max(1.0, c.W / 8.0), 1e-12, against="fp32 restatement")
+    # incl. the r_[n][0] decay (:421).  Flat 1e-5 on n, v and r: the observed margins (profiles/r04_parity_margins.txt)
+    # stay below 5e-6 on every case
+    margins.check(name, fl, "r pass 3", r, res["r"], 1e-5, 1e-12, against="fp32 restatement")
     assert np.array_equal(r == 0, res["r"] == 0)
     em.close(); ss.close()
 
@@ -98,9 +98,9 @@ def test_mask_k4_sliced_counts(gpu_ctx, orc):
     em.mask(0.1)
     res = orc.mask(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, f=0.1, epsilon=0.0, max_iter=2)
     assert em.last_mask["listed"] == res["listed"]
-    name, fl = f"mask {c.name} f={f} optQ={int(oq)}", "mask kernels"
-    margins.check(name, fl, "n pass 3", em.getCounts(), res["n"], 2e-5, 1e-7, against="fp32 restatement")
-    margins.check(name, fl, "v pass 3", em.getV(), res["v"], 2e-5, 1e-9, against="fp32 restatement")
+    name, fl = "mask k4 sliced f=0.1", "mask kernels"
+    margins.check(name, fl, "n pass 2", em.getCounts(), res["n"], 1e-5, 1e-7, against="fp32 restatement")
+    margins.check(name, fl, "v pass 2", em.getV(), res["v"], 1e-5, 1e-9, against="fp32 restatement")
     em.close(); ss.close()
 
 

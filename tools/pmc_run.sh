@@ -19,5 +19,17 @@ for grp in "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
       python3 bench.py --no-cpu-baseline --no-extras --warmup 25 --steps 6 "$@" > gpurun_out/pmc/g$i.log 2>&1
   echo "pmc group $i done"
 done
+# the same command once more under --kernel-trace --stats: the kernels' average durations over the SAME dispatches the
+# counters were averaged over (rates per kernel = counter / duration)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/pmc/stats -o stats --output-format csv -- \
+    python3 bench.py --no-cpu-baseline --no-extras --warmup 25 --steps 6 "$@" > gpurun_out/pmc/stats.log 2>&1
+stats=$(find gpurun_out/pmc/stats -name '*kernel_stats.csv' | head -1)
+echo "kernel stats done: $stats"
 tools/lds_mix_bench > gpurun_out/lds_mix_bench.txt 2>&1 || true
-python3 tools/summarize_pmc.py gpurun_out/pmc $positions --order $order --out $out --lds-mix gpurun_out/lds_mix_bench.txt
+extra=""
+if [ "$order" -ge 4 ]; then
+  [ -x tools/lds_c4_bench ] || hipcc --offload-arch=gfx950 -O3 tools/lds_c4_bench.hip -o tools/lds_c4_bench
+  tools/lds_c4_bench > gpurun_out/lds_c4_bench.txt 2>&1 || true
+  extra="--lds-c4 gpurun_out/lds_c4_bench.txt"
+fi
+python3 tools/summarize_pmc.py gpurun_out/pmc $positions --order $order --out $out --lds-mix gpurun_out/lds_mix_bench.txt --kernel-stats "$stats" $extra

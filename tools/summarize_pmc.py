@@ -22,6 +22,8 @@ ap.add_argument("positions", type=int)
 ap.add_argument("--order", type=int, default=2)
 ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "hbm_traffic.json"))
 ap.add_argument("--lds-mix", default=None)
+ap.add_argument("--lds-c4", default=None, help="output of tools/lds_c4_bench: the LDS ceilings of the sliced path's two kernels")
+ap.add_argument("--kernel-stats", default=None, help="rocprofv3 --kernel-trace --stats csv of the same command: average duration per kernel")
 ap.add_argument("--commit", default=os.environ.get("BAMM_COMMIT"), help="git commit the counters were taken at (the GPU box has no .git)")
 args = ap.parse_args()
 
@@ -52,7 +54,10 @@ if args.order >= 4 and seq_kernels and updates:
             continue
         launches = m["dispatches"] / updates
         parts[k] = {"launches_per_iteration": launches, "hbm_bytes_per_launch": hbm_bytes(m),
-                    "fetch_size_kib": m["FETCH_SIZE"], "write_size_kib": m["WRITE_SIZE"]}
+                    "fetch_size_kib": m["FETCH_SIZE"], "write_size_kib": m["WRITE_SIZE"],
+                    "lds_wave_instr_per_launch": m.get("SQ_INSTS_LDS"),
+                    "lds_busy_cycles_per_cu": (m["SQ_LDS_IDX_ACTIVE"] / CUS) if "SQ_LDS_IDX_ACTIVE" in m else None,
+                    "lds_bank_conflict_cycles_per_cu": (m["SQ_LDS_BANK_CONFLICT"] / CUS) if "SQ_LDS_BANK_CONFLICT" in m else None}
         if "GRBM_GUI_ACTIVE" in m:
             parts[k]["gpu_cycles_per_launch"] = m["GRBM_GUI_ACTIVE"] / XCDS
             cyc += launches * m["GRBM_GUI_ACTIVE"] / XCDS
@@ -87,6 +92,23 @@ if args.lds_mix and os.path.exists(args.lds_mix):
                 res["lds_mix_bench"]["uniform_rows_wave_instr_per_s"] = res["lds_mix_bench"]["wave_instr_per_s"]
                 res["lds_mix_bench"]["wave_instr_per_s"] = res["lds_mix_bench"]["mixed_rows_wave_instr_per_s"]
                 res["lds_mix_bench"]["what"] = res["lds_mix_bench"]["mixed_rows_what"]
+if args.lds_c4 and os.path.exists(args.lds_c4):
+    for line in open(args.lds_c4):
+        if line.startswith("{"):
+            res["lds_c4_bench"] = json.loads(line)
+if args.kernel_stats and os.path.exists(args.kernel_stats):
+    # "Name","Calls","TotalDurationNs","AverageNs",...: the average launch duration of every kernel of the same command
+    dur = {}
+    for row in csv.DictReader(open(args.kernel_stats)):
+        name = row.get("Name") or row.get("Kernel_Name") or ""
+        avg = row.get("AverageNs") or row.get("Average(ns)") or row.get("AverageDurationNs")
+        if name and avg:
+            dur[name] = float(avg) * 1e-3
+    res["avg_duration_us"] = dur
+    for k, part in (res.get("per_kernel") or {}).items():
+        hit = next((v for n, v in dur.items() if n.startswith(k.split("(")[0]) or k.startswith(n.split("(")[0])), None)
+        if hit is not None:
+            part["avg_duration_us"] = hit
 res["commit"] = args.commit
 json.dump(res, open(args.out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_mean_counters"}))
