@@ -15,7 +15,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbamm_em.so")
-SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "grouped_mix.hip", "grouped_mix1.hip", "mask.hip", "seed.hip", "long_seq.hip", "abi.cpp", "comm.cpp", "pack.cpp"]
+SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "grouped_mix.hip", "grouped_mix1.hip", "mask.hip", "seed.hip", "long_seq.hip", "prep.hip", "abi.cpp", "comm.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(CSRC, "grouped_kernel.h"), os.path.join(CSRC, "mixed_kernel.h"), os.path.join(CSRC, "update_kernel.h"), os.path.join(CSRC, "phase_clock.h"),
            os.path.join(HERE, "..", "include", "bamm_em.h")]
 # -Rpass-analysis=kernel-resource-usage: registers / scratch / spills of every kernel go to the compiler's
@@ -109,6 +109,8 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+# headers only some translation units include (a change there does not rebuild the sequence kernels)
+EXTRA_DEPS = {"prep.hip": [os.path.join(CSRC, "prep.h")], "abi.cpp": [os.path.join(CSRC, "prep.h")], "pack.cpp": [os.path.join(CSRC, "glibc_rand.h")]}
 FLAGS_STAMP = os.path.join(OBJDIR, "flags.txt")
 
 
@@ -124,9 +126,10 @@ def _flags_changed() -> bool:
 def is_stale() -> bool:
     """The library is older than a source or header, was built with other flags, or -- where the objects are at hand -- some
     object is older than its source (a source edited WHILE a build ran: the link that followed is newer than the edit)."""
-    if _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS) or _flags_changed():
+    if _stale(LIB, [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [h for v in EXTRA_DEPS.values() for h in v]) or _flags_changed():
         return True
-    return any(os.path.exists(_obj(s)) and _stale(_obj(s), [os.path.join(CSRC, s)] + HEADERS) for s in SOURCES)
+    return any((os.path.exists(_obj(s)) and _stale(_obj(s), [os.path.join(CSRC, s)] + HEADERS + EXTRA_DEPS.get(s, []))) or
+               (os.path.isdir(OBJDIR) and os.path.exists(RESOURCES) and not os.path.exists(_obj(s))) for s in SOURCES)
 
 
 @contextlib.contextmanager
@@ -160,7 +163,7 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), _obj(s)
-        if force or _stale(obj, [src] + HEADERS) or not os.path.exists(_remarks(s)):
+        if force or _stale(obj, [src] + HEADERS + EXTRA_DEPS.get(s, [])) or not os.path.exists(_remarks(s)):
             cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))

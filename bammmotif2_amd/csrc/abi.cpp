@@ -12,6 +12,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include "prep.h"
 
 // the longest length class (positions per lane) whose grouped kernels are built with the fused-update prologue and the
 // all-reduce tail (grouped_kernel.h carries the same default)
@@ -1077,6 +1078,136 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
     BAMM_HIP(hipStreamSynchronize(c->stream));
     s->hbm_bytes = (w1 - w0) * 4 + (s->n + 1) * 8 * 2 + s->n * 4;
     *out = s.release();
+    return BAMM_OK;
+}
+
+// bamm_pack_codes_seeded on the device (csrc/prep.hip), then bamm_seqs_upload: the same packed set, the same resident set
+int bamm_seqs_from_codes(bamm_ctx* c, const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand, uint32_t seed,
+                         bamm_packed** packed_out, bamm_seqs** seqs_out) {
+    if (!c || !packed_out || (n_seqs && (!codes || !off))) { set_error("bamm_seqs_from_codes: null argument"); return BAMM_ERR_ARG; }
+    *packed_out = nullptr;
+    if (seqs_out) *seqs_out = nullptr;
+    if (n_seqs == 0) {
+        int rc0 = bamm_pack_codes_seeded(codes, off, 0, single_strand, seed, packed_out);
+        if (!rc0 && seqs_out) rc0 = bamm_seqs_upload(c, *packed_out, 0, 0, seqs_out);
+        return rc0;
+    }
+    for (uint64_t n = 0; n < n_seqs; n++) {
+        const uint64_t L0 = off[n + 1] - off[n];
+        if ((single_strand ? L0 : 2 * L0 + 1) > 0xffffffffull) { set_error("sequence %llu longer than 2^32-1", (unsigned long long)n); return BAMM_ERR_ARG; }
+    }
+    BAMM_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const uint64_t n_codes = off[n_seqs] - off[0];
+    std::vector<void*> owned;                                // everything allocated here is freed on every path out
+    auto release = [&](int rc) { for (void* p : owned) (void)hipFree(p); return rc; };
+    auto alloc = [&](auto** p, size_t count) -> int {
+        int rc = dev_alloc(p, count ? count : 1);
+        if (!rc) owned.push_back((void*)*p);
+        return rc;
+    };
+    int rc;
+    uint8_t* d_codes = nullptr;
+    uint64_t* d_off = nullptr;
+    PrepArgs a{};
+    if ((rc = alloc(&d_codes, n_codes)) || (rc = alloc(&d_off, n_seqs + 1))) return release(rc);
+    {
+        // the records as one contiguous run starting at 0 (off[0] may be anything)
+        std::vector<uint64_t> rel(n_seqs + 1);
+        for (uint64_t n = 0; n <= n_seqs; n++) rel[n] = off[n] - off[0];
+        if (hipMemcpyAsync(d_codes, codes + off[0], n_codes, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_off, rel.data(), (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { set_error("bamm_seqs_from_codes: upload failed"); return release(BAMM_ERR_HIP); }
+    }
+    a.codes = d_codes; a.off = d_off; a.n = n_seqs; a.single_strand = single_strand;
+    if ((rc = alloc(&a.len, n_seqs)) || (rc = alloc(&a.word_off, n_seqs + 1)) || (rc = alloc(&a.pos_off, n_seqs + 1)) ||
+        (rc = alloc(&a.zero_off, n_seqs + 1)) || (rc = alloc(&a.draw_off, n_seqs + 1)) || (rc = alloc(&a.exc_off, n_seqs + 1))) return release(rc);
+    for (uint64_t* p : {a.word_off, a.pos_off, a.zero_off, a.draw_off, a.exc_off})
+        if (hipMemsetAsync(p, 0, sizeof(uint64_t), st) != hipSuccess) { set_error("hipMemsetAsync failed"); return release(BAMM_ERR_HIP); }
+    if ((rc = launch_prep_count(a, st))) return release(rc);
+    for (uint64_t* p : {a.word_off, a.pos_off, a.zero_off, a.draw_off})
+        if ((rc = launch_scan_u64(p, n_seqs + 1, st))) return release(rc);
+    uint64_t tot[4] = {0, 0, 0, 0};                          // words, positions, zeros, draws
+    {
+        uint64_t* src[4] = {a.word_off, a.pos_off, a.zero_off, a.draw_off};
+        for (int i = 0; i < 4; i++)
+            if (hipMemcpyAsync(&tot[i], src[i] + n_seqs, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess) { set_error("read-back failed"); return release(BAMM_ERR_HIP); }
+        if (hipStreamSynchronize(st) != hipSuccess) { set_error("bamm_seqs_from_codes: the counting pass failed"); return release(BAMM_ERR_HIP); }
+    }
+    uint8_t* d_draws = nullptr;
+    if ((rc = alloc(&a.zero_pos, tot[2])) || (rc = alloc(&d_draws, tot[3]))) return release(rc);
+    if ((rc = launch_prep_zeros(a, st))) return release(rc);
+    {
+        // the one serial resource of Sequence::Sequence is libc's rand() stream: the draws are taken on the host (all
+        // threads enter the stream by jump-ahead, pack.cpp) while the device lists the zero positions
+        std::vector<uint8_t> draws(tot[3] ? tot[3] : 1);
+        rand_draws_mod4(seed, tot[3], draws.data());
+        if (tot[3] && (hipMemcpyAsync(d_draws, draws.data(), tot[3], hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+            set_error("bamm_seqs_from_codes: upload of the draws failed"); return release(BAMM_ERR_HIP);
+        }
+    }
+    a.draws = d_draws;
+    if ((rc = launch_prep_pack(a, false, st)) || (rc = launch_scan_u64(a.exc_off, n_seqs + 1, st))) return release(rc);
+    uint64_t n_exc = 0;
+    if (hipMemcpyAsync(&n_exc, a.exc_off + n_seqs, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error("bamm_seqs_from_codes: the exception count failed"); return release(BAMM_ERR_HIP);
+    }
+    if ((rc = alloc(&a.words, tot[0])) || (rc = alloc(&a.exc_pos, n_exc)) || (rc = alloc(&a.exc_kmer, n_exc)) || (rc = alloc(&a.exc_clean, n_exc))) return release(rc);
+    if ((rc = launch_prep_pack(a, true, st))) return release(rc);
+    // the host's view of the packed set (malloc: bamm_packed_free releases it)
+    bamm_packed* p = (bamm_packed*)calloc(1, sizeof(bamm_packed));
+    if (!p) { set_error("out of memory"); return release(BAMM_ERR_ARG); }
+    p->n_seqs = n_seqs; p->n_words = tot[0]; p->n_exc = n_exc; p->total_len = tot[1];
+    p->words = (uint32_t*)malloc((tot[0] ? tot[0] : 1) * sizeof(uint32_t));
+    p->word_off = (uint64_t*)malloc((n_seqs + 1) * sizeof(uint64_t));
+    p->len = (uint32_t*)malloc(n_seqs * sizeof(uint32_t));
+    p->exc_off = (uint64_t*)malloc((n_seqs + 1) * sizeof(uint64_t));
+    p->exc_pos = (uint32_t*)calloc(n_exc ? n_exc : 1, sizeof(uint32_t));
+    p->exc_kmer = (uint32_t*)calloc(n_exc ? n_exc : 1, sizeof(uint32_t));
+    p->exc_clean = (uint32_t*)calloc(n_exc ? n_exc : 1, sizeof(uint32_t));
+    bool ok = p->words && p->word_off && p->len && p->exc_off && p->exc_pos && p->exc_kmer && p->exc_clean;
+    auto down = [&](void* dst, const void* src, size_t bytes) { if (ok && bytes) ok = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess; };
+    down(p->words, a.words, tot[0] * sizeof(uint32_t));
+    down(p->word_off, a.word_off, (n_seqs + 1) * sizeof(uint64_t));
+    down(p->len, a.len, n_seqs * sizeof(uint32_t));
+    down(p->exc_off, a.exc_off, (n_seqs + 1) * sizeof(uint64_t));
+    down(p->exc_pos, a.exc_pos, n_exc * sizeof(uint32_t));
+    down(p->exc_kmer, a.exc_kmer, n_exc * sizeof(uint32_t));
+    down(p->exc_clean, a.exc_clean, n_exc * sizeof(uint32_t));
+    if (ok) ok = hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) { bamm_packed_free(p); set_error("bamm_seqs_from_codes: the packed set could not be brought back"); return release(BAMM_ERR_HIP); }
+    uint32_t mx = 0, mn = UINT32_MAX;
+    for (uint64_t n = 0; n < n_seqs; n++) { mx = std::max(mx, p->len[n]); mn = std::min(mn, p->len[n]); }
+    p->max_len = mx; p->min_len = mn;
+    release(BAMM_OK);
+    *packed_out = p;
+    if (seqs_out && (rc = bamm_seqs_upload(c, p, 0, n_seqs, seqs_out))) { bamm_packed_free(p); *packed_out = nullptr; return rc; }
+    return BAMM_OK;
+}
+
+// BackgroundModel's counting pass over a resident set (BackgroundModel.cpp:26-42), calculateV on the host (:441-473)
+int bamm_seqs_bg_model(bamm_ctx* c, bamm_seqs* s, uint32_t K, const float* alpha, float* vbg_out) {
+    if (!c || !s || !alpha || !vbg_out || K > BAMM_MAX_ORDER) { set_error("bamm_seqs_bg_model: bad argument"); return BAMM_ERR_ARG; }
+    if (s->ctx != c) { set_error("sequence set belongs to another context"); return BAMM_ERR_ARG; }
+    const size_t Y = ipow4(K + 1);
+    std::vector<uint64_t> top(Y, 0);
+    if (s->n) {
+        BAMM_HIP(hipSetDevice(c->device));
+        ExcK* exc = nullptr;
+        int rc = exceptions_for_order(s, K, &exc);
+        if (rc) return rc;
+        unsigned long long* d_counts = nullptr;
+        if ((rc = dev_alloc(&d_counts, Y))) return rc;
+        hipError_t e = hipMemsetAsync(d_counts, 0, Y * sizeof(unsigned long long), c->stream);
+        if (e == hipSuccess) rc = launch_bg_counts(s->d_words, s->d_word_off, s->d_len, exc->d_off, exc->d_exc, s->n, K, d_counts,
+                                                   (uint32_t)std::max(1, c->num_cus), c->stream);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(top.data(), d_counts, Y * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && !rc) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(d_counts);
+        if (rc) return rc;
+        if (e != hipSuccess) { set_error("bamm_seqs_bg_model: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+    }
+    bg_from_top_counts(top.data(), K, alpha, vbg_out);
     return BAMM_OK;
 }
 

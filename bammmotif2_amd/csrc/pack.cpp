@@ -35,6 +35,10 @@ void set_error(const char* fmt, ...) {
 
 using namespace bamm;
 
+namespace bamm {
+void bg_from_top_counts(const uint64_t* top_counts, uint32_t K, const float* alpha, float* vbg_out);
+}
+
 namespace {
 
 std::atomic<uint32_t> g_host_threads{0};
@@ -183,6 +187,33 @@ static int pack_impl(const uint64_t* const* ptrs, const uint64_t* flat, const ui
 
 void bamm_set_host_threads(uint32_t n) { g_host_threads.store(n); }
 
+}  // extern "C"
+
+namespace bamm {
+// out[d] = rand() % 4 for the first D draws of the libc stream as srand(seed) leaves it.  glibc's generator is restated
+// (glibc_rand.h), checked once against the running libc, and every host thread jumps to its share of the draws; where
+// libc is another generator the draws come from srand(seed) + rand(), one after the other.  Postcondition either way:
+// libc's stream stands at srand(seed), not advanced (include/bamm_em.h: bamm_pack_codes_seeded).
+void rand_draws_mod4(uint32_t seed, uint64_t D, uint8_t* out) {
+    GlibcRandStream gen;
+    gen.start(seed);
+    if (gen.fast) {
+        const uint32_t T = host_threads();
+        parallel_ranges(D, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(T, D / 65536 + 1)), [&](uint32_t, uint64_t d0, uint64_t d1) {
+            GlibcRandStream mine = gen;
+            mine.jump(d0);
+            for (uint64_t d = d0; d < d1; d++) out[d] = (uint8_t)(mine.next_fast() % 4);
+        });
+    } else {
+        srand(seed);
+        for (uint64_t d = 0; d < D; d++) out[d] = (uint8_t)(rand() % 4);
+    }
+    srand(seed);
+}
+}  // namespace bamm
+
+extern "C" {
+
 int bamm_pack_kmers(const uint64_t* kmer, const uint64_t* off, uint64_t n_seqs, bamm_packed** out) {
     return pack_impl(nullptr, kmer, off, n_seqs, out);
 }
@@ -269,23 +300,8 @@ static int pack_codes_impl(const uint8_t* codes, const uint64_t* off, uint64_t n
     // mainBaMM.cpp:22, and reads its positives first): glibc's generator is restated (glibc_rand.h), checked against
     // the running libc, and every host thread jumps to its share of the draws -- 11 M draws at 1 M double-stranded
     // sequences were a tenth of a second in one thread.  libc's own stream is left freshly seeded.
-    GlibcRandStream gen;
-    if (seeded) gen.start(seed);
-    if (seeded && gen.fast) {
-        const uint64_t D = doff[n_seqs];
-        parallel_ranges(D, (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(T, D / 65536 + 1)), [&](uint32_t, uint64_t d0, uint64_t d1) {
-            GlibcRandStream mine = gen;
-            mine.jump(d0);
-            for (uint64_t d = d0; d < d1; d++) draws[d] = (uint8_t)(mine.next_fast() % 4);
-        });
-    } else {
-        if (seeded) srand(seed);
-        for (uint64_t d = 0; d < doff[n_seqs]; d++) draws[d] = (uint8_t)(rand() % 4);
-    }
-    // one postcondition for both seeded paths (include/bamm_em.h): libc's stream stands at srand(seed), not advanced --
-    // the reference's later consumers of the stream all reseed (SeqGenerator.cpp:35, FDR.cpp:153); a caller that does
-    // continue the one stream behind the positives uses bamm_pack_codes, which draws from libc's rand() itself
-    if (seeded) srand(seed);
+    if (seeded) rand_draws_mod4(seed, doff[n_seqs], draws.data());
+    else for (uint64_t d = 0; d < doff[n_seqs]; d++) draws[d] = (uint8_t)(rand() % 4);
 
     struct Local { std::vector<uint32_t> epos, ekmer, eclean; uint64_t n0 = 0, n1 = 0; };
     std::vector<Local> loc(T);
@@ -404,7 +420,6 @@ int bamm_bg_model(const bamm_packed* p, uint32_t K, const float* alpha, float* v
     }
     const uint32_t maskK = (uint32_t)(ipow4(K + 1) - 1);
     std::vector<uint64_t> top(ipow4(K + 1), 0);               // counts of the highest order
-    std::vector<std::vector<uint64_t>> cnt(K + 1);
     // integer counts: ranges of sequences on host threads, per-thread tables summed afterwards
     const uint32_t T = std::max<uint32_t>(1, std::min<uint64_t>(host_threads(), p->n_seqs / 1024 + 1));
     std::vector<std::vector<uint64_t>> part(T, std::vector<uint64_t>(ipow4(K + 1), 0));
@@ -426,8 +441,20 @@ int bamm_bg_model(const bamm_packed* p, uint32_t K, const float* alpha, float* v
     });
     for (uint32_t t = 0; t < T; t++)
         for (size_t y = 0; y < top.size(); y++) top[y] += part[t][y];
+    bg_from_top_counts(top.data(), K, alpha, vbg_out);
+    return BAMM_OK;
+}
+
+}  // extern "C"
+
+namespace bamm {
+// BackgroundModel::calculateV (BackgroundModel.cpp:441-473) from the counts of the highest order (where they were
+// counted does not matter: host threads here, csrc/prep.hip on the device): lower orders by marginalisation, then the
+// interpolated conditionals
+void bg_from_top_counts(const uint64_t* top_counts, uint32_t K, const float* alpha, float* vbg_out) {
+    std::vector<std::vector<uint64_t>> cnt(K + 1);
     // lower orders: kmer mod 4^(k+1) = y_K mod 4^(k+1)
-    cnt[K] = top;
+    cnt[K].assign(top_counts, top_counts + ipow4(K + 1));
     for (uint32_t k = K; k > 0; k--) {
         cnt[k - 1].assign(ipow4(k), 0);
         for (size_t y = 0; y < ipow4(k + 1); y++) cnt[k - 1][y % ipow4(k)] += cnt[k][y];
@@ -442,8 +469,10 @@ int bamm_bg_model(const bamm_packed* p, uint32_t K, const float* alpha, float* v
         for (size_t y = 0; y < ipow4(k + 1); y++)
             vk[y] = ((float)cnt[k][y] + alpha[k] * vk1[y % ipow4(k)]) / ((float)cnt[k - 1][y / 4] + alpha[k]);
     }
-    return BAMM_OK;
 }
+}  // namespace bamm
+
+extern "C" {
 
 void bamm_em_default_params(bamm_em_params* p) {
     if (!p) return;

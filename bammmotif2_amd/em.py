@@ -96,6 +96,14 @@ class PackedSeqs:
     def words(self) -> np.ndarray:
         return np.ctypeslib.as_array(self.c.words, (max(int(self.c.n_words), 1),))[: int(self.c.n_words)].copy()
 
+    def arrays(self) -> dict:
+        """Every array of the packed set (copies): words, word_off, len, exc_off, exc_pos, exc_kmer, exc_clean."""
+        c, n, ne = self.c, self.n_seqs, int(self.c.n_exc)
+        view = lambda ptr, count: np.ctypeslib.as_array(ptr, (max(count, 1),))[:count].copy()
+        return dict(words=view(c.words, int(c.n_words)), word_off=view(c.word_off, n + 1), len=view(c.len, n),
+                    exc_off=view(c.exc_off, n + 1), exc_pos=view(c.exc_pos, ne), exc_kmer=view(c.exc_kmer, ne),
+                    exc_clean=view(c.exc_clean, ne), total_len=int(c.total_len), max_len=int(c.max_len), min_len=int(c.min_len))
+
     def offsets(self) -> np.ndarray:
         return np.concatenate([[0], np.cumsum(self.lengths.astype(np.int64))]).astype(np.uint64)
 
@@ -245,6 +253,32 @@ class SeqSet:
         self.n_seqs = end - begin
         self.lengths = packed.lengths[begin:end]
         self.off = np.concatenate([[0], np.cumsum(self.lengths.astype(np.int64))]).astype(np.uint64)
+
+    @classmethod
+    def from_codes(cls, ctx: "Context", codes, off, single_strand: bool = False, seed: int = 42, resident: bool = True):
+        """Sequence::Sequence on the device (include/bamm_em.h: bamm_seqs_from_codes): returns (PackedSeqs, SeqSet) -- the
+        packed set bamm_pack_codes_seeded would have built on the host, and the resident set (None with resident=False)."""
+        off = _u64(off)
+        pk, h = C.POINTER(abi.Packed)(), C.c_void_p()
+        check(ctx.lib.bamm_seqs_from_codes(ctx.h, np.ascontiguousarray(codes, np.uint8), off, len(off) - 1, int(single_strand), seed,
+                                           C.byref(pk), C.byref(h) if resident else None))
+        packed = PackedSeqs(pk)
+        if not resident:
+            return packed, None
+        self = cls.__new__(cls)
+        self.ctx, self.lib, self.h = ctx, ctx.lib, h
+        self.n_seqs = packed.n_seqs
+        self.lengths = packed.lengths
+        self.off = np.concatenate([[0], np.cumsum(self.lengths.astype(np.int64))]).astype(np.uint64)
+        return packed, self
+
+    def bg_model(self, K: int, alpha) -> np.ndarray:
+        """BackgroundModel learned from the resident set, its counting pass on the device (bamm_seqs_bg_model)."""
+        out = np.zeros(bg_size(K), np.float32)
+        alpha = _f32(alpha)
+        assert len(alpha) >= K + 1
+        check(self.lib.bamm_seqs_bg_model(self.ctx.h, self.h, K, alpha, out))
+        return out
 
     def info(self):
         n, t, m, b = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint64()

@@ -339,6 +339,17 @@ int  bamm_logodds_subset(bamm_ctx* ctx, bamm_seqs* seqs, const uint8_t* seq_mask
                          uint32_t bg_order, const float* v_flat, const float* vbg, float* mops,
                          uint64_t mops_cap, float* zoops, uint64_t* z);
 
+/* Sequence::Sequence where the data will live: bamm_pack_codes_seeded + bamm_seqs_upload with the packing done on the
+ * device (csrc/prep.hip) -- reverse complement, 2-bit stream, kmer_[i] next to unknown bases term by term with the
+ * reference's rand() draws, the exception list.  The draws themselves are taken on the host (libc's one stream, entered
+ * by jump-ahead on all threads).  *packed_out receives the same packed set bamm_pack_codes_seeded returns, array for
+ * array (bamm_packed_free releases it); *seqs_out (may be NULL) the resident set.                                 */
+int  bamm_seqs_from_codes(bamm_ctx* ctx, const uint8_t* codes, const uint64_t* off, uint64_t n_seqs, int single_strand,
+                          uint32_t seed, bamm_packed** packed_out, bamm_seqs** seqs_out);
+/* bamm_bg_model over a resident set: the counting pass of BackgroundModel (BackgroundModel.cpp:26-42) on the device,
+ * calculateV (:441-473) on the handful of counts it leaves.  Same vbg_out as bamm_bg_model on the packed set.      */
+int  bamm_seqs_bg_model(bamm_ctx* ctx, bamm_seqs* seqs, uint32_t K, const float* alpha, float* vbg_out);
+
 /* ------------------------------------------------------------------ small host helpers -- */
 /* BackgroundModel ctor + calculateV (BackgroundModel.cpp:3-46, :441-473): interpolated
  * order-K conditionals learned from a packed set; alpha[K+1]; vbg_out[bamm_bg_size(K)].     */

@@ -5,9 +5,13 @@ the g_k2_m56_64 / g_k1_m64_ss shapes through whatever libbamm_em.so is in the tr
 -DBAMM_FUSE_MAX_M=64), compared against the fp64 restatement: which statistics, which cells (column j, y), and -- through
 getR() against the oracle's r -- which sequences, lanes and positions per lane are off."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+if os.environ.get("BAMM_PROBE_PACKAGE"):                   # another commit's package + library (tools/.v3/<name>/), this tree's oracle and cases
+    sys.path.insert(0, os.environ["BAMM_PROBE_PACKAGE"])
 import numpy as np
 import bammmotif2_amd as bm
+print("package:", os.path.dirname(bm.__file__))
 import oracle
 from tests.cases import Case
 
