@@ -4,8 +4,8 @@
 reference's EM / ScoreSeqSet interface over that ABI; `synth.py` makes the benchmark inputs.
 """
 from . import abi, synth  # noqa: F401
-from .em import (EM, Comm, Context, PackedSeqs, SeqSet, calculate_p, logodds, seed_from_pwm, libc_srand,  # noqa: F401
+from .em import (EM, Comm, Context, PackedSeqs, SeqSet, calculate_p, logodds, seed_from_pwm, sample_negatives, libc_srand,  # noqa: F401
                  v_size, v_offset, bg_size, bg_offset, device_count)
 
-__all__ = ["EM", "Comm", "Context", "PackedSeqs", "SeqSet", "calculate_p", "logodds", "seed_from_pwm", "libc_srand",
+__all__ = ["EM", "Comm", "Context", "PackedSeqs", "SeqSet", "calculate_p", "logodds", "seed_from_pwm", "sample_negatives", "libc_srand",
            "v_size", "v_offset", "bg_size", "bg_offset", "device_count", "abi", "synth"]

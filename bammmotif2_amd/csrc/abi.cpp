@@ -11,7 +11,11 @@
 #include <mutex>
 #include <unordered_map>
 
+#include <thread>
+
 #include "common.h"
+#include "glibc_rand.h"
+#include "negs.h"
 #include "prep.h"
 
 // the longest length class (positions per lane) whose grouped kernels are built with the fused-update prologue and the
@@ -363,6 +367,17 @@ SeqView make_view(const bamm_seqs* s, const ExcK* exc, const EmBucket& b, const 
     return make_view(s, exc, t, d_mask);
 }
 
+// fn(begin, end) over contiguous ranges of [0, n) on the host threads the process was granted (bamm_set_host_threads):
+// the per-sequence set-up loops below walk a million records and several million exceptions
+template <class F>
+void host_ranges(uint64_t n, F&& fn) {
+    const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(host_threads_hint(), n / 16384 + 1));
+    if (T <= 1) { fn(uint64_t(0), n); return; }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; t++) th.emplace_back([&fn, n, t, T] { fn(n * t / T, n * (t + 1) / T); });
+    for (auto& x : th) x.join();
+}
+
 // build (once per order) the list of positions whose kmer_ mod 4^(K+1) differs from what the
 // 2-bit stream gives
 int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
@@ -372,12 +387,23 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
     ExcK k;
     k.h_off.assign(s->n + 1, 0);
-    for (uint64_t n = 0; n < s->n; n++) {
-        k.h_off[n] = k.h_ex.size();
-        for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
-            if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
-                k.h_ex.push_back(make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY));
-    }
+    host_ranges(s->n, [&](uint64_t n0, uint64_t n1) {         // count per sequence, then fill: the same list in the same order
+        for (uint64_t n = n0; n < n1; n++) {
+            uint64_t c = 0;
+            for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++) c += ((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u;
+            k.h_off[n + 1] = c;
+        }
+    });
+    for (uint64_t n = 0; n < s->n; n++) k.h_off[n + 1] += k.h_off[n];
+    k.h_ex.resize(k.h_off[s->n]);
+    host_ranges(s->n, [&](uint64_t n0, uint64_t n1) {
+        for (uint64_t n = n0; n < n1; n++) {
+            uint64_t at = k.h_off[n];
+            for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
+                if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
+                    k.h_ex[at++] = make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY);
+        }
+    });
     k.h_off[s->n] = k.h_ex.size();
     k.count = k.h_ex.size();
     int rc = dev_upload(&k.d_off, k.h_off.data(), k.h_off.size(), s->ctx->stream);
@@ -415,7 +441,8 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
         }
         return y;
     };
-    for (uint64_t n = 0; n < s->n; n++) {
+    host_ranges(s->n, [&](uint64_t n_begin, uint64_t n_end) {
+    for (uint64_t n = n_begin; n < n_end; n++) {
         const uint64_t e0 = k->h_off[n], e1 = k->h_off[n + 1];
         if (e0 == e1) continue;
         const uint32_t lo = k->h_ex[e0].x, hi = k->h_ex[e1 - 1].x, L = s->h_len[n];
@@ -443,6 +470,7 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
         }
         xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
     }
+    });
     int rc = dev_upload(&x.d_xrec, xrec.data(), xrec.size(), s->ctx->stream);
     if (rc) return rc;
     if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {
@@ -1208,6 +1236,145 @@ int bamm_seqs_bg_model(bamm_ctx* c, bamm_seqs* s, uint32_t K, const float* alpha
         if (e != hipSuccess) { set_error("bamm_seqs_bg_model: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
     }
     bg_from_top_counts(top.data(), K, alpha, vbg_out);
+    return BAMM_OK;
+}
+
+// SeqGenerator::sample_bgseqset_by_fold (SeqGenerator.cpp:63-348) on the device: csrc/negs.hip
+int bamm_sample_negatives(bamm_ctx* c, bamm_seqs* pos, uint32_t s_order, uint64_t m_fold, int generic, uint64_t keep_stride,
+                          bamm_packed** packed_out, bamm_seqs** seqs_out) {
+    if (!c || !pos || !packed_out || m_fold == 0) { set_error("bamm_sample_negatives: bad argument"); return BAMM_ERR_ARG; }
+    *packed_out = nullptr;
+    if (seqs_out) *seqs_out = nullptr;
+    if (pos->ctx != c) { set_error("sequence set belongs to another context"); return BAMM_ERR_ARG; }
+    if (s_order != kNegMaxOrder) {
+        set_error("the device sampler is written for -s 2 (SeqGenerator.cpp:112-186); other orders run on the host");
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    if (pos->max_len > BAMM_MAX_SEQ_POSITIONS || pos->n == 0) { set_error("the device sampler takes non-empty sets of sequences up to %u positions", BAMM_MAX_SEQ_POSITIONS); return BAMM_ERR_UNSUPPORTED; }
+    if (!GlibcRandStream::libc_is_this_generator()) {
+        set_error("libc's rand() is not the restated glibc generator on this host: the sampler runs on the host, drawing from libc itself");
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    BAMM_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    ExcK* exc = nullptr;
+    int rc = exceptions_for_order(pos, s_order, &exc);
+    if (rc) return rc;
+    std::vector<void*> owned;
+    auto release = [&](int r) { for (void* p : owned) (void)hipFree(p); return r; };
+    auto alloc = [&](auto** p, size_t count) -> int { int r = dev_alloc(p, count ? count : 1); if (!r) owned.push_back((void*)*p); return r; };
+    NegArgs a{};
+    a.words = pos->d_words; a.word_off = pos->d_word_off; a.len = pos->d_len; a.exc_off = exc->d_off; a.exc = exc->d_exc;
+    a.n = pos->n; a.s = s_order; a.generic = generic; a.m_fold = m_fold; a.keep_stride = keep_stride;
+    for (uint32_t k = 0; k <= kNegMaxOrder; k++) a.A[k] = 20.0f;            // SeqGenerator.cpp:29-32
+    const uint32_t tot = (uint32_t)bg_size(s_order);
+    float *d_v = nullptr, *d_bar = nullptr;
+    if ((rc = alloc(&a.total_counts, tot)) || (rc = alloc(&d_v, tot)) || (rc = alloc(&d_bar, tot)) || (rc = alloc(&a.bad, 1))) return release(rc);
+    if (hipMemsetAsync(a.total_counts, 0, tot * sizeof(unsigned long long), st) != hipSuccess || hipMemsetAsync(a.bad, 0, sizeof(uint32_t), st) != hipSuccess) {
+        set_error("hipMemsetAsync failed"); return release(BAMM_ERR_HIP);
+    }
+    if ((rc = launch_neg_counts(a, st))) return release(rc);
+    std::vector<unsigned long long> cnt(tot);
+    if (hipMemcpyAsync(cnt.data(), a.total_counts, tot * sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        set_error("bamm_sample_negatives: the counting pass failed"); return release(BAMM_ERR_HIP);
+    }
+    // the set's conditionals and their bars from the totals (SeqGenerator.cpp:86-110, the float order of host/fdr.cpp)
+    std::vector<float> v(tot, 0.f), bar(tot, 0.f);
+    {
+        auto off = [](uint32_t k) { return (uint32_t)bg_offset(k); };
+        unsigned long long norm = 0;
+        for (uint32_t y = 0; y < 4; y++) norm += cnt[y];
+        float sum = 0.0f;
+        for (uint32_t y = 0; y < 4; y++) {
+            v[y] = ((float)cnt[y] + a.A[0] * 0.25f) / ((float)norm + a.A[0]);
+            sum += v[y];
+            bar[y] = sum;
+        }
+        for (uint32_t k = 1; k <= s_order; k++) {
+            sum = 0.f;
+            for (uint32_t y = 0; y < (uint32_t)ipow4(k + 1); y++) {
+                const uint32_t yk = y / 4, y2 = y % (uint32_t)ipow4(k);
+                v[off(k) + y] = ((float)cnt[off(k) + y] + a.A[k] * v[off(k - 1) + y2]) / ((float)cnt[off(k - 1) + yk] + a.A[k]);
+                if (y % 4 == 0) sum = 0.f;
+                sum += v[off(k) + y];
+                bar[off(k) + y] = sum;
+            }
+        }
+    }
+    // where every positive's draws start, where its kept negatives go; the generator's seed state and the powers t^(2^b)
+    const uint64_t total_neg = pos->n * m_fold;
+    auto kept = [&](uint64_t idx) { return keep_stride <= 1 || (idx % keep_stride == 0 && idx + keep_stride <= total_neg); };
+    std::vector<uint64_t> draw0(pos->n + 1, 0), wo(pos->n + 1, 0), first_kept(pos->n + 1, 0);
+    for (uint64_t i = 0; i < pos->n; i++) {
+        const uint64_t L = pos->h_len[i];
+        uint64_t nk = 0;
+        if (keep_stride <= 1) nk = m_fold;
+        else for (uint64_t f = 0; f < m_fold; f++) nk += kept(i * m_fold + f);
+        draw0[i + 1] = draw0[i] + L * m_fold;
+        wo[i + 1] = wo[i] + nk * ((L + 15) / 16);
+        first_kept[i + 1] = first_kept[i] + nk;
+    }
+    const uint64_t n_neg = first_kept[pos->n], n_words = wo[pos->n];
+    GlibcRandStream g;
+    g.seed(42u);                                             // SeqGenerator.cpp:35
+    std::vector<uint32_t> pw(48 * 31, 0);
+    {
+        uint32_t base[31] = {0, 1}, tmp[31];
+        for (int b = 0; b < 48; b++) {
+            memcpy(pw.data() + 31 * b, base, sizeof base);
+            GlibcRandStream::poly_mul(base, base, tmp);
+            memcpy(base, tmp, sizeof tmp);
+        }
+    }
+    uint64_t *d_draw0 = nullptr, *d_wo = nullptr;
+    uint32_t *d_seed = nullptr, *d_pw = nullptr;
+    if ((rc = alloc(&d_draw0, pos->n)) || (rc = alloc(&d_wo, pos->n)) || (rc = alloc(&d_seed, 34)) || (rc = alloc(&d_pw, pw.size())) ||
+        (rc = alloc(&a.out_words, n_words))) return release(rc);
+    hipError_t e = hipMemcpyAsync(d_v, v.data(), tot * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bar, bar.data(), tot * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_draw0, draw0.data(), pos->n * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_wo, wo.data(), pos->n * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_seed, g.r, 34 * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) { set_error("bamm_sample_negatives: upload failed: %s", hipGetErrorString(e)); return release(BAMM_ERR_HIP); }
+    a.v = d_v; a.bar = d_bar; a.draw0 = d_draw0; a.out_word_off = d_wo; a.seed_state = d_seed; a.pow2 = d_pw;
+    if ((rc = launch_neg_sample(a, st))) return release(rc);
+    // the negatives as a packed set of their own (single strand, no unknown base: no exceptions)
+    bamm_packed* p = (bamm_packed*)calloc(1, sizeof(bamm_packed));
+    if (!p) { set_error("out of memory"); return release(BAMM_ERR_ARG); }
+    p->n_seqs = n_neg; p->n_words = n_words;
+    p->words = (uint32_t*)malloc((n_words ? n_words : 1) * sizeof(uint32_t));
+    p->word_off = (uint64_t*)calloc(n_neg + 1, sizeof(uint64_t));
+    p->len = (uint32_t*)calloc(n_neg ? n_neg : 1, sizeof(uint32_t));
+    p->exc_off = (uint64_t*)calloc(n_neg + 1, sizeof(uint64_t));
+    p->exc_pos = (uint32_t*)calloc(1, sizeof(uint32_t));
+    p->exc_kmer = (uint32_t*)calloc(1, sizeof(uint32_t));
+    p->exc_clean = (uint32_t*)calloc(1, sizeof(uint32_t));
+    uint32_t bad = 0;
+    bool ok = p->words && p->word_off && p->len && p->exc_off && p->exc_pos && p->exc_kmer && p->exc_clean;
+    if (ok && n_words) ok = hipMemcpyAsync(p->words, a.out_words, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (ok) ok = hipMemcpyAsync(&bad, a.bad, sizeof bad, hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) { bamm_packed_free(p); set_error("bamm_sample_negatives: the sampling pass failed"); return release(BAMM_ERR_HIP); }
+    release(BAMM_OK);
+    if (bad) {                                               // rand() == RAND_MAX at a first base: the reference leaves that byte unset
+        bamm_packed_free(p);
+        set_error("a first base drew rand() == RAND_MAX, which the reference leaves undefined: sample this set on the host");
+        return BAMM_ERR_UNSUPPORTED;
+    }
+    uint64_t at = 0, total = 0;
+    uint32_t mx = 0, mn = UINT32_MAX;
+    for (uint64_t i = 0; i < pos->n; i++) {
+        const uint32_t L = pos->h_len[i];
+        for (uint64_t k = first_kept[i]; k < first_kept[i + 1]; k++) {
+            p->len[k] = L; p->word_off[k] = at; at += (L + 15) / 16; total += L;
+            mx = std::max(mx, L); mn = std::min(mn, L);
+        }
+    }
+    p->word_off[n_neg] = at;
+    p->total_len = total; p->max_len = mx; p->min_len = n_neg ? mn : 0;
+    *packed_out = p;
+    if (seqs_out && (rc = bamm_seqs_upload(c, p, 0, n_neg, seqs_out))) { bamm_packed_free(p); *packed_out = nullptr; return rc; }
     return BAMM_OK;
 }
 

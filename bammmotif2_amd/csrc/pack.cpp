@@ -190,6 +190,7 @@ void bamm_set_host_threads(uint32_t n) { g_host_threads.store(n); }
 }  // extern "C"
 
 namespace bamm {
+uint32_t host_threads_hint() { return host_threads(); }
 // out[d] = rand() % 4 for the first D draws of the libc stream as srand(seed) leaves it.  glibc's generator is restated
 // (glibc_rand.h), checked once against the running libc, and every host thread jumps to its share of the draws; where
 // libc is another generator the draws come from srand(seed) + rand(), one after the other.  Postcondition either way:

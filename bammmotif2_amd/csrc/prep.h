@@ -10,6 +10,8 @@ namespace bamm {
 
 // pack.cpp (host): the first D draws rand() % 4 of the stream srand(seed) starts, on all host threads (jump-ahead)
 void rand_draws_mod4(uint32_t seed, uint64_t D, uint8_t* out);
+// pack.cpp (host): the host threads the process was granted (bamm_set_host_threads; a modest default when unset)
+uint32_t host_threads_hint();
 // pack.cpp (host): BackgroundModel::calculateV from the counts of the highest order
 void bg_from_top_counts(const uint64_t* top_counts, uint32_t K, const float* alpha, float* vbg_out);
 

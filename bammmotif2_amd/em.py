@@ -465,6 +465,24 @@ class EM:
             self.h = None
 
 
+def sample_negatives(ctx: Context, positives: SeqSet, s_order: int = 2, m_fold: int = 1, generic: bool = False,
+                     keep_stride: int = 0, resident: bool = True):
+    """SeqGenerator's negative sampler on the device (include/bamm_em.h: bamm_sample_negatives): (PackedSeqs, SeqSet or
+    None) -- m_fold negatives per resident positive, the reference's own, base for base."""
+    pk, h = C.POINTER(abi.Packed)(), C.c_void_p()
+    check(ctx.lib.bamm_sample_negatives(ctx.h, positives.h, s_order, m_fold, int(generic), keep_stride, C.byref(pk),
+                                        C.byref(h) if resident else None))
+    packed = PackedSeqs(pk)
+    if not resident:
+        return packed, None
+    neg = SeqSet.__new__(SeqSet)
+    neg.ctx, neg.lib, neg.h = ctx, ctx.lib, h
+    neg.n_seqs = packed.n_seqs
+    neg.lengths = packed.lengths
+    neg.off = np.concatenate([[0], np.cumsum(neg.lengths.astype(np.int64))]).astype(np.uint64)
+    return packed, neg
+
+
 def seed_from_pwm(ctx: Context, seqs: SeqSet, K: int, W: int, score, q: float, u):
     """The pass over the sequences of Motif::initFromPWM (Motif.cpp:228-311) on the device: returns
     (counts[v_size(K,W)] int32, z[n_seqs] uint32).  score: [4][W] floored PWM / 0th-order background;

@@ -11,6 +11,7 @@
 #include <memory>
 #include <thread>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cmath>
@@ -62,6 +63,8 @@ void print_help() {
     printf("\t EXTENSIONS of this build:\n");
     printf("\t\t --maxEMIterations <INT> (1000)   -e, --epsilon <FLOAT> (0.01)   --device <INT> (0)\n");
     printf("\t\t --timing (wall time per stage on stderr)   --hostSeeding (initFromPWM's pass on the host)\n");
+    printf("\t\t --hostPacking (Sequence.cpp's encoding and the background counts on the host instead of the device)\n");
+    printf("\t\t --hostSampler (SeqGenerator's negative sampler on the host instead of the device)\n");
     printf("\t\t --gpus <INT> (1)   --deviceList <INT,INT,..>\n");
     printf("\t\t\t --EM: the sequences are sharded over the GPUs, one RCCL all-reduce of the count table per iteration;\n");
     printf("\t\t\t --FDR: cross-validation fold f runs on GPU f mod N (FDR.cpp:37 runs the folds on host threads).\n");
@@ -153,7 +156,7 @@ struct Options {                       // Global.cpp:6-96 defaults
     size_t cvFold = 4, mFold = 1, sOrder = 2, threads = 4;
     uint32_t max_iter = 1000;
     int device = 0;
-    bool timing = false, hostSeeding = false, forceComm = false;
+    bool timing = false, hostSeeding = false, hostPacking = false, hostSampler = false, forceComm = false, debug = false;
     size_t gpus = 1;                   // --gpus N: devices device .. device+N-1 (or --deviceList)
     std::vector<int> device_list;
 };
@@ -240,7 +243,7 @@ Options parse(int nargs, char** args) {
     o.score = a.present(0, "scoreSeqset");
     a.get(0, "pvalCutoff", o.pvalCutoff);
     o.verbose = a.present(0, "verbose");
-    a.present(0, "debug");
+    o.debug = a.present(0, "debug");
     o.saveBaMMs = a.present(0, "saveBaMMs");                  // presence overwrites the default (getopt_pp.h:497)
     o.saveInitial = a.present(0, "saveInitialBaMMs");
     a.get(0, "savePRs", o.savePRs);
@@ -259,6 +262,8 @@ Options parse(int nargs, char** args) {
     a.get(0, "device", o.device);
     o.timing = a.present(0, "timing");
     o.hostSeeding = a.present(0, "hostSeeding");
+    o.hostPacking = a.present(0, "hostPacking");
+    o.hostSampler = a.present(0, "hostSampler");
     a.get(0, "gpus", o.gpus);
     {   // --deviceList 0,1,2: explicit devices (a device may appear twice for the fold replicas of --FDR; the
         // sharded --EM wants distinct ones, RCCL has one rank per GPU)
@@ -310,8 +315,16 @@ int main(int nargs, char* args[]) {
 
     // the HIP runtime takes 0.1-0.2 s to come up on first use: it does so on a thread of its own while the FASTA
     // file is read and packed (nothing is decided there: the contexts proper are created where they always were)
+    // ... and since the packing itself runs on the device, the first slot's CONTEXT is created there as well (the
+    // runtime's first use of a device, its stream, the library's code objects): ready when the FASTA file is
+    static bamm_ctx* warm_ctx = nullptr;                     // written by the warm-up thread only; read after it was joined
+    static int warm_device = 0;
+    warm_device = o.device_list.empty() ? 0 : o.device_list[0];
     std::thread& hip_warmup = g_hip_warmup;
-    if (o.EM || o.score || o.FDR) hip_warmup = std::thread([] { int n = 0; (void)bamm_device_count(&n); });
+    if (o.EM || o.score || o.FDR) hip_warmup = std::thread([] {
+        int n = 0;
+        if (bamm_device_count(&n) == BAMM_OK && bamm_ctx_create(warm_device, nullptr, &warm_ctx) != BAMM_OK) warm_ctx = nullptr;
+    });
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } hip_warmup_joiner{hip_warmup};
 
     std::string err;
@@ -319,27 +332,6 @@ int main(int nargs, char* args[]) {
     if (read_fasta(o.fasta, pos, err)) die(err);
     if (pos.size() < o.cvFold) die("Error: Input sequences are too few for training! \n");
     stage("read FASTA");
-    bamm_packed* packed = nullptr;
-    // the stream stands at srand(42) (above; nothing between draws from it): the N draws are taken on all host threads
-    if (bamm_pack_codes_seeded(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, 42u, &packed)) die_abi("packing sequences");
-    stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
-    // records beyond 8192 positions leave the register-resident kernels for the window-by-window path
-    // (csrc/long_seq.hip); initFromPWM's pass over such a record runs on the host
-    if (packed->max_len > BAMM_MAX_SEQ_POSITIONS) o.hostSeeding = true;
-
-    if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
-    BgModel bg;
-    if (o.bg_file.empty()) {
-        if (bg_learn(packed, o.Kbg, o.alpha_bg, bg)) die_abi("background model");
-    } else if (bg_read(o.bg_file, bg, err)) {
-        die(err);
-    }
-    if (bg_write(o.out_dir, o.basename, bg, err)) die(err);   // always saved (mainBaMM.cpp:51)
-    stage("background model");
-
-    if (o.verbose) std::cout << std::endl << "***************************" << std::endl << "*   Initial Motif Model   *" << std::endl << "***************************" << std::endl;
-    std::vector<uint64_t> off(pos.size() + 1, 0);
-    for (size_t n = 0; n < pos.size(); n++) off[n + 1] = off[n] + packed->len[n];
     const bool need_gpu = o.EM || o.score || o.FDR;
     // one slot per GPU (a single one unless --gpus / --deviceList): context, resident sets, RCCL rank
     struct Dev {
@@ -357,15 +349,47 @@ int main(int nargs, char* args[]) {
     for (size_t d = 0; d < ndev; d++) devs[d].device = o.device_list[d];
     auto make_ctx = [&](Dev& dv) {
         if (hip_warmup.joinable()) hip_warmup.join();
+        if (!dv.ctx && warm_ctx && dv.device == warm_device) { dv.ctx = warm_ctx; warm_ctx = nullptr; }   // the one the warm-up made
         if (!dv.ctx && bamm_ctx_create(dv.device, nullptr, &dv.ctx)) die_abi("no usable MI355X");
     };
-    bamm_seqs* dseqs_all = nullptr;                          // every positive record, resident (seeding, then EM)
+    bamm_packed* packed = nullptr;
+    bamm_seqs* dseqs_all = nullptr;                          // every positive record, resident (packing, seeding, then EM)
+    // the stream stands at srand(42) (above; nothing between draws from it): the N draws are taken on all host threads
+    if (need_gpu && !o.hostPacking) {
+        // Sequence::Sequence where the data will live (csrc/prep.hip): the same packed set, and the resident set with it
+        make_ctx(devs[0]);
+        if (bamm_seqs_from_codes(devs[0].ctx, pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, 42u, &packed, &dseqs_all)) die_abi("packing sequences");
+        stage("encode + 2-bit pack on the device, resident set (Sequence.cpp incl. rand() protocol)");
+    } else {
+        if (bamm_pack_codes_seeded(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, 42u, &packed)) die_abi("packing sequences");
+        stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
+    }
+    // records beyond 8192 positions leave the register-resident kernels for the window-by-window path
+    // (csrc/long_seq.hip); initFromPWM's pass over such a record runs on the host
+    if (packed->max_len > BAMM_MAX_SEQ_POSITIONS) o.hostSeeding = true;
+
+    if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
+    BgModel bg;
+    if (o.bg_file.empty()) {
+        if (dseqs_all) {                                     // the counting pass over the resident set (BackgroundModel.cpp:26-42)
+            bg.K = o.Kbg; bg.alpha = o.alpha_bg; bg.v.assign(bamm_bg_size(o.Kbg), 0.f);
+            if (bamm_seqs_bg_model(devs[0].ctx, dseqs_all, o.Kbg, o.alpha_bg.data(), bg.v.data())) die_abi("background model");
+        } else if (bg_learn(packed, o.Kbg, o.alpha_bg, bg)) die_abi("background model");
+    } else if (bg_read(o.bg_file, bg, err)) {
+        die(err);
+    }
+    if (bg_write(o.out_dir, o.basename, bg, err)) die(err);   // always saved (mainBaMM.cpp:51)
+    stage("background model");
+
+    if (o.verbose) std::cout << std::endl << "***************************" << std::endl << "*   Initial Motif Model   *" << std::endl << "***************************" << std::endl;
+    std::vector<uint64_t> off(pos.size() + 1, 0);
+    for (size_t n = 0; n < pos.size(); n++) off[n + 1] = off[n] + packed->len[n];
     SeedDevice seed_dev;
     std::vector<uint32_t> yK;
     if (need_gpu && o.seed_tag == "PWM" && !o.hostSeeding) {
         // Motif::initFromPWM's pass over the sequences runs on the device: upload first
         make_ctx(devs[0]);
-        if (bamm_seqs_upload(devs[0].ctx, packed, 0, packed->n_seqs, &dseqs_all)) die_abi("upload");
+        if (!dseqs_all && bamm_seqs_upload(devs[0].ctx, packed, 0, packed->n_seqs, &dseqs_all)) die_abi("upload");
         seed_dev.ctx = devs[0].ctx; seed_dev.seqs = dseqs_all;
         stage("device context + upload of the positives");
     } else if (o.seed_tag == "PWM") {
@@ -393,6 +417,7 @@ int main(int nargs, char* args[]) {
     std::thread& neg_thread = g_neg_thread; // samples, packs and uploads the negatives beside the main run (joined by die() too)
     struct NegJoin { std::thread& t; ~NegJoin() { if (t.joinable()) t.join(); } } neg_join{neg_thread};
     std::string neg_err;
+    bool neg_on_device = false;
     double neg_t_sample = 0, neg_t_pack = 0;
     std::vector<uint32_t> kept_len;
     // The plan: which GPU slot does what (FDR.cpp:37-127, mainBaMM.cpp:131-147).
@@ -495,6 +520,22 @@ int main(int nargs, char* args[]) {
                 auto fail_abi = [&](const char* what) { neg_err = std::string("Error: ") + what + ": " + bamm_last_error(); };
                 auto t0 = std::chrono::high_resolution_clock::now();
                 std::string serr;
+                bamm_packed* npk = nullptr;
+                // the sampler on the device (csrc/negs.hip) where the kept positives are resident on slot 0 and the
+                // negatives are wanted as a set of their own -- all of them, or the folds' subset; it declines (-s other than 2,
+                // a libc that is not glibc, ...) with BAMM_ERR_UNSUPPORTED and the host path below takes over
+                // (--scoreSeqset --saveLogOdds prints the negatives' text: the host path keeps their codes)
+                if (!o.hostSampler && devs[0].full && (stride > 1 || !o.FDR) && !(o.score && o.saveLogOdds)) {
+                    const int rc = bamm_sample_negatives(devs[0].ctx, devs[0].full, (uint32_t)o.sOrder, mFold, o.genericNeg ? 1 : 0, stride, &npk, nullptr);
+                    if (rc != BAMM_OK && rc != BAMM_ERR_UNSUPPORTED) return fail_abi("negative sampler");
+                    if (rc == BAMM_OK) {
+                        neg_on_device = true;
+                        if (filtered) bamm_packed_free(filtered);
+                        neg_off.assign(1, 0);
+                        for (uint64_t n = 0; n < npk->n_seqs; n++) neg_off.push_back(neg_off.back() + npk->len[n]);
+                    }
+                }
+                if (!npk)
                 {
                     std::vector<uint32_t, DefaultInitAlloc<uint32_t>> ys(use->total_len ? use->total_len : 1);   // every cell is written
                     std::vector<uint64_t> uoff(n_pos + 1, 0);
@@ -506,8 +547,7 @@ int main(int nargs, char* args[]) {
                 }
                 auto t1 = std::chrono::high_resolution_clock::now();
                 neg_t_sample = std::chrono::duration<double>(t1 - t0).count();
-                bamm_packed* npk = nullptr;
-                if (bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) return fail_abi("packing negatives");
+                if (!npk && bamm_pack_codes(neg_codes.data(), neg_off.data(), neg_off.size() - 1, 1, &npk)) return fail_abi("packing negatives");
                 if (stride > 1) {                                // what was sampled IS the folds' subset
                     for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_cv_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
                     for (size_t d = 0; d < ndev; d++)
@@ -559,7 +599,7 @@ int main(int nargs, char* args[]) {
         neg_thread.join();
         if (!neg_err.empty()) die(neg_err);
         if (o.score) for (size_t n = 0; n + 1 < neg_off.size(); n++) neg_len.push_back((uint32_t)(neg_off[n + 1] - neg_off[n]));
-        if (timing) std::cerr << "[timing-beside] negative set: sample (host, rand() stream of the reference) " << neg_t_sample
+        if (timing) std::cerr << "[timing-beside] negative set: sample (" << (neg_on_device ? "device" : "host") << ", rand() stream of the reference) " << neg_t_sample
                               << " s, pack + upload " << neg_t_pack << " s, on a thread of their own beside the stages above" << std::endl;
         stage("negative set: wait for the sampler thread");
     };
@@ -840,6 +880,15 @@ int main(int nargs, char* args[]) {
     auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0_wall);
     std::cout << std::endl << "------ Runtime: " << dt.count() << " seconds -------" << std::endl;
 
+    // Everything is written and closed.  What is left is giving memory back -- a dozen hipFree calls (each a device
+    // synchronisation), a hundred megabytes of host vectors, then the HIP runtime's own static destructors: 0.1 s of a
+    // 0.7 s command that ends anyway.  The process leaves here (no other thread is alive: the side threads were joined
+    // where their results were taken); --debug keeps the orderly teardown for leak checkers.
+    if (!o.debug) {
+        std::cout.flush(); std::cerr.flush();
+        fflush(nullptr);
+        _exit(0);
+    }
     for (auto& dv : devs) {
         if (dv.comm) bamm_comm_destroy(dv.comm);
         if (dv.neg) bamm_seqs_destroy(dv.neg);

@@ -350,6 +350,17 @@ int  bamm_seqs_from_codes(bamm_ctx* ctx, const uint8_t* codes, const uint64_t* o
  * calculateV (:441-473) on the handful of counts it leaves.  Same vbg_out as bamm_bg_model on the packed set.      */
 int  bamm_seqs_bg_model(bamm_ctx* ctx, bamm_seqs* seqs, uint32_t K, const float* alpha, float* vbg_out);
 
+/* SeqGenerator::sample_bgseqset_by_fold (SeqGenerator.cpp:63-348) on the device (csrc/negs.hip): m_fold negatives per
+ * resident positive, each as long as its positive, every base one draw of the rand() stream srand(42) starts -- the
+ * reference's negatives, base for base.  keep_stride > 1: only the negatives 0, stride, 2 stride, ... (with idx + stride <=
+ * total) are generated and returned, which is all --FDR scores (FDR.cpp:58-60); the others still own their draws.
+ * generic != 0: --genericNeg (the set's own conditionals for every positive).  *packed_out: the negatives as a packed set
+ * (single strand, no exceptions; bamm_packed_free), *seqs_out (may be NULL): resident.  BAMM_ERR_UNSUPPORTED (the
+ * caller samples on the host instead): s_order != 2, sequences beyond BAMM_MAX_SEQ_POSITIONS, a libc whose rand() is
+ * not glibc's generator.                                                                                          */
+int  bamm_sample_negatives(bamm_ctx* ctx, bamm_seqs* positives, uint32_t s_order, uint64_t m_fold, int generic,
+                           uint64_t keep_stride, bamm_packed** packed_out, bamm_seqs** seqs_out);
+
 /* ------------------------------------------------------------------ small host helpers -- */
 /* BackgroundModel ctor + calculateV (BackgroundModel.cpp:3-46, :441-473): interpolated
  * order-K conditionals learned from a packed set; alpha[K+1]; vbg_out[bamm_bg_size(K)].     */

@@ -252,3 +252,55 @@ def test_cli_fold_replicas_and_native_comm_do_not_change_the_files(tmp_path, gpu
         for f in ("pos_motif_1.zoops.stats", "pos_motif_1.zoops.pvalues", "pos_motif_1.zoops.logOdds", "pos_motif_1.ihbcp"):
             if f in outs["one"]:
                 assert open(out / f, "rb").read() == outs["one"][f], f"{tag}: {f} differs"
+
+
+def test_cli_device_packing_and_host_packing_write_the_same_files(tmp_path, gpu_ctx):
+    """Sequence::Sequence and BackgroundModel's counts on the device (the default with a GPU stage; csrc/prep.hip) against
+    --hostPacking (csrc/pack.cpp): every output file byte for byte, on a FASTA with N inside, at the ends and lower case."""
+    build.build_host()
+    import random
+    rnd = random.Random(3)
+    fa = tmp_path / "n.fasta"
+    with open(fa, "w") as f:
+        for i in range(300):
+            L = rnd.randint(40, 160)
+            s = "".join(rnd.choice("ACGT") for _ in range(L))
+            if i % 7 == 0:
+                s = "N" + s[1:]
+            if i % 11 == 0:
+                s = s[:-2] + "NN"
+            if i % 5 == 0:
+                k = rnd.randint(5, L - 5)
+                s = s[:k] + "n" * rnd.randint(1, 14) + s[k:]
+            if i % 13 == 0:
+                s = s.lower()
+            f.write(f">seq{i}\n{s[:70]}\n{s[70:]}\n" if len(s) > 70 else f">seq{i}\n{s}\n")
+    outs = []
+    for extra in ([], ["--hostPacking"]):
+        out = tmp_path / ("dev" if not extra else "host")
+        r = subprocess.run([build.CLI, str(out), str(fa), "--PWMFile", MEME, "--EM", "-k", "2", "--maxPWM", "1", "--saveBaMMs",
+                            "--saveInitialBaMMs", "--FDR", "-m", "3", "-n", "3"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+        outs.append({p.name: p.read_bytes() for p in sorted(out.iterdir())})
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 6
+    for name in outs[0]:
+        assert outs[0][name] == outs[1][name], name
+
+
+@pytest.mark.parametrize("flags", [["--FDR", "-m", "3", "-n", "3"], ["--scoreSeqset"], ["--FDR", "-m", "2", "-n", "4", "--genericNeg"]],
+                         ids=["fdr", "score", "fdr_generic"])
+def test_cli_device_sampler_and_host_sampler_write_the_same_files(flags, tmp_path, gpu_ctx):
+    """SeqGenerator's negatives from the device (csrc/negs.hip, the default where the CLI wants them as a set of their own)
+    against --hostSampler (host/fdr.cpp): every output file byte for byte."""
+    build.build_host()
+    outs = []
+    for extra in ([], ["--hostSampler"]):
+        out = tmp_path / ("dev" if not extra else "host")
+        r = subprocess.run([build.CLI, str(out), FASTA, "--PWMFile", MEME, "--EM", "-k", "2", "--maxPWM", "1", "--timing"] + flags + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+        assert ("sample (device" in r.stderr) == (not extra), r.stderr[-1500:]
+        outs.append({p.name: p.read_bytes() for p in sorted(out.iterdir())})
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 4
+    for name in outs[0]:
+        assert outs[0][name] == outs[1][name], name

@@ -5,7 +5,8 @@
 //   sequence 8 x 16 = 128 `ds_read_b128` of random rows, 16 in flight at a time.
 // M slice (k_m_list, 15 columns of the count table [15][1025] u64 = 123 KB + a u16 copy of the decoded sequence per wave):
 //   per sequence 16 `ds_write_b16`, then per round of 64 listed windows 15 `ds_read_u16` + 15 full-lane `ds_add_u64` on
-//   random rows (steady state: ~240 of 972 windows listed, i.e. 4 rounds; `rounds` is the second argument).
+//   random rows (`rounds` is the second argument; default 2: in steady state the PMC counters show 16 + ~1.7 x 30 LDS
+//   wave-instructions per sequence and slice, i.e. ~110 of 972 windows listed).
 // Same table geometry and waves per CU as the kernels, random rows, no decode, no chain, no HBM: the rate the LDS pipe alone
 // allows for THESE access patterns.  One JSON line at the end for tools/summarize_pmc.py (--lds-c4).
 //   hipcc --offload-arch=gfx950 -O3 tools/lds_c4_bench.hip -o tools/lds_c4_bench && tools/lds_c4_bench [iters] [rounds]
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(THREADS) k_m(int iters, int rounds, float* sin
 }
 
 int main(int argc, char** argv) {
-    const int iters = argc > 1 ? atoi(argv[1]) : 2000, rounds = argc > 2 ? atoi(argv[2]) : 4;
+    const int iters = argc > 1 ? atoi(argv[1]) : 2000, rounds = argc > 2 ? atoi(argv[2]) : 2;
     float* sink;
     CK(hipMalloc(&sink, 4));
     hipEvent_t e0, e1;

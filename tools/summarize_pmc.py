@@ -106,7 +106,8 @@ if args.kernel_stats and os.path.exists(args.kernel_stats):
             dur[name] = float(avg) * 1e-3
     res["avg_duration_us"] = dur
     for k, part in (res.get("per_kernel") or {}).items():
-        hit = next((v for n, v in dur.items() if n.startswith(k.split("(")[0]) or k.startswith(n.split("(")[0])), None)
+        base = k.split("::")[-1].split("(")[0]                # "k_m_list<16, 768>"
+        hit = dur.get(k, next((v for n, v in dur.items() if base in n), None))
         if hit is not None:
             part["avg_duration_us"] = hit
 res["commit"] = args.commit
