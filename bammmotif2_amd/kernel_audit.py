@@ -12,6 +12,8 @@ What is checked, on the disassembly of every kernel in the code object:
 * ``in-flight`` audit: the LGKM counter is modelled instruction by instruction (DS and scalar-memory
   operations enter a queue, ``s_waitcnt lgkmcnt(N)`` retires all but the N youngest); any instruction that
   names a destination register of a ``ds_read`` that has not been retired yet is a violation.
+* ``spill holders``: a VGPR whose lanes hold spilled SGPRs may only be moved (to an AGPR and back) in whole-wave mode
+  (``audit_spill_holders``).
 * resources: scratch instructions per kernel and the compiler's own figures (registers, spills,
   scratch bytes) from ``-Rpass-analysis=kernel-resource-usage`` go to ``build/resources.json``.
 """
@@ -122,10 +124,59 @@ def audit_disassembly(text: str):
     return violations, stats
 
 
+def audit_spill_holders(text: str):
+    """SGPRs the register allocator spills live in LANES of holder VGPRs (v_writelane / v_readlane, which ignore EXEC).  When
+    VGPRs run out as well -- the 56 / 64-positions-per-lane classes: 256 VGPRs + 600-800 spilled SGPRs -- a holder is itself
+    copied to an AGPR and back.  Those copies are ordinary VALU moves: under a partial EXEC they move some lanes only, i.e.
+    they drop spilled SGPRs.  The compiler brackets them with `s_or_saveexec_b64 sX, -1` / `s_mov_b64 exec, -1` (whole-wave
+    mode); the rule here is that it always does: any instruction other than v_writelane / v_readlane that names a holder
+    must directly follow such an EXEC = -1.  (Round 3's wrong counts at those classes -- reproduced at 1b24a07 and gone
+    with 1e80103, tools/v3_bisect_build.sh -- were looked for here first; both objects satisfy the rule.)
+    Returns violations like audit_disassembly's."""
+    violations = []
+    kernel, body = None, []
+
+    def flush():
+        holders = set()
+        for _, ins in body:
+            m = re.match(r"v_writelane_b32\s+v(\d+)\b", ins)
+            if m:
+                holders.add(int(m.group(1)))
+        if not holders:
+            return
+        prev = ""
+        for lineno, ins in body:
+            op = ins.split(" ", 1)[0]
+            if op not in ("v_writelane_b32", "v_readlane_b32") and (_vregs(ins.partition(" ")[2]) & holders):
+                wwm = ("exec, -1" in prev) or (prev.startswith("s_or_saveexec_b64") and prev.rstrip().endswith("-1"))
+                if not wwm:
+                    violations.append((kernel, lineno, ins + "   <- a VGPR that holds spilled SGPRs in its lanes, moved outside whole-wave mode",
+                                       sorted(_vregs(ins.partition(" ")[2]) & holders)))
+            prev = ins
+
+    for lineno, raw in enumerate(text.splitlines(), 1):
+        m = _FUNC.match(raw)
+        if m:
+            if kernel is not None:
+                flush()
+            kernel, body = m.group(1), []
+            continue
+        if kernel is None or not raw.startswith("\t"):
+            continue
+        ins = raw.split("//")[0].strip()
+        if ins:
+            body.append((lineno, ins))
+    if kernel is not None:
+        flush()
+    return violations
+
+
 def audit_object(obj: str, workdir: str):
     co = extract_code_object(obj, workdir)
     try:
-        return audit_disassembly(disassemble(co))
+        text = disassemble(co)
+        violations, stats = audit_disassembly(text)
+        return violations + audit_spill_holders(text), stats
     finally:
         for suffix in (f".0.{TARGET}", ".0.host-x86_64-unknown-linux-gnu-"):
             try:

@@ -84,3 +84,23 @@ def test_audit_sees_a_dpp_behind_a_valu_write_of_exec():
     assert len(v) == 1 and "DPP" in v[0][2]
     v, _ = kernel_audit.audit_disassembly(listing.replace("s_nop 1", "s_nop 4"))
     assert v == []
+
+
+def test_audit_sees_a_spill_holder_moved_outside_whole_wave_mode():
+    """A VGPR whose lanes hold spilled SGPRs (v_writelane) copied to an AGPR under whatever EXEC happens to be: the lanes
+    that are switched off lose their SGPRs.  The compiler's own copies sit behind `s_or_saveexec_b64 sX, -1`."""
+    listing = """
+0000000000002000 <k_spill>:
+\tv_writelane_b32 v247, s0, 12                               // 000000002000: D28A00F7
+\ts_and_saveexec_b64 s[2:3], s[4:5]                          // 000000002008: BE822004
+\tv_accvgpr_write_b32 a0, v247                               // 00000000200C: D3D94000
+\ts_mov_b64 exec, s[2:3]                                     // 000000002014: BEFE0102
+\tv_accvgpr_read_b32 v247, a0                                // 000000002018: D3D840F7
+\tv_readlane_b32 s0, v247, 12                                // 000000002020: D28900F7
+\ts_endpgm                                                   // 000000002028: BF810000
+"""
+    v = kernel_audit.audit_spill_holders(listing)
+    assert len(v) == 2 and all(x[3] == [247] for x in v)
+    good = listing.replace("s_and_saveexec_b64 s[2:3], s[4:5]", "s_or_saveexec_b64 s[2:3], -1")
+    good = good.replace("\tv_accvgpr_read_b32 v247, a0", "\ts_mov_b64 exec, -1\n\tv_accvgpr_read_b32 v247, a0")
+    assert kernel_audit.audit_spill_holders(good) == []

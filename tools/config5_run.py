@@ -16,6 +16,9 @@ extra_dev = []
 for flag in ("--gpus", "--deviceList"):
     if flag in argv:
         i = argv.index(flag); extra_dev += argv[i:i + 2]; del argv[i:i + 2]
+for flag in ("--hostSampler", "--hostPacking"):                # the host flavours of the stages that run on the device by default
+    if flag in argv:
+        argv.remove(flag); extra_dev.append(flag)
 N = int(argv[0]) if len(argv) > 0 else 200000
 out = argv[1] if len(argv) > 1 else "/tmp/c5"
 em_only = len(argv) > 2 and argv[2] == "em"
