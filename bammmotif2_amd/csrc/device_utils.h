@@ -199,12 +199,17 @@ __device__ __forceinline__ uint32_t pick_sequence(const SeqView& sv, uint32_t t)
 // The same decode split in two so that the HBM loads of sequence t+1 are in flight while
 // sequence t is being processed (a wave owns one sequence at a time; without this every
 // sequence starts with a chain of dependent global loads).
+// (the sequence's first kRawExc exceptions travel with it: read one after the other inside decode_raw, each a global round
+// trip behind the previous one's use, they were the longest dependent chain of a sequence at k = 4 -- three or four per
+// double-stranded sequence at the strand junction)
+constexpr int kRawExc = 6;
 template <int M>
 struct RawSeq {
     static constexpr int NSEL = (M + 14) / 16 + 1;
     uint32_t seq, L;
     uint32_t w[NSEL + 1];
     uint64_t e0, e1;
+    uint2 ex[kRawExc];
     bool ok;
 };
 template <int M>
@@ -221,6 +226,8 @@ __device__ __forceinline__ RawSeq<M> fetch_seq(const SeqView& sv, uint32_t t, in
     for (int i = 0; i < RawSeq<M>::NSEL; i++) r.w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
     r.e0 = sv.exc_off[r.seq];
     r.e1 = sv.exc_off[r.seq + 1];
+#pragma unroll
+    for (int i = 0; i < kRawExc; i++) r.ex[i] = (r.e0 + (uint64_t)i < r.e1) ? sv.exc[r.e0 + (uint64_t)i] : make_uint2(0xffffffffu, 0u);
     return r;
 }
 template <int M>
@@ -242,7 +249,14 @@ __device__ __forceinline__ void decode_raw(const RawSeq<M>& r, const SeqView& sv
         const uint32_t sh = 30u - 2u * (p & 15u);
         y[m] = __builtin_amdgcn_alignbit(hi, lo, sh) & (Y - 1u);
     }
-    for (uint64_t e = r.e0; e < r.e1; e++) {             // N exceptions (Sequence.cpp:38)
+    // N exceptions (Sequence.cpp:38): the ones that came with the sequence, then whatever lies beyond them
+#pragma unroll
+    for (int i = 0; i < kRawExc; i++) {
+        const uint32_t mm = r.ex[i].x - p0;                  // 0xffffffff - p0 never lands in [0, M): lane * M <= 8128
+#pragma unroll
+        for (int m = 0; m < M; m++) y[m] = (mm == (uint32_t)m) ? r.ex[i].y : y[m];
+    }
+    for (uint64_t e = r.e0 + (uint64_t)kRawExc; e < r.e1; e++) {
         const uint2 x = sv.exc[e];
         const int mm = (int)x.x - (int)p0;
 #pragma unroll

@@ -597,23 +597,44 @@ __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0,
     const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
     unsigned short* ybuf = reinterpret_cast<unsigned short*>(n_lds + ((size_t)(nc * Ys) << logC)) + (size_t)wave * (64u * M + 8u);
     const uint32_t cstride = Ys << logC;
-    for (uint32_t t = blockIdx.x * waves_per_block + wave; t < a.sv.count; t += total_waves) {
-        const uint32_t seq = pick_sequence(a.sv, t);
-        if (a.sv.mask && !a.sv.mask[seq]) continue;
-        const uint32_t nnz = a.list_n[seq];
+    // A wave's next sequence is fetched while the current one is walked -- its words and first exceptions (fetch_seq), its
+    // list length and the first NP batches of its list: what used to be three dependent global round trips at the head of
+    // every sequence (list_n -> entries, word_off -> words, exc_off -> exceptions one by one) against ~50 LDS instructions
+    // of work (the kernel ran at 43 % of its LDS-only ceiling, profiles/r04_c4_bench.json).
+    constexpr uint32_t NP = 4;
+    struct Ahead { RawSeq<M> raw; uint32_t nnz; uint64_t base; float r[NP]; uint32_t p[NP]; };
+    auto fetch = [&](uint32_t t) {
+        Ahead h;
+        h.raw = fetch_seq<M>(a.sv, t, lane);
+        h.nnz = a.list_n[h.raw.seq];
+        h.base = a.sv.pos_off[h.raw.seq];
+#pragma unroll
+        for (uint32_t u = 0; u < NP; u++) {
+            const uint32_t idx = (uint32_t)lane + u * 64u;
+            const bool ok = idx < h.nnz;
+            h.r[u] = ok ? a.list_r[h.base + idx] : 0.0f;
+            h.p[u] = ok ? (uint32_t)a.list_p[h.base + idx] : 0u;
+        }
+        return h;
+    };
+    uint32_t t = blockIdx.x * waves_per_block + wave;
+    Ahead nxt{};
+    if (t < a.sv.count) nxt = fetch(t);
+    for (; t < a.sv.count; t += total_waves) {
+        const Ahead cur = nxt;
+        if (t + total_waves < a.sv.count) nxt = fetch(t + total_waves);
+        if (!cur.raw.ok) continue;
+        const uint32_t nnz = cur.nnz;
         if (nnz == 0u) continue;
-        const uint32_t L = a.sv.len[seq];
+        const uint32_t L = cur.raw.L;
         const uint32_t LW1 = L - W + 1u;
         const uint32_t p0 = (uint32_t)lane * M;
-        const uint64_t base = a.sv.pos_off[seq];
-        // NP batches of 64 entries are requested at once and the next NP while those are walked: with one batch in
-        // flight the walk waited a full HBM round trip per 64 windows -- nothing to hide behind while the model is
-        // uninformative and a list holds every window (11.6 ms per slice at 1M x 1001 positions against 1.5 ms in
-        // steady state, profiles/r02_c4_kernel_stats.csv).  The first ones are on their way while the sequence is decoded.
-        constexpr uint32_t NP = 4;
+        const uint64_t base = cur.base;
         float r_nxt[NP];
         uint32_t p_nxt[NP];
-        auto request = [&](uint32_t e) {
+#pragma unroll
+        for (uint32_t u = 0; u < NP; u++) { r_nxt[u] = cur.r[u]; p_nxt[u] = cur.p[u]; }
+        auto request = [&](uint32_t e) {                      // lists beyond the first NP batches: the next NP while these are walked
 #pragma unroll
             for (uint32_t u = 0; u < NP; u++) {
                 const uint32_t idx = e + u * 64u;
@@ -622,9 +643,8 @@ __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0,
                 p_nxt[u] = ok ? (uint32_t)a.list_p[base + idx] : 0u;
             }
         };
-        request((uint32_t)lane);
         uint32_t y[M];
-        decode_positions<M>(a.sv, seq, L, Y, LW1, lane, y);          // EM.cpp:236: positions >= LW1 take no part (row Y)
+        decode_raw<M>(cur.raw, a.sv, Y, LW1, lane, y);               // EM.cpp:236: positions >= LW1 take no part (row Y)
 #pragma unroll
         for (int m = 0; m < M; m++) ybuf[p0 + m] = (unsigned short)y[m];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
