@@ -597,32 +597,58 @@ __global__ void __launch_bounds__(THREADS) k_m_list(EmKernelArgs a, uint32_t j0,
     const uint32_t copy = (uint32_t)lane & ((1u << logC) - 1u);
     unsigned short* ybuf = reinterpret_cast<unsigned short*>(n_lds + ((size_t)(nc * Ys) << logC)) + (size_t)wave * (64u * M + 8u);
     const uint32_t cstride = Ys << logC;
-    // A wave's next sequence is fetched while the current one is walked -- its words and first exceptions (fetch_seq), its
+    // A wave's next sequence is fetched while the current one is walked -- its words and first exceptions, its
     // list length and the first NP batches of its list: what used to be three dependent global round trips at the head of
     // every sequence (list_n -> entries, word_off -> words, exc_off -> exceptions one by one) against ~50 LDS instructions
     // of work (the kernel ran at 43 % of its LDS-only ceiling, profiles/r04_c4_bench.json).
+    // Two levels of loads hang on each other -- the sequence's offsets and counts (head), then its words, exceptions and list
+    // entries (body) -- so the pipeline is two deep: the head of the sequence after next is requested while the body of the
+    // next one goes out, and neither round trip is waited for at the head of a sequence.
     constexpr uint32_t NP = 4;
+    struct Head { uint32_t seq, L, nnz; uint64_t woff, base, e0, e1; bool ok; };
     struct Ahead { RawSeq<M> raw; uint32_t nnz; uint64_t base; float r[NP]; uint32_t p[NP]; };
-    auto fetch = [&](uint32_t t) {
+    auto head = [&](uint32_t t) {
+        Head h;
+        h.seq = pick_sequence(a.sv, t);
+        h.ok = !(a.sv.mask && !a.sv.mask[h.seq]);
+        h.L = a.sv.len[h.seq];
+        h.nnz = a.list_n[h.seq];
+        h.woff = a.sv.word_off[h.seq];
+        h.base = a.sv.pos_off[h.seq];
+        h.e0 = a.sv.exc_off[h.seq];
+        h.e1 = a.sv.exc_off[h.seq + 1];
+        return h;
+    };
+    auto body = [&](const Head& hd) {
         Ahead h;
-        h.raw = fetch_seq<M>(a.sv, t, lane);
-        h.nnz = a.list_n[h.raw.seq];
-        h.base = a.sv.pos_off[h.raw.seq];
+        h.raw.seq = hd.seq; h.raw.ok = hd.ok; h.raw.L = hd.L; h.raw.e0 = hd.e0; h.raw.e1 = hd.e1;
+        h.nnz = hd.nnz; h.base = hd.base;
+        const uint32_t* wp = a.sv.words + hd.woff;
+        const uint32_t nw = (hd.L + 15u) >> 4;
+        const uint32_t wi0 = ((uint32_t)lane * M) >> 4;
+        h.raw.w[0] = (wi0 >= 1u && wi0 - 1u < nw) ? wp[wi0 - 1u] : 0u;
+#pragma unroll
+        for (int i = 0; i < RawSeq<M>::NSEL; i++) h.raw.w[i + 1] = (wi0 + i < nw) ? wp[wi0 + i] : 0u;
+#pragma unroll
+        for (int i = 0; i < kRawExc; i++) h.raw.ex[i] = (hd.e0 + (uint64_t)i < hd.e1) ? a.sv.exc[hd.e0 + (uint64_t)i] : make_uint2(0xffffffffu, 0u);
 #pragma unroll
         for (uint32_t u = 0; u < NP; u++) {
             const uint32_t idx = (uint32_t)lane + u * 64u;
-            const bool ok = idx < h.nnz;
-            h.r[u] = ok ? a.list_r[h.base + idx] : 0.0f;
-            h.p[u] = ok ? (uint32_t)a.list_p[h.base + idx] : 0u;
+            const bool ok = idx < hd.nnz;
+            h.r[u] = ok ? a.list_r[hd.base + idx] : 0.0f;
+            h.p[u] = ok ? (uint32_t)a.list_p[hd.base + idx] : 0u;
         }
         return h;
     };
     uint32_t t = blockIdx.x * waves_per_block + wave;
     Ahead nxt{};
-    if (t < a.sv.count) nxt = fetch(t);
+    Head h1{};
+    if (t < a.sv.count) nxt = body(head(t));
+    if (t + total_waves < a.sv.count) h1 = head(t + total_waves);
     for (; t < a.sv.count; t += total_waves) {
         const Ahead cur = nxt;
-        if (t + total_waves < a.sv.count) nxt = fetch(t + total_waves);
+        if (t + total_waves < a.sv.count) nxt = body(h1);                      // its head was requested an iteration ago
+        if (t + 2u * total_waves < a.sv.count) h1 = head(t + 2u * total_waves);
         if (!cur.raw.ok) continue;
         const uint32_t nnz = cur.nnz;
         if (nnz == 0u) continue;
