@@ -525,8 +525,10 @@ int main(int nargs, char* args[]) {
                 // negatives are wanted as a set of their own -- all of them, or the folds' subset; it declines (-s other than 2,
                 // a libc that is not glibc, ...) with BAMM_ERR_UNSUPPORTED and the host path below takes over
                 // (--scoreSeqset --saveLogOdds prints the negatives' text: the host path keeps their codes)
-                if (!o.hostSampler && devs[0].full && (stride > 1 || !o.FDR) && !(o.score && o.saveLogOdds)) {
-                    const int rc = bamm_sample_negatives(devs[0].ctx, devs[0].full, (uint32_t)o.sOrder, mFold, o.genericNeg ? 1 : 0, stride, &npk, nullptr);
+                size_t dfull = ndev;                             // the first slot that holds every kept positive (with a sharded main
+                for (size_t d = 0; d < ndev && dfull == ndev; d++) if (devs[d].full) dfull = d;   // run: a fold's slot)
+                if (!o.hostSampler && dfull < ndev && (stride > 1 || !o.FDR) && !(o.score && o.saveLogOdds)) {
+                    const int rc = bamm_sample_negatives(devs[dfull].ctx, devs[dfull].full, (uint32_t)o.sOrder, mFold, o.genericNeg ? 1 : 0, stride, &npk, nullptr);
                     if (rc != BAMM_OK && rc != BAMM_ERR_UNSUPPORTED) return fail_abi("negative sampler");
                     if (rc == BAMM_OK) {
                         neg_on_device = true;
