@@ -12,9 +12,19 @@
 namespace bammhost {
 
 // ---- sequences (init/SequenceSet.cpp:67-225, init/Alphabet.cpp:10-55, STANDARD alphabet) ----
+// resize() of a vector of bytes with this allocator leaves the new bytes uninitialised: 400 MB of negatives are written
+// by the sampler's threads, a serial zero-fill in front of that costs as much as the sampling (1.0 of 1.6 s)
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
+    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+using ByteVec = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;
+
 struct FastaSet {
     std::vector<std::string> headers;   // keep the leading '>' like the reference (SequenceSet.cpp:137-139)
-    std::vector<uint8_t> codes;         // 0 = N, 1..4 = A,C,G,T
+    ByteVec codes;                      // 0 = N, 1..4 = A,C,G,T
     std::vector<uint64_t> off;          // [n+1]
     size_t min_len = 0, max_len = 0;
     float base_freq[4] = {0, 0, 0, 0};
@@ -81,15 +91,6 @@ namespace bammhost {
 // srand(42) (:35), calculate_kmer_frequency (:63-110), rescale_kmer_frequency (:112-186, hard-wired
 // to s = 2 like the reference), bgseq_on_rescaled_v (:285-348) and bg_sequence (:222-283).
 // y_s: kmer_ mod 4^(s+1) for every position of the reference sequences (as EM sees them).
-// resize() of a vector of bytes with this allocator leaves the new bytes uninitialised: 400 MB of negatives are written
-// by the sampler's threads, a serial zero-fill in front of that costs as much as the sampling (1.0 of 1.6 s)
-template <class T>
-struct DefaultInitAlloc : std::allocator<T> {
-    template <class U> struct rebind { using other = DefaultInitAlloc<U>; };
-    template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
-    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
-};
-using ByteVec = std::vector<uint8_t, DefaultInitAlloc<uint8_t>>;
 
 // every core the process may use (affinity mask capped by the cgroup quota): for host work whose result does not
 // depend on how it is cut -- the negative sampler, packing, sorts
@@ -97,6 +98,9 @@ int host_parallelism();
 void set_host_parallelism(int n);           // tests: force a thread count (0 = every granted core again)
 int sample_negatives(const uint32_t* y_s, const uint64_t* off, size_t n_seqs, uint32_t s_order, size_t m_fold,
                      bool generic, ByteVec& codes_out, std::vector<uint64_t>& off_out, std::string& err, size_t keep_stride = 0);
+
+// one float as `ostream << float` prints it at `precision` significant digits (printf %g); `out` holds 48 bytes; returns the length
+size_t format_g(char* out, float x, int precision);
 
 struct FdrResult {                      // what FDR::calculatePR / calculatePvalues leave behind (FDR.h:54-84)
     std::vector<float> zoops_tp, zoops_fp, zoops_fdr, zoops_rec, pn_pvalue, zoops_pvalue;

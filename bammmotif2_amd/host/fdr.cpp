@@ -432,19 +432,73 @@ void fdr_statistics(std::vector<float> posMax, std::vector<float> negMax, std::v
     }
 }
 
+// `ostream << float` at precision P, i.e. printf's %.Pg, without the general-purpose machinery: the P significant digits
+// come from one double multiplication (a float times a power of ten up to 1e22 is one rounding away from exact) and
+// are used only when that rounding cannot have changed them -- the scaled value further than 1e-6 from a half; anything
+// else (zero, non-finite, exponents beyond the exact powers, the rare near-tie) goes to std::to_chars, which IS %g.
+// 11 M numbers per .stats file: most of what the file costs.
+size_t format_g(char* out, float xf, int P) {
+    static const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    auto slow = [&]() { return (size_t)(std::to_chars(out, out + 40, xf, std::chars_format::general, P).ptr - out); };
+    if (P < 1 || P > 9 || !(xf == xf) || xf == 0.0f || std::isinf(xf)) return slow();
+    char* o = out;
+    double x = (double)xf;
+    if (x < 0) { *o++ = '-'; x = -x; }
+    int e2;
+    (void)std::frexp(x, &e2);                                // x in [2^(e2-1), 2^e2)
+    int e = (int)std::floor((e2 - 1) * 0.30102999566398120); // floor(log10(x)) or one below
+    if (e < -15 || e > 15) return slow();
+    auto ge_pow = [&](int k) { return k >= 0 ? x >= p10[k] : x * p10[-k] >= 1.0; };   // x >= 10^k (x * 10^-k exact enough: checked again below)
+    if (ge_pow(e + 1)) e++;
+    const int k = P - 1 - e;                                 // scale to P digits in front of the point
+    double v = k >= 0 ? x * p10[k] : x / p10[-k];
+    const double lo = p10[P - 1], hi = p10[P];
+    if (v < lo || v >= hi) {                                 // e was one off at a power of ten (x * 10^-k rounding): settle it exactly
+        if (v < lo) { e--; } else { e++; }
+        const int k2 = P - 1 - e;
+        if (k2 < -22 || k2 > 22) return slow();
+        v = k2 >= 0 ? x * p10[k2] : x / p10[-k2];
+        if (v < lo || v >= hi) return slow();
+    }
+    uint64_t m = (uint64_t)v;
+    const double frac = v - (double)m;
+    if (std::fabs(frac - 0.5) < 1e-6) return slow();         // too close to a tie for one rounding to be trusted
+    if (frac > 0.5 && ++m == (uint64_t)hi) { m = (uint64_t)lo; e++; }
+    char dig[16];
+    for (int i = P - 1; i >= 0; i--) { dig[i] = (char)('0' + m % 10); m /= 10; }
+    int nd = P;
+    while (nd > 1 && dig[nd - 1] == '0') nd--;               // %g drops trailing zeros
+    if (e < -4 || e >= P) {                                  // d.ddde+XX
+        *o++ = dig[0];
+        if (nd > 1) { *o++ = '.'; memcpy(o, dig + 1, (size_t)nd - 1); o += nd - 1; }
+        *o++ = 'e';
+        int ae = e;
+        if (ae < 0) { *o++ = '-'; ae = -ae; } else { *o++ = '+'; }
+        *o++ = (char)('0' + ae / 10); *o++ = (char)('0' + ae % 10);
+    } else if (e >= 0) {
+        const int ip = e + 1;                                // digits in front of the point (<= P)
+        for (int i = 0; i < ip; i++) *o++ = i < nd ? dig[i] : '0';
+        if (nd > ip) { *o++ = '.'; memcpy(o, dig + ip, (size_t)(nd - ip)); o += nd - ip; }
+    } else {
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -e - 1; i++) *o++ = '0';
+        memcpy(o, dig, (size_t)nd); o += nd;
+    }
+    return (size_t)(o - out);
+}
+
 namespace {
 
 // rows of floats exactly as `ostream << float` prints them (printf %g at the stream's precision),
 // collected in memory and written once: the reference ends every row with std::endl, i.e. one
 // write() per line, which at 2.2 M rows costs more than computing the statistics
-struct RowWriter {
+struct alignas(128) RowWriter {                          // a line of its own: the string's length changes with every number, and the threads' writers sit side by side
     std::string buf;
     int precision;
     explicit RowWriter(int prec = 6) : precision(prec) { buf.reserve(1 << 20); }
     void num(float x) {
         char tmp[48];
-        auto res = std::to_chars(tmp, tmp + sizeof tmp, x, std::chars_format::general, precision);
-        buf.append(tmp, res.ptr);
+        buf.append(tmp, format_g(tmp, x, precision));
     }
     void tab() { buf.push_back('\t'); }
     void nl() { buf.push_back('\n'); }

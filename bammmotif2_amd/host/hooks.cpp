@@ -4,6 +4,7 @@
 
 #include <omp.h>
 
+#include <charconv>
 #include "bamm_host.h"
 
 using namespace bammhost;
@@ -172,6 +173,19 @@ int bh_fdr_stats(const float* pos_max, uint64_t n_pos_max, const float* neg_max,
                    std::vector<float>(pos_all, pos_all + n_pos_all), std::vector<float>(neg_all, neg_all + n_neg_all), posN, negN,
                    q, mops != 0, zoops != 0, save_pvalues != 0, r);
     return fdr_write(dir, base, r, posN, negN, mops != 0, zoops != 0, true, save_pvalues != 0, g_err);
+}
+
+// tests: format_g against std::to_chars (which is printf's %g) on n floats; returns the number of differing strings and
+// the first offender's bits
+uint64_t bh_format_g_check(const float* x, uint64_t n, int precision, uint32_t* first_bad_bits) {
+    uint64_t bad = 0;
+    char a[48], b[48];
+    for (uint64_t i = 0; i < n; i++) {
+        const size_t la = format_g(a, x[i], precision);
+        const size_t lb = (size_t)(std::to_chars(b, b + sizeof b, x[i], std::chars_format::general, precision).ptr - b);
+        if (la != lb || memcmp(a, b, la)) { if (!bad && first_bad_bits) memcpy(first_bad_bits, &x[i], 4); bad++; }
+    }
+    return bad;
 }
 
 // --saveLogOdds writers on caller-provided scores

@@ -309,6 +309,8 @@ int main(int nargs, char* args[]) {
     srand(42);                                               // mainBaMM.cpp:22
     Options o = parse(nargs, args);
     timing = o.timing;
+    auto epoch = [] { return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count(); };
+    if (timing) fprintf(stderr, "[timing-abs] main entered at %.4f\n", epoch() - std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0_wall).count());
     if (o.alphabet != "STANDARD") die("Error: this build supports --alphabet STANDARD only.");
     if (o.CGS) die("Error: --CGS (collapsed Gibbs sampling) is not part of the MI355X build.");
     if (o.K > BAMM_MAX_ORDER) die("Error: model order above 10 is not supported (kmer_ spans 11 bases).");
@@ -605,16 +607,22 @@ int main(int nargs, char* args[]) {
                               << " s, pack + upload " << neg_t_pack << " s, on a thread of their own beside the stages above" << std::endl;
         stage("negative set: wait for the sampler thread");
     };
-    // kept positives: FASTA codes / headers in the same order as the resident set
-    std::vector<std::string> kept_headers;
-    std::vector<uint8_t> kept_codes;
-    std::vector<uint64_t> kept_off{0};
-    for (size_t n = 0; n < pos.size(); n++)
-        if (keep[n]) {
-            kept_headers.push_back(pos.headers[n]);
-            kept_codes.insert(kept_codes.end(), pos.codes.begin() + pos.off[n], pos.codes.begin() + pos.off[n + 1]);
-            kept_off.push_back(kept_codes.size());
-        }
+    // kept positives: FASTA codes / headers in the same order as the resident set -- what --scoreSeqset's writers print;
+    // copies only where a record was dropped (0.1 s at a million records otherwise, for nothing)
+    std::vector<std::string> kept_headers_own;
+    ByteVec kept_codes_own;
+    std::vector<uint64_t> kept_off_own{0};
+    if (o.score && posN != pos.size())
+        for (size_t n = 0; n < pos.size(); n++)
+            if (keep[n]) {
+                kept_headers_own.push_back(pos.headers[n]);
+                kept_codes_own.insert(kept_codes_own.end(), pos.codes.begin() + pos.off[n], pos.codes.begin() + pos.off[n + 1]);
+                kept_off_own.push_back(kept_codes_own.size());
+            }
+    const bool kept_all = posN == pos.size();
+    const std::vector<std::string>& kept_headers = kept_all ? pos.headers : kept_headers_own;
+    const ByteVec& kept_codes = kept_all ? pos.codes : kept_codes_own;
+    const std::vector<uint64_t>& kept_off = kept_all ? pos.off : kept_off_own;
     auto em_params = [&](const Motif& m) {
         bamm_em_params p;
         bamm_em_default_params(&p);
@@ -886,6 +894,7 @@ int main(int nargs, char* args[]) {
     // synchronisation), a hundred megabytes of host vectors, then the HIP runtime's own static destructors: 0.1 s of a
     // 0.7 s command that ends anyway.  The process leaves here (no other thread is alive: the side threads were joined
     // where their results were taken); --debug keeps the orderly teardown for leak checkers.
+    if (timing) fprintf(stderr, "[timing-abs] main left at %.4f\n", epoch());
     if (!o.debug) {
         std::cout.flush(); std::cerr.flush();
         fflush(nullptr);

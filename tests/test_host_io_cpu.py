@@ -219,3 +219,30 @@ def test_cli_without_em_and_option_errors(host, tmp_path):
     assert r.returncode == 1 and "No initial model is provided" in r.stderr          # Global.cpp:194-197
     r = subprocess.run([build.CLI, str(out)], capture_output=True, text=True)
     assert r.returncode == 1 and "Arguments are missing" in r.stderr                 # Global.cpp:127-131
+
+
+def test_row_formatter_is_printf_g(host):
+    """The .stats / .pvalues writers print floats as `ostream << float` does (printf %g at precision 6 / 3); the fast
+    formatter must give those bytes on every float: random bit patterns, counts, tenths (FP = in / mFold), unit-interval
+    values, tiny p-values, exact half-way cases, powers of ten, zeros, infinities, NaN, denormals."""
+    host.bh_format_g_check.restype = C.c_uint64
+    host.bh_format_g_check.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(5)
+    sets = {
+        "bits": rng.integers(0, 2 ** 32, 1_000_000, dtype=np.uint64).astype(np.uint32).view(np.float32),
+        "counts": rng.integers(0, 3_000_000, 500_000).astype(np.float32),
+        "tenths": rng.integers(0, 30_000_000, 500_000).astype(np.float32) / np.float32(10),
+        "unit": rng.random(500_000).astype(np.float32),
+        "pvalues": np.exp(-rng.random(500_000) * 60).astype(np.float32),
+        "halves": ((rng.integers(0, 2_000_000, 300_000).astype(np.float64) + 0.5) / 10.0 ** rng.integers(0, 8, 300_000)).astype(np.float32),
+        "pow10": (10.0 ** rng.integers(-20, 20, 20_000)).astype(np.float32),
+        "edge": np.array([0.0, -0.0, 1.0, 9.999995, 9.9999949, 999999.5, 999999.4, 1e6, 1e-5, 9.9999e-5, 1e-4, 0.000123456,
+                          123456.5, 1234565, 0.5, 0.25, np.inf, -np.inf, np.nan, 1e-38, 1e-45, 3.4e38, 1e5, 999999, -2.5, -1e-7],
+                         dtype=np.float32),
+    }
+    for name, x in sets.items():
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        for precision in (6, 3):
+            bits = C.c_uint32(0)
+            bad = host.bh_format_g_check(x.ctypes.data_as(C.c_void_p), len(x), precision, C.byref(bits))
+            assert bad == 0, (name, precision, bad, hex(bits.value))

@@ -53,6 +53,9 @@ for n, s in stages:
 for l in r.stderr.splitlines():
     if l.startswith("[timing-beside]"):
         print("  beside the stages above:", l[len("[timing-beside] "):])
+ab = dict(re.findall(r"\[timing-abs\] main (entered|left) at ([\d.]+)", r.stderr))
+if len(ab) == 2:
+    print("  outside main: %.3f s from the spawn to main, %.3f s from main's last line to the reaped process" % (float(ab["entered"]) - t, t + dt - float(ab["left"])))
 print("  GPU stages (EM runs, fold EMs + scoring) %.3f s of %.3f s in all; the rest is host work" % (gpu, sum(float(s) for _, s in stages)))
 print("\n".join(l for l in r.stdout.splitlines() if "Runtime" in l))
 if r.returncode:
