@@ -909,5 +909,6 @@ int main(int nargs, char* args[]) {
         if (dv.ctx) bamm_ctx_destroy(dv.ctx);
     }
     bamm_packed_free(packed);
+    if (timing) fprintf(stderr, "[timing-abs] teardown done at %.4f\n", epoch());
     return 0;
 }

@@ -16,7 +16,7 @@ extra_dev = []
 for flag in ("--gpus", "--deviceList"):
     if flag in argv:
         i = argv.index(flag); extra_dev += argv[i:i + 2]; del argv[i:i + 2]
-for flag in ("--hostSampler", "--hostPacking"):                # the host flavours of the stages that run on the device by default
+for flag in ("--hostSampler", "--hostPacking", "--debug"):                # the host flavours of the stages that run on the device by default
     if flag in argv:
         argv.remove(flag); extra_dev.append(flag)
 N = int(argv[0]) if len(argv) > 0 else 200000
@@ -54,6 +54,9 @@ for l in r.stderr.splitlines():
     if l.startswith("[timing-beside]"):
         print("  beside the stages above:", l[len("[timing-beside] "):])
 ab = dict(re.findall(r"\[timing-abs\] main (entered|left) at ([\d.]+)", r.stderr))
+td = re.search(r"\[timing-abs\] teardown done at ([\d.]+)", r.stderr)
+if td:
+    print("  --debug: orderly teardown %.3f s, then %.3f s to the reaped process" % (float(td.group(1)) - float(ab["left"]), t + dt - float(td.group(1))))
 if len(ab) == 2:
     print("  outside main: %.3f s from the spawn to main, %.3f s from main's last line to the reaped process" % (float(ab["entered"]) - t, t + dt - float(ab["left"])))
 print("  GPU stages (EM runs, fold EMs + scoring) %.3f s of %.3f s in all; the rest is host work" % (gpu, sum(float(s) for _, s in stages)))
