@@ -1927,23 +1927,22 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     if (int rcc = clean_accumulator(em)) return rcc;          // sums nobody consumed (bamm_em_accumulate without an update, a getR replay)
     const size_t kLds = 160 * 1024;
     const uint32_t W = em->prm.W, Y = em->Y;
-    const size_t wave_bytes = mask_wave_bytes(s->max_len);
     auto round16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t s_bytes = round16((size_t)W * (Y + 1) * sizeof(float));
     // M-step: as many columns per launch as fit next to one wave's arrays.  Sequences whose arrays (10 bytes per
     // position) do not fit beside one column's counts keep them in a global scratch region per wave instead
-    // (~16 000 positions at k = 2): slower, same arithmetic in the same order.
-    if (round16((size_t)Y * 8) > kLds || s->max_len > 65535u) {
-        set_error("bamm_em_mask: %s", round16((size_t)Y * 8) > kLds ? "one column of the count table exceeds the LDS (order > 6)"
-                                                                       : "sequences beyond 65 535 positions (16-bit window lists)");
-        return BAMM_ERR_UNSUPPORTED;
-    }
-    const bool wave_global = wave_bytes + round16((size_t)Y * 8) > kLds;
+    // (~16 000 positions at k = 2; the window lists are 32 bits wide there, so any length goes): slower, same
+    // arithmetic in the same order.  Orders whose count column alone exceeds the LDS (k >= 7) add the listed windows
+    // straight into the pass's accumulator.  The reference has neither limit (EM.cpp:261-503).
+    const bool direct = round16((size_t)Y * 8) > kLds;
+    const bool wave_global = direct || mask_wave_bytes(s->max_len, false) + round16((size_t)Y * 8) > kLds || s->max_len > 65535u;
+    const size_t wave_bytes = mask_wave_bytes(s->max_len, wave_global);
+    if (wave_bytes > 0xffffffffull) { set_error("bamm_em_mask: sequences beyond 2^28 positions"); return BAMM_ERR_UNSUPPORTED; }
     const bool s_in_lds = s_bytes <= 64 * 1024 && (wave_global || s_bytes + wave_bytes <= kLds);
     const size_t e_table = s_in_lds ? s_bytes : 0;
-    uint32_t m_cols = std::min<size_t>(W, (wave_global ? kLds / 2 : std::min(kLds / 2, kLds - wave_bytes)) / ((size_t)Y * 8));
+    uint32_t m_cols = direct ? W : (uint32_t)std::min<size_t>(W, (wave_global ? kLds / 2 : std::min(kLds / 2, kLds - wave_bytes)) / ((size_t)Y * 8));
     m_cols = std::max(1u, m_cols);
-    const size_t m_table = round16((size_t)m_cols * Y * 8);
+    const size_t m_table = direct ? 0 : round16((size_t)m_cols * Y * 8);
     auto waves_for = [&](size_t table) {
         return wave_global ? 4u : (uint32_t)std::max<size_t>(1, std::min<size_t>(4, (kLds - table) / wave_bytes));
     };
@@ -1954,13 +1953,16 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     const uint32_t e_waves = waves_for(e_table), m_waves = waves_for(m_table);
     // 16 waves per CU (as the fused kernel), but no more partial tables than 64 MiB worth
     // (arrays in global memory: at most 2048 waves' worth of them)
-    const uint32_t cus = wave_global ? std::min(64u, (uint32_t)std::max(1, em->ctx->num_cus)) : (uint32_t)std::max(1, em->ctx->num_cus);
+    // ... and no more than 8 GiB of them: a launch has at most cus * 8 blocks of 4 waves
+    const uint32_t cus = wave_global ? (uint32_t)std::max<size_t>(1, std::min<size_t>(std::min(64u, (uint32_t)std::max(1, em->ctx->num_cus)), ((size_t)8 << 30) / (32 * wave_bytes)))
+                                     : (uint32_t)std::max(1, em->ctx->num_cus);
     const uint32_t per_cu = std::max(1u, 16u / std::min(e_waves, m_waves));
-    const uint32_t cap_blocks = (uint32_t)std::max<size_t>(cus, std::min<size_t>((size_t)cus * per_cu, ((size_t)64 << 20) / (em->cells * 8)));
+    const uint32_t cap_blocks = direct ? cus * 8u            // no partial tables at all
+                                       : (uint32_t)std::max<size_t>(cus, std::min<size_t>((size_t)cus * per_cu, ((size_t)64 << 20) / (em->cells * 8)));
     const uint32_t mblocks = std::max(1u, std::min(((uint32_t)s->n + std::min(e_waves, m_waves) - 1) / std::min(e_waves, m_waves), cap_blocks));
     if (!em->d_mask_r) {
         em->mask_blocks = mblocks;
-        if ((rc = dev_alloc(&em->d_mask_partial_n, (size_t)mblocks * em->cells)) ||
+        if ((!direct && (rc = dev_alloc(&em->d_mask_partial_n, (size_t)mblocks * em->cells))) ||
             (rc = dev_alloc(&em->d_mask_partial_stat, (size_t)mblocks * 4)) ||
             (rc = scratch_alloc(em->ctx, &em->d_mask_r, (size_t)s->total_len)) ||
             (rc = dev_alloc(&em->d_mask_bits, (size_t)s->total_len / 32 + 2)) ||
@@ -2030,10 +2032,11 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
         a.table_bytes = (uint32_t)m_table;
         for (uint32_t j0 = 0; j0 < W && !rc; j0 += m_cols) {
             a.j0 = j0; a.j1 = std::min(W, j0 + m_cols);
+            a.acc_direct = direct ? em->d_acc : nullptr;
             rc = launch_mask_m(a, mblocks, m_waves * 64, st);
         }
         if (!rc) rc = record_event(em, false);
-        if (!rc) rc = launch_reduce_partials(em->d_mask_partial_n, em->d_mask_partial_stat, mblocks, W, Y, em->d_acc, st);
+        if (!rc) rc = launch_reduce_partials(direct ? nullptr : em->d_mask_partial_n, em->d_mask_partial_stat, mblocks, W, Y, em->d_acc, st);
         if (!rc) rc = run_allreduce(em);
         if (!rc) rc = run_update(em, false);
         if (!rc) rc = fetch_status(em);

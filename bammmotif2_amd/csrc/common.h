@@ -277,7 +277,7 @@ struct MaskKernelArgs {          // EM::mask kernels (mask.hip)
     SeqView  sv;                 // every resident sequence, exceptions of order K
     uint32_t K, W, Y;
     uint32_t max_len;            // sizes the per-wave LDS arrays
-    uint32_t wave_bytes;         // mask_wave_bytes(max_len)
+    uint32_t wave_bytes;         // mask_wave_bytes(max_len, arrays in the global scratch)
     uint32_t table_bytes;        // block-shared table in front of the per-wave arrays
     const float* v0;             // order-0 conditionals [4][W]
     const float* vbg0;           // order-0 background [4]
@@ -295,11 +295,13 @@ struct MaskKernelArgs {          // EM::mask kernels (mask.hip)
     double*  partial_stat;
     uint32_t j0, j1;             // column range of k_mask_m
     unsigned char* wave_scratch; // nullable: the per-wave arrays live here, one region per wave of the grid, instead of
-                                 // in LDS (sequences whose arrays do not fit beside the block's table)
+                                 // in LDS (sequences whose arrays do not fit beside the block's table); 32-bit lists there
+    long long* acc_direct;       // nullable: k_mask_m adds straight into the pass's accumulator ([y][j] + statistics) instead
+                                 // of a per-block table in LDS (orders whose count column exceeds the LDS)
 };
 
 // launchers (mask.hip)
-size_t mask_wave_bytes(uint32_t max_len);
+size_t mask_wave_bytes(uint32_t max_len, bool wide_lists);   // wide: 32-bit window lists (arrays in the global scratch)
 int launch_mask_init(const MaskKernelArgs& a, bool serial, uint32_t blocks, uint32_t threads, hipStream_t st);
 int launch_mask_hist(const MaskKernelArgs& a, int pass, uint32_t blocks, hipStream_t st);
 int launch_mask_pick(const MaskKernelArgs& a, int pass, float f, hipStream_t st);

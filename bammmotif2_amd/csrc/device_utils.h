@@ -95,16 +95,45 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-by
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
+// -DBAMM_PLAIN_LDS (tools/plain_lds_build.sh; a bisect build, never the shipped one): every hand-issued LDS instruction of
+// the sequence kernels as the plain HIP statement it stands for -- loads the compiler sees, schedules and waits for itself,
+// atomicAdd under an ordinary `if` -- so that a wrong result after a toolchain change can be pinned on (or cleared of) the
+// hand-written part by running the same parity tests on both builds.  Slower (hipcc splits the 128-bit gathers); same results.
+#ifdef BAMM_PLAIN_LDS
+template <class T>
+__device__ __forceinline__ T lds_load(uint32_t byte_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) const T lds_t;
+    return *(lds_t*)(size_t)byte_addr;
+#else
+    return T{};
+#endif
+}
+__device__ __forceinline__ uint32_t plain_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ void plain_lds_add(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    if ((mask >> plain_lane()) & 1ull) atomicAdd((unsigned long long*)(lds_u64*)(size_t)byte_addr, v);
+#endif
+}
+#endif
 __device__ __forceinline__ f32x4 lds_read_b128(uint32_t byte_addr) {
+#ifdef BAMM_PLAIN_LDS
+    return lds_load<f32x4>(byte_addr);
+#else
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(byte_addr));
     return v;
+#endif
 }
-template <int M>
-__device__ __forceinline__ void lds_wait(f32x4 (&v)[M]) {
+// what was read by hand has landed (and no consumer moves above the wait); the plain build's loads are the compiler's to wait for
+template <class T, int M>
+__device__ __forceinline__ void lds_wait(T (&v)[M]) {
+#ifndef BAMM_PLAIN_LDS
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]));
 #pragma unroll
     for (int m = 1; m < M; m++) asm volatile("" : "+v"(v[m]) : "v"(v[0]));
+#endif
 }
 
 // One predicated 64-bit LDS add: exec <- exec & pad & nz (both wave masks in SGPR pairs; the incoming
@@ -113,9 +142,13 @@ __device__ __forceinline__ void lds_wait(f32x4 (&v)[M]) {
 // fire-and-forget (no return): lds_drain() must run before anyone reads the table.
 __device__ __forceinline__ void lds_add_u64_masked(uint32_t byte_addr, unsigned long long v,
                                                    unsigned long long pad_mask, unsigned long long nz_mask) {
+#ifdef BAMM_PLAIN_LDS
+    plain_lds_add(byte_addr, v, pad_mask & nz_mask);
+#else
     unsigned long long saved;
     asm volatile("s_and_b64 %0, %3, %4\n\ts_and_saveexec_b64 %0, %0\n\tds_add_u64 %1, %2\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(byte_addr), "v"(v), "s"(pad_mask), "s"(nz_mask) : "memory", "scc");
+#endif
 }
 __device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // One slot of one column.  The long-sequence classes (M > 16) keep 2*M wave masks, more than the

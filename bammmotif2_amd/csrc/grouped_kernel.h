@@ -95,16 +95,34 @@ __device__ __forceinline__ void static_for(F&& f) {           // f(IntC<0>{}), f
 // forcing exec back to -1, but a divergent or partial-wave caller keeps its masked-off lanes off.
 template <int OFF>
 __device__ __forceinline__ void lds_add_u64_exec(uint32_t byte_addr, unsigned long long v, unsigned long long mask) {
+#ifdef BAMM_PLAIN_LDS
+    plain_lds_add(byte_addr + (uint32_t)OFF, v, mask);
+#else
     unsigned long long saved;
     asm volatile("s_and_saveexec_b64 %0, %3\n\tds_add_u64 %1, %2 offset:%4\n\ts_mov_b64 exec, %0"
                  : "=&s"(saved) : "v"(byte_addr), "v"(v), "s"(mask), "n"(OFF) : "memory", "scc");
+#endif
 }
 
 template <int OFF>
 __device__ __forceinline__ f32x4 lds_read_b128_off(uint32_t byte_addr) {
+#ifdef BAMM_PLAIN_LDS
+    return lds_load<f32x4>(byte_addr + (uint32_t)OFF);
+#else
     f32x4 v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
     return v;
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ float lds_read_b32_off(uint32_t byte_addr) {
+#ifdef BAMM_PLAIN_LDS
+    return lds_load<float>(byte_addr + (uint32_t)OFF);
+#else
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF));
+    return v;
+#endif
 }
 
 template <int M>
@@ -172,10 +190,8 @@ __device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]
 #define BAMM_GRP_SLOT(SL)                                                                       \
         if constexpr (4 * NQ > (SL)) {                                                          \
             float f[M];                                                                         \
-            _Pragma("unroll") for (int m = 0; m < M; m++)                                       \
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(f[m]) : "v"(ra[m]), "n"((SL) * 4));  \
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));                                 \
-            _Pragma("unroll") for (int m = 1; m < M; m++) asm volatile("" : "+v"(f[m]) : "v"(f[0])); \
+            _Pragma("unroll") for (int m = 0; m < M; m++) f[m] = lds_read_b32_off<(SL) * 4>(ra[m]); \
+            lds_wait(f);                                                                        \
             if constexpr ((SL) == 0) {                                                          \
                 _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = f[m];                      \
             } else {                                                                            \
@@ -192,7 +208,7 @@ __device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]
     if constexpr (NQ > (JQ)) {                                                                  \
         f32x4 sv[M];                                                                            \
         _Pragma("unroll") for (int m = 0; m < M; m++) sv[m] = lds_read_b128_off<(JQ) * 16>(ra[m]); \
-        lds_wait<M>(sv);                                                                        \
+        lds_wait(sv);                                                                        \
         float f[M];                                                                             \
         if constexpr ((JQ) == 0) {                                                              \
             _Pragma("unroll") for (int m = 0; m < M; m++) U[m] = sv[m].x;                       \
@@ -534,7 +550,7 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
                         f32x4 sv[M];
 #pragma unroll
                         for (int m = 0; m < M; m++) sv[m] = lds_read_b128(ra[m] + jq * 16u);
-                        lds_wait<M>(sv);
+                        lds_wait(sv);
                         float f[M];
 #pragma unroll
                         for (int m = 0; m < M; m++) f[m] = sv[m].x;

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             for (int m = 0; m < M; m++) sv[m] = lds_read_b128(sa[m]);
 #pragma unroll
             for (int m = 0; m < M; m++) sa[m] += Ys * 16u;
-            lds_wait<M>(sv);
+            lds_wait(sv);
 #pragma unroll
             for (int m = 0; m < M; m++) U[m] = sv[m].x;
             BAMM_SEQ_STEP(y)
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(THREADS) k_em_seq(EmKernelArgs a) {
             for (int m = 0; m < M; m++) sv[m] = lds_read_b128(sa[m]);
 #pragma unroll
             for (int m = 0; m < M; m++) sa[m] += Ys * 16u;
-            lds_wait<M>(sv);
+            lds_wait(sv);
             BAMM_SEQ_STEP(x)
             BAMM_SEQ_STEP(y)
             BAMM_SEQ_STEP(z)

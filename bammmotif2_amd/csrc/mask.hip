@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace bamm {
 namespace {
@@ -55,30 +56,34 @@ __device__ __forceinline__ unsigned long long mask_to_fixed40(float r) {   // as
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// WG: the arrays of a wave in the launch's global scratch (sequences beyond the LDS plan: the reference has no limit,
+// EM.cpp:261-503) -- and there the listed r-indices are 32 bits wide (any length); in LDS they are 16 (<= 65 535 positions)
+template <bool WG>
 struct WaveLds {
+    using lst_t = typename std::conditional<WG, uint32_t, uint16_t>::type;
     uint32_t* y;        // [max_len]  kmer_ mod 4^(K+1) per position
     float* f;           // [max_len]
-    uint16_t* lst;      // [max_len]  listed r-indices, ascending
+    lst_t* lst;         // [max_len]  listed r-indices, ascending
     uint32_t* mb;       // [max_len/32 + 2]  membership words covering this sequence's r slots
 };
 
-__device__ __forceinline__ WaveLds wave_lds(unsigned char* base, const MaskKernelArgs& a, uint32_t wave) {
+template <bool WG>
+__device__ __forceinline__ WaveLds<WG> wave_lds(unsigned char* base, const MaskKernelArgs& a, uint64_t wave) {
     unsigned char* p = base + (size_t)wave * a.wave_bytes;
-    const uint32_t n4 = (a.max_len * 4u + 15u) & ~15u, n2 = (a.max_len * 2u + 15u) & ~15u;
-    WaveLds w;
+    const size_t n4 = ((size_t)a.max_len * 4u + 15u) & ~(size_t)15u, nl = ((size_t)a.max_len * sizeof(typename WaveLds<WG>::lst_t) + 15u) & ~(size_t)15u;
+    WaveLds<WG> w;
     w.y = reinterpret_cast<uint32_t*>(p);
     w.f = reinterpret_cast<float*>(p + n4);
-    w.lst = reinterpret_cast<uint16_t*>(p + 2 * (size_t)n4);
-    w.mb = reinterpret_cast<uint32_t*>(p + 2 * (size_t)n4 + n2);
+    w.lst = reinterpret_cast<typename WaveLds<WG>::lst_t*>(p + 2 * n4);
+    w.mb = reinterpret_cast<uint32_t*>(p + 2 * n4 + nl);
     return w;
 }
 
-// WG: the arrays of wave `wave` of this block in the launch's global scratch (sequences beyond the LDS plan: the
-// reference has no limit, EM.cpp:261-503); else in LDS behind the block's table
+// the arrays of wave `wave` of this block: one region per wave of the grid in the global scratch, or in LDS behind the block's table
 template <bool WG>
-__device__ __forceinline__ WaveLds wave_arrays(unsigned char* lds_base, const MaskKernelArgs& a, uint32_t wave, uint32_t wpb) {
-    if constexpr (WG) return wave_lds(a.wave_scratch, a, blockIdx.x * wpb + wave);
-    else return wave_lds(lds_base, a, wave);
+__device__ __forceinline__ WaveLds<WG> wave_arrays(unsigned char* lds_base, const MaskKernelArgs& a, uint32_t wave, uint32_t wpb) {
+    if constexpr (WG) return wave_lds<true>(a.wave_scratch, a, (uint64_t)blockIdx.x * wpb + wave);
+    else return wave_lds<false>(lds_base, a, wave);
 }
 
 // kmer_[p] mod Y for every position of one sequence (Sequence.cpp:35-41) into LDS
@@ -100,8 +105,9 @@ __device__ __forceinline__ void decode_to_lds(const SeqView& sv, uint32_t seq, u
 }
 
 // the membership words of this sequence's r slots, then the listed r-indices in ascending order
+template <bool WG>
 __device__ __forceinline__ uint32_t load_list(const MaskKernelArgs& a, uint64_t base, uint32_t L, uint32_t LW1, int lane,
-                                              const WaveLds& w) {
+                                              const WaveLds<WG>& w) {
     const uint64_t w0 = base >> 5;
     const uint32_t nw = (uint32_t)(((base + L - 1u) >> 5) - w0) + 1u;
     for (uint32_t i = (uint32_t)lane; i < nw; i += 64u) w.mb[i] = a.bits[w0 + i];
@@ -113,14 +119,15 @@ __device__ __forceinline__ uint32_t load_list(const MaskKernelArgs& a, uint64_t 
         const bool in = ri < LW1 && ((w.mb[(uint32_t)((slot >> 5) - w0)] >> (slot & 31u)) & 1u);
         const unsigned long long bal = __ballot(in);
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (in) w.lst[cnt + before] = (uint16_t)ri;
+        if (in) w.lst[cnt + before] = (typename WaveLds<WG>::lst_t)ri;
         cnt += (uint32_t)__popcll(bal);
     }
     wave_lds_sync();
     return cnt;
 }
 
-__device__ __forceinline__ bool listed(const WaveLds& w, uint64_t base, uint32_t ri) {
+template <bool WG>
+__device__ __forceinline__ bool listed(const WaveLds<WG>& w, uint64_t base, uint32_t ri) {
     const uint64_t slot = base + ri;
     return (w.mb[(uint32_t)((slot >> 5) - (base >> 5))] >> (slot & 31u)) & 1u;
 }
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(256) k_mask_init(MaskKernelArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const WaveLds w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
+    const WaveLds<WG> w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
     float q = *a.q;
     float N1 = 0.0f;                                                  // EM.cpp:507, running over the processed sequences
     for (uint32_t seq = blockIdx.x * wpb + wave; seq < a.sv.count; seq += gridDim.x * wpb) {
@@ -271,7 +278,7 @@ __global__ void __launch_bounds__(256) k_mask_e(MaskKernelArgs a) {
     __shared__ double stat[4][3];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const WaveLds w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
+    const WaveLds<WG> w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
     const float q = *a.q;
     double llh = 0.0, sum_r = 0.0, nseq = 0.0;
     for (uint32_t seq = blockIdx.x * wpb + wave; seq < a.sv.count; seq += gridDim.x * wpb) {
@@ -313,16 +320,21 @@ __global__ void __launch_bounds__(256) k_mask_e(MaskKernelArgs a) {
 }
 
 // ---- EM.cpp:452-461, columns [j0, j1) ---------------------------------------------------------
-template <bool WG>
+// DIRECT: one column of the count table does not fit the LDS (order 7 and up: 4^(K+1) cells of 8 bytes) -- the listed
+// windows' addends go straight into the pass's accumulator (device-scope integer atomics on 65 536+ rows per column:
+// the same sums; contention is what the size of the table makes of it), all W columns in one launch
+template <bool WG, bool DIRECT>
 __global__ void __launch_bounds__(256) k_mask_m(MaskKernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t W = a.W, Y = a.Y, j0 = a.j0, j1 = a.j1;
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(smem);   // [j1-j0][Y]
-    for (uint32_t i = threadIdx.x; i < (j1 - j0) * Y; i += blockDim.x) tab[i] = 0ull;
-    __syncthreads();
+    if constexpr (!DIRECT) {
+        for (uint32_t i = threadIdx.x; i < (j1 - j0) * Y; i += blockDim.x) tab[i] = 0ull;
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const WaveLds w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
+    const WaveLds<WG> w = wave_arrays<WG>(smem + a.table_bytes, a, wave, wpb);
     for (uint32_t seq = blockIdx.x * wpb + wave; seq < a.sv.count; seq += gridDim.x * wpb) {
         if (a.sv.mask && !a.sv.mask[seq]) continue;
         const uint32_t L = a.sv.len[seq], LW1 = L - W + 1u;
@@ -334,21 +346,27 @@ __global__ void __launch_bounds__(256) k_mask_m(MaskKernelArgs a) {
             const unsigned long long fx = mask_to_fixed40(a.r[base + ri] * a.fix_scale);
             if (fx == 0ull) continue;
             const uint32_t start = L - W - ri;
-            for (uint32_t j = j0; j < j1; j++) atomicAdd(&tab[(j - j0) * Y + w.y[start + j]], fx);
+            if constexpr (DIRECT) {
+                for (uint32_t j = j0; j < j1; j++) acc_add(a.acc_direct + (size_t)w.y[start + j] * W + j, (long long)fx);   // ABI layout [y][j]
+            } else {
+                for (uint32_t j = j0; j < j1; j++) atomicAdd(&tab[(j - j0) * Y + w.y[start + j]], fx);
+            }
         }
         wave_lds_sync();
     }
-    __syncthreads();
-    unsigned long long* out = a.partial_n + (size_t)blockIdx.x * W * Y;      // [j][y], as k_reduce_partials reads it
-    for (uint32_t i = threadIdx.x; i < (j1 - j0) * Y; i += blockDim.x) out[(size_t)j0 * Y + i] = tab[i];
+    if constexpr (!DIRECT) {
+        __syncthreads();
+        unsigned long long* out = a.partial_n + (size_t)blockIdx.x * W * Y;  // [j][y], as k_reduce_partials reads it
+        for (uint32_t i = threadIdx.x; i < (j1 - j0) * Y; i += blockDim.x) out[(size_t)j0 * Y + i] = tab[i];
+    }
 }
 
 }  // namespace
 
-size_t mask_wave_bytes(uint32_t max_len) {
-    const size_t n4 = ((size_t)max_len * 4 + 15) & ~(size_t)15, n2 = ((size_t)max_len * 2 + 15) & ~(size_t)15;
+size_t mask_wave_bytes(uint32_t max_len, bool wide_lists) {
+    const size_t n4 = ((size_t)max_len * 4 + 15) & ~(size_t)15, nl = ((size_t)max_len * (wide_lists ? 4 : 2) + 15) & ~(size_t)15;
     const size_t nb = (((size_t)max_len / 32 + 2) * 4 + 15) & ~(size_t)15;
-    return 2 * n4 + n2 + nb;
+    return 2 * n4 + nl + nb;
 }
 
 #define BAMM_MASK_LAUNCH(KERNEL, LDS, ...)                                                          \
@@ -408,8 +426,13 @@ int launch_mask_e(const MaskKernelArgs& a, bool s_in_lds, uint32_t blocks, uint3
 
 int launch_mask_m(const MaskKernelArgs& a, uint32_t blocks, uint32_t threads, hipStream_t st) {
     const size_t lds = mask_lds(a, threads);
-    if (a.wave_scratch != nullptr) BAMM_MASK_LAUNCH(k_mask_m<true>, lds, a);
-    else BAMM_MASK_LAUNCH(k_mask_m<false>, lds, a);
+    if (a.acc_direct != nullptr) {
+        if (a.wave_scratch != nullptr) BAMM_MASK_LAUNCH((k_mask_m<true, true>), lds, a);
+        else BAMM_MASK_LAUNCH((k_mask_m<false, true>), lds, a);
+    } else {
+        if (a.wave_scratch != nullptr) BAMM_MASK_LAUNCH((k_mask_m<true, false>), lds, a);
+        else BAMM_MASK_LAUNCH((k_mask_m<false, false>), lds, a);
+    }
     return BAMM_OK;
 }
 

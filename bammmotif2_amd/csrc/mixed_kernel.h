@@ -296,13 +296,16 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             float2 pr[M];
 #pragma unroll
             for (int m = 0; m < M; m++) {
+#ifdef BAMM_PLAIN_LDS
+                if constexpr (A == 2) pr[m] = lds_load<float2>(sg6_base + row6[m] * 8u);
+                else pr[m].x = lds_load<float>(sg6_base + row6[m] * 4u);
+#else
                 if constexpr (A == 2) asm volatile("ds_read_b64 %0, %1" : "=v"(pr[m]) : "v"(sg6_base + row6[m] * 8u));
                 else asm volatile("ds_read_b32 %0, %1" : "=v"(pr[m].x) : "v"(sg6_base + row6[m] * 4u));
+#endif
             }
             grp_chain<M, 3, NQ>(ra, U);                      // waits with lgkmcnt(0): the reads above have landed as well
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pr[0]));
-#pragma unroll
-            for (int m = 1; m < M; m++) asm volatile("" : "+v"(pr[m]) : "v"(pr[0]));
+            lds_wait(pr);
             float w0[M];
 #pragma unroll
             for (int m = 0; m < M; m++) w0[m] = pr[m].x;

@@ -713,16 +713,6 @@ int main(int nargs, char* args[]) {
                 if (bamm_em_create(devs[d].ctx, devs[d].shard, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &ems[d])) die_abi("EM");
                 if (devs[d].comm && bamm_em_set_comm(ems[d], devs[d].comm)) die_abi("EM communicator");
             }
-            // every refusal that depends on the data is decided from GLOBAL quantities before any collective starts
-            // (a rank that refused alone would leave its peers in ncclAllReduce): EM::mask lists a sequence's windows
-            // as 16-bit indices and needs one count column of 4^(K+1) u64 cells in LDS (bamm_em_mask, csrc/abi.cpp)
-            if (o.advanceEM && sharded) {
-                uint32_t longest = 0;
-                for (uint64_t n = 0; n < (uint64_t)kept_len.size(); n++) longest = std::max(longest, kept_len[n]);
-                if (longest > 65535u) die("Error: --advanceEM lists a sequence's windows as 16-bit indices (65 535 positions at most); "
-                                          "the longest sequence here has " + std::to_string(longest) + ".");
-                if ((size_t(1) << (2 * (motif.K + 1))) * 8 > 160u * 1024u) die("Error: --advanceEM needs one column of the count table in LDS (order 6 at most).");
-            }
             // one std::thread per rank, not an OpenMP team (which may come back smaller than asked for and leave ranks
             // out of the collective); a rank that still fails aborts every communicator so that its peers return
             auto run_rank = [&](size_t d) {

@@ -150,9 +150,9 @@ int  bamm_ctx_set_tuning(bamm_ctx* ctx, const char* key, int value);
  * Any length: sequences up to BAMM_MAX_SEQ_POSITIONS go through the register-resident kernels, longer
  * ones through a window-by-window path with identical results (EM passes, getR, the scorer);
  * bamm_seed_from_pwm and bamm_em_mask keep per-wave arrays over one sequence: in LDS up to about
- * 10 000 / 16 000 positions, in a global scratch region per wave beyond (same arithmetic, slower);
- * bamm_em_mask refuses sequences beyond 65 535 positions (16-bit window lists) and orders > 6 with
- * BAMM_ERR_UNSUPPORTED.                                                                          */
+ * 10 000 / 16 000 positions, in a global scratch region per wave beyond (same arithmetic, slower;
+ * bamm_em_mask's window lists are 32 bits wide there, and from order 7 on its counts go straight into
+ * the accumulator: no limit on length or order short of BAMM_MAX_ORDER, as in the reference).     */
 int  bamm_seqs_upload(bamm_ctx* ctx, const bamm_packed* p, uint64_t begin, uint64_t end,
                       bamm_seqs** out);
 int  bamm_seqs_destroy(bamm_seqs* s);

@@ -19,7 +19,13 @@ CASES = [d for d in SMALL_CASES if d["W"] >= 2] + [
     dict(name="m_long", N=6, L0=6100, W=12, K=2, ss=True, ragged=2000, n_frac=0.0005),      # M = 80..128
     # beyond the per-wave LDS arrays (~16 000 positions at k = 2): the arrays live in a global scratch region per wave
     dict(name="m_xlong", N=5, L0=14000, W=10, K=2, ragged=9000, n_frac=0.0002),
-    dict(name="m_xlong_k4", N=4, L0=30000, W=8, K=4, ss=True, ragged=12000)]
+    dict(name="m_xlong_k4", N=4, L0=30000, W=8, K=4, ss=True, ragged=12000),
+    # beyond 65 535 positions (both strands of 40 000 bases): the window lists in the scratch region are 32 bits wide
+    dict(name="m_wide_lists", N=3, L0=40000, W=10, K=1, ragged=3000, n_frac=0.0002),
+    # order 7: one column of the count table (4^8 cells of 8 bytes) exceeds the LDS -- the listed windows' addends go
+    # straight into the accumulator
+    dict(name="m_k7", N=60, L0=260, W=6, K=7, ragged=60, n_frac=0.002),
+    dict(name="m_k8_ss", N=30, L0=400, W=5, K=8, ss=True)]
 
 
 @pytest.mark.parametrize("oq", [False, True], ids=["fixq", "optq"])
@@ -35,16 +41,21 @@ def test_mask_three_passes_match_oracle(spec, f, oq, gpu_ctx, orc):
     assert em.last_mask["listed"] == res["listed"]                                   # EM.cpp:345-356
     assert np.float32(em.getQ()) == np.float32(res["q"])                             # EM.cpp:321 chain
     name, fl = f"mask {c.name} f={f} optQ={int(oq)}", "mask kernels"
-    margins.check(name, fl, "n pass 3", em.getCounts(), res["n"], 1e-5, 1e-7, against="fp32 restatement")
-    margins.check(name, fl, "v pass 3", em.getV(), res["v"], 1e-5, 1e-9, against="fp32 restatement")
+    # flat 1e-5; the restatement's normaliser is a sequential fp32 sum over a sequence's listed windows (EM.cpp:417), whose
+    # own rounding grows with their number: beyond 4 000 listed windows per sequence (m_wide_lists at f = 0.2: 16 000)
+    # the bar follows sqrt(count)
+    flat = 1e-5 * max(1.0, float(np.sqrt(res["listed"] / c.N / 4000.0)))
+    margins.check(name, fl, "n pass 3", em.getCounts(), res["n"], flat, 1e-7, against="fp32 restatement")
+    margins.check(name, fl, "v pass 3", em.getV(), res["v"], flat, 1e-9, against="fp32 restatement")
     llh, vd, _ = em.trace()
     # the reference's llh is a sequential fp32 sum over the sequences: ~1e-7 per term
     np.testing.assert_allclose(llh, res["trace_llh"], rtol=1e-5, atol=max(1e-5, 3e-7 * c.N))
-    np.testing.assert_allclose(vd, res["trace_vdiff"], rtol=1e-3, atol=1e-6)
+    # v_diff is the reference's sequential fp32 sum of |dv| over the whole model (EM.cpp:102-108): 1.7 M terms at order 8
+    np.testing.assert_allclose(vd, res["trace_vdiff"], rtol=1e-3 * max(1.0, float(np.sqrt(c.v0.size / 1e5))), atol=1e-6)
     r = em.getR()
     # incl. the r_[n][0] decay (:421).  Flat 1e-5 on n, v and r: the observed margins (profiles/r04_parity_margins.txt)
     # stay below 5e-6 on every case
-    margins.check(name, fl, "r pass 3", r, res["r"], 1e-5, 1e-12, against="fp32 restatement")
+    margins.check(name, fl, "r pass 3", r, res["r"], flat, 1e-12, against="fp32 restatement")
     assert np.array_equal(r == 0, res["r"] == 0)
     em.close(); ss.close()
 

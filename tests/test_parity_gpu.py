@@ -473,18 +473,20 @@ def test_long_sequences_match_exact_arithmetic(spec, gpu_ctx, orc):
 
 
 def test_sequences_beyond_the_length_classes(gpu_ctx, orc):
-    """More than 8192 positions: accepted (csrc/long_seq.hip, tests/test_long_gpu.py checks the numbers).  EM::mask
-    lists a sequence's windows as 16-bit indices and says so beyond 65 535 positions instead of computing something
-    else; PWM seeding has no limit (its per-wave arrays move to global scratch, tests/test_seed_gpu.py)."""
+    """More than 8192 positions: accepted (csrc/long_seq.hip, tests/test_long_gpu.py checks the numbers).  EM::mask and
+    PWM seeding have no limit either: their per-wave arrays move to a global scratch region (mask: with 32-bit window
+    lists there; tests/test_mask_gpu.py::m_wide_lists and tests/test_seed_gpu.py check the numbers)."""
     c = Case("toolong", N=2, L0=70000, W=8, K=1, ss=True)
     _, kmer, off, vbg = c.encode(orc)
     ss = bm.SeqSet(gpu_ctx, bm.PackedSeqs.from_kmers(kmer, off))
     assert ss.info()["max_len"] == 70000
     em = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q)
     assert em.plan()[2] == 1                                  # one launch: the long bucket
-    with pytest.raises(bm.abi.BammError) as e:
-        em.mask(0.1)                                          # EM::mask's 16-bit window lists
-    assert e.value.code == bm.abi.ERR_UNSUPPORTED
+    res = orc.mask(kmer, off, c.K, c.W, c.bg_order, vbg, c.A, c.v0, c.q, f=0.1, epsilon=0.0, max_iter=1)
+    em_m = bm.EM(gpu_ctx, ss, c.K, c.W, vbg, c.A, c.v0, c.q, epsilon=0.0, max_iterations=1)
+    em_m.mask(0.1)                                            # 70 000 positions: beyond 16-bit window indices
+    assert np.float32(em_m.last_mask["cutoff"]) == np.float32(res["cutoff"]) and em_m.last_mask["listed"] == res["listed"]
+    em_m.close()
     counts, z = bm.seed_from_pwm(gpu_ctx, ss, c.K, c.W, np.ones(4 * c.W, np.float32), 0.3, np.full(c.N, 0.85))
     LW1 = 70000 - c.W + 1                                     # flat odds: 0.7 on "no motif", 0.3 / LW1 per window
     assert np.all(np.abs(z.astype(np.int64) - LW1 // 2) < LW1 // 100)
