@@ -330,6 +330,10 @@ struct bamm_em {
     uint32_t events_used = 0;
     uint32_t timing_every = 8, pass_no = 0;     // bamm_em_set_kernel_timing
     bool timing_now = false;
+    // timing_every == BAMM_TIMING_WHOLE_CALL: ONE pair of events around all the passes of a call
+    bool region_open = false;
+    uint32_t region_passes = 0;
+    std::vector<uint32_t> event_passes;          // passes between the two events of pair i (1 in the per-pass modes)
     // EM::mask state (allocated on first use)
     uint64_t n_active = 0;                      // sequences the handle trains on (mask applied)
     float* d_mask_r = nullptr;                  // responsibilities in the reference layout
@@ -507,28 +511,58 @@ int use_device(const bamm_ctx* c) {
     return BAMM_OK;
 }
 
-// An event pair costs ~6 us of stream time per pass on gfx950 (4 % of a 125k-sequence iteration):
-// only every `timing_every`-th pass of a call is bracketed.
+// An event pair costs 7-8 us of stream time per pass on gfx950 (0.9 % of a 1M-sequence iteration, 6.5 % of a 125k-sequence
+// one: profiles/r04_timing_every_cost.txt).  Three ways: every `timing_every`-th pass of a call bracketed; none; or
+// (BAMM_TIMING_WHOLE_CALL) one pair around ALL passes of a call -- every pass covered, nothing between two passes, the
+// launch gaps inside the interval.
+static int event_pair(bamm_em* em) {
+    if (em->events_used == em->events.size()) {
+        hipEvent_t a, b;
+        BAMM_HIP(hipEventCreate(&a));
+        BAMM_HIP(hipEventCreate(&b));
+        em->events.emplace_back(a, b);
+        em->event_passes.push_back(1u);
+    }
+    return BAMM_OK;
+}
 int record_event(bamm_em* em, bool start) {
+    if (em->timing_every == BAMM_TIMING_WHOLE_CALL) {
+        if (!start) return BAMM_OK;
+        em->pass_no++;
+        if (!em->region_open) {
+            if (int rc = event_pair(em)) return rc;
+            BAMM_HIP(hipEventRecord(em->events[em->events_used].first, em->ctx->stream));
+            em->region_open = true;
+            em->region_passes = 0;
+        }
+        em->region_passes++;
+        return BAMM_OK;
+    }
     if (start) {
         em->timing_now = em->timing_every != 0 && em->pass_no % em->timing_every == 0;
         em->pass_no++;
     }
     if (!em->timing_now) return BAMM_OK;
     if (start) {
-        if (em->events_used == em->events.size()) {
-            hipEvent_t a, b;
-            BAMM_HIP(hipEventCreate(&a));
-            BAMM_HIP(hipEventCreate(&b));
-            em->events.emplace_back(a, b);
-        }
+        if (int rc = event_pair(em)) return rc;
         BAMM_HIP(hipEventRecord(em->events[em->events_used].first, em->ctx->stream));
     } else {
         BAMM_HIP(hipEventRecord(em->events[em->events_used].second, em->ctx->stream));
+        em->event_passes[em->events_used] = 1u;
         em->events_used++;
     }
     return BAMM_OK;
 }
+// the second event of a whole-call interval: behind the last pass's kernels
+int close_timed_region(bamm_em* em) {
+    if (!em->region_open) return BAMM_OK;
+    em->region_open = false;
+    BAMM_HIP(hipEventRecord(em->events[em->events_used].second, em->ctx->stream));
+    em->event_passes[em->events_used] = em->region_passes;
+    em->events_used++;
+    return BAMM_OK;
+}
+struct TimedRegionCloser { bamm_em* em; ~TimedRegionCloser() { (void)close_timed_region(em); } };
 
 // one bucket through the fused kernel of its flavour (grouped columns or one column at a time)
 int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKernelArgs& a, uint32_t threads,
@@ -1805,12 +1839,14 @@ int bamm_em_update(bamm_em* em) {
 int bamm_em_iterate(bamm_em* em, uint32_t n) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
     if (int vrc = verify_comm(em)) return vrc;
-    em->events_used = 0; em->pass_no = 0;
+    em->events_used = 0; em->pass_no = 0; em->region_open = false;
+    TimedRegionCloser closer{em};                            // (an error return)
     // fusable handles: the update of pass i runs in the prologue of pass i+1's first kernel (one launch and one
     // collective per iteration); the last pass's update is a k_update launch, so the handle is in the same state
     // at every API boundary whichever way its updates ran
     for (uint32_t i = 0; i < n; i++) {
         int rc = run_accumulate(em, true, false, false, (em->fusable && i > 0u) ? (int)(i - 1u < 5u) : -1);
+        if (!rc && i + 1u == n) rc = close_timed_region(em); // a whole-call interval ends behind the last pass's sequence kernel
         if (!rc) rc = run_allreduce(em);
         if (!rc && (!em->fusable || i + 1u == n)) rc = run_update(em, i < 5u);
         if (rc) { em->acc_dirty = true; return rc; }
@@ -1821,7 +1857,8 @@ int bamm_em_iterate(bamm_em* em, uint32_t n) {
 int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
     if (int vrc = verify_comm(em)) return vrc;
-    em->events_used = 0; em->pass_no = 0;
+    em->events_used = 0; em->pass_no = 0; em->region_open = false;
+    TimedRegionCloser closer{em};
     if (iterations) *iterations = 0;
     const uint32_t max_it = em->prm.max_iterations;
     if (max_it == 0) return BAMM_OK;
@@ -2017,7 +2054,8 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     // EM over the listed windows (EM.cpp:373-494)
     const int32_t oq = em->prm.optimize_q;
     em->prm.optimize_q = 0;                                  // q is not touched inside this loop
-    em->events_used = 0; em->pass_no = 0;
+    em->events_used = 0; em->pass_no = 0; em->region_open = false;
+    TimedRegionCloser closer{em};
     bool iterate = true;
     uint32_t iteration = 0;
     float llh = em->llh_prev;
@@ -2212,15 +2250,18 @@ int bamm_em_set_kernel_timing(bamm_em* em, uint32_t every) {
 
 int bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches) {
     if (!em || !total_ms || !launches) { set_error("bad argument"); return BAMM_ERR_ARG; }
+    if (int rc = close_timed_region(em)) return rc;           // hand-driven passes (bamm_em_accumulate) in whole-call mode
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
     float acc = 0.0f;
+    uint32_t passes = 0;
     for (uint32_t i = 0; i < em->events_used; i++) {
         float ms = 0.0f;
         BAMM_HIP(hipEventElapsedTime(&ms, em->events[i].first, em->events[i].second));
         acc += ms;
+        passes += em->event_passes[i];
     }
     *total_ms = acc;
-    *launches = em->events_used;
+    *launches = passes;
     return BAMM_OK;
 }
 

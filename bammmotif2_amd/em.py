@@ -438,9 +438,12 @@ class EM:
         m = min(int(n.value), cap)
         return llh[:m].copy(), vd[:m].copy(), q[:m].copy()
 
+    TIMING_WHOLE_CALL = 0xFFFFFFFF                           # BAMM_TIMING_WHOLE_CALL
+
     def set_kernel_timing(self, every: int):
-        """Time passes 0, every, 2*every, ... of each call with HIP events (0 = none, 1 = all)."""
-        check(self.lib.bamm_em_set_kernel_timing(self.h, every))
+        """Time passes 0, every, 2*every, ... of each call with a pair of HIP events each (0 = none, 1 = all; a pair costs
+        7-8 us of stream time); -1 / TIMING_WHOLE_CALL: one pair around all passes of a call (gaps included, no cost per pass)."""
+        check(self.lib.bamm_em_set_kernel_timing(self.h, self.TIMING_WHOLE_CALL if every < 0 else every))
 
     def kernel_time(self):
         ms, n = C.c_float(), C.c_uint32()

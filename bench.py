@@ -73,16 +73,21 @@ def parse():
                     help="in-process form only: --gpus N ranks as N contexts on device 0 with the host-staged sum of "
                          "bamm_comm_init_local instead of RCCL (self-test of the N>1 logic on a 1-GPU box; never "
                          "used for reported numbers)")
-    ap.add_argument("--timing-every", type=int, default=1,
-                    help="HIP events around every n-th pass of the timed call (1 = every pass: `avg_kernel_ms` then covers the "
-                         "whole timed region and cannot exceed `ms_per_step`; a pair takes a few us of stream time)")
+    ap.add_argument("--timing-every", type=int, default=None,
+                    help="HIP events of the timed call: -1 = ONE pair around all its passes (every pass covered, launch gaps "
+                         "included, nothing added between passes: the default on 1 GPU); n >= 1 = a pair around every n-th pass "
+                         "(a pair takes 7-8 us of stream time, profiles/r04_timing_every_cost.txt; 8 is the default with "
+                         "N > 1, where the interval of -1 would include the collective); 0 = none")
     ap.add_argument("--allreduce-iters", type=int, default=200, help="N > 1: bare all-reduces of the accumulator timed for `attribution`")
     ap.add_argument("--no-fused-update", action="store_true",
                     help="a k_update launch after every pass instead of the update fused into the next pass's kernel")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo stages the fused buffer through the host: lets 2 ranks share ONE GPU (self-test of "
                          "the N>1 logic on a 1-GPU box; never used for reported numbers)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.timing_every is None:
+        args.timing_every = -1 if args.gpus <= 1 else 8
+    return args
 
 
 def usable_cpus():
@@ -291,6 +296,12 @@ def report(args, wl, world, dt, kernel_ms, launches, local_positions, local_wind
                      "algorithmic_achieved": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": pmc_src,
                      "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
+                     "avg_kernel_ms_is": ("one pair of HIP events around ALL passes of the timed call, divided by their number: every "
+                                          "pass covered, the launch gaps between passes included (<= ms_per_step by construction)"
+                                          if args.timing_every < 0 else
+                                          "no pass timed" if args.timing_every == 0 else
+                                          f"mean over every {args.timing_every}-th pass of the timed call, a pair of HIP events around each "
+                                          "(7-8 us of stream time per pair)"),
                      "algorithmic_bytes_per_launch": alg_bytes,
                      "algorithmic_bytes_rule": ("0.5 B/position + 8 B/window (sequence read by the E and the M pass, "
                                                 "r written and read once as f32)" if sliced else
@@ -342,7 +353,8 @@ def attribution(step_us, kernel_us, allreduce_us, args):
             "kernel_us_per_rank": list(kernel_us), "allreduce_us_per_rank": list(allreduce_us),
             "allreduce_is": f"{args.allreduce_iters} back-to-back all-reduces of the accumulator on the kernels' stream, HIP events "
                             "around the loop (bamm_comm_time_allreduce); inside an iteration the collective also waits for the slowest rank's kernel",
-            "kernel_is": "HIP events around the sequence kernel(s) of every pass of the timed call (the fused model update is its prologue)"}
+            "kernel_is": (f"HIP events around the sequence kernel(s) of every {args.timing_every}-th pass of the timed call" if args.timing_every > 0 else
+                          "one HIP event pair around all passes of the timed call (includes the collective)") + " (the fused model update is its prologue)"}
 
 
 def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_max):
@@ -648,8 +660,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events around the sequence kernel(s) of every pass of the timed call (--timing-every 1): the kernel time covers
-    # the whole timed region, so its average cannot exceed ms_per_step
+    # one HIP event pair around all passes of the timed call (1 GPU), or a pair around every 8th pass (N > 1): --timing-every
     em.set_kernel_timing(args.timing_every)
     with torch.cuda.stream(tstream):       # the context's stream is torch's current one for the callback
         em.iterate(args.warmup)

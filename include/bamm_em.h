@@ -304,7 +304,11 @@ int  bamm_em_get_trace(bamm_em* em, float* llh, float* v_diff, float* q, uint32_
 /* device time of the sequence kernel over the last iterate()/optimize() call (HIP events on
  * the context's stream): total milliseconds over the timed passes and their number.  Passes
  * 0, every, 2*every, ... of a call are timed (default every = 8; 1 = all, 0 = none): an event
- * pair takes ~6 us of stream time, which a short iteration would notice.                     */
+ * pair takes 7-8 us of stream time, which a short iteration notices.  BAMM_TIMING_WHOLE_CALL:
+ * one pair around ALL passes of the call (first event in front of the first pass's kernel, second
+ * behind the last pass's): every pass covered at no cost per pass; the interval includes the
+ * launch gaps and whatever runs between two passes (a collective), `launches` = the passes in it. */
+#define BAMM_TIMING_WHOLE_CALL 0xffffffffu
 int  bamm_em_kernel_time(bamm_em* em, float* total_ms, uint32_t* launches);
 int  bamm_em_set_kernel_timing(bamm_em* em, uint32_t every);
 /* how one pass is laid out: sequences that go through the grouped-column kernel (grouped.hip)
