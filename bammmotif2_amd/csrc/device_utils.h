@@ -217,9 +217,15 @@ __device__ __forceinline__ void decode_positions(const SeqView& sv, uint32_t seq
     const uint64_t e0 = sv.exc_off[seq], e1 = sv.exc_off[seq + 1];
     for (uint64_t e = e0; e < e1; e++) {
         const uint2 x = sv.exc[e];
-        const int mm = (int)x.x - (int)p0;
+        if constexpr (M >= 10 && M <= 32) {                  // one indexed register write in the owning lane (see decode_raw)
+            const uint32_t pos = __builtin_amdgcn_readfirstlane(x.x), val = __builtin_amdgcn_readfirstlane(x.y);
+            const uint32_t owner = pos / (uint32_t)M, slot = pos % (uint32_t)M;
+            if ((uint32_t)lane == owner) y[slot] = val;
+        } else {
+            const int mm = (int)x.x - (int)p0;
 #pragma unroll
-        for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+            for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+        }
     }
 #pragma unroll
     for (int m = 0; m < M; m++) y[m] = (p0 + m < limit) ? y[m] : Y;
@@ -282,18 +288,32 @@ __device__ __forceinline__ void decode_raw(const RawSeq<M>& r, const SeqView& sv
         const uint32_t sh = 30u - 2u * (p & 15u);
         y[m] = __builtin_amdgcn_alignbit(hi, lo, sh) & (Y - 1u);
     }
-    // N exceptions (Sequence.cpp:38): the ones that came with the sequence, then whatever lies beyond them
+    // N exceptions (Sequence.cpp:38): the ones that came with the sequence, then whatever lies beyond them.  An exception
+    // is the same (position, value) in every lane: position and value go to SGPRs, the owning lane is position / M and the
+    // slot position mod M is wave-uniform, so the patch is ONE indexed register write under the owner's exec mask
+    // (s_set_gpr_idx_on + v_mov) behind a scalar branch -- not a compare and a select per slot (32 VALU instructions and 16
+    // wait states per exception, absent ones included: a sixth of the E pass's VALU work at k = 4).
+    // (10 to 32 positions per lane: hipcc indexes register arrays of up to 32 dwords, a longer one would move to scratch
+    // memory; below 10 the selects are the cheaper of the two -- k = 5, W = 12 at 7 per lane: 1.645 against 1.619 ms)
+    auto patch = [&](uint32_t pos_v, uint32_t val_v) {
+        if constexpr (M >= 10 && M <= 32) {
+            const uint32_t pos = __builtin_amdgcn_readfirstlane(pos_v);
+            if (pos != 0xffffffffu) {
+                const uint32_t owner = pos / (uint32_t)M, slot = pos % (uint32_t)M;
+                const uint32_t val = __builtin_amdgcn_readfirstlane(val_v);
+                if ((uint32_t)lane == owner) y[slot] = val;
+            }
+        } else {
+            const uint32_t mm = pos_v - p0;                  // 0xffffffff - p0 never lands in [0, M): lane * M <= 8128
 #pragma unroll
-    for (int i = 0; i < kRawExc; i++) {
-        const uint32_t mm = r.ex[i].x - p0;                  // 0xffffffff - p0 never lands in [0, M): lane * M <= 8128
+            for (int m = 0; m < M; m++) y[m] = (mm == (uint32_t)m) ? val_v : y[m];
+        }
+    };
 #pragma unroll
-        for (int m = 0; m < M; m++) y[m] = (mm == (uint32_t)m) ? r.ex[i].y : y[m];
-    }
+    for (int i = 0; i < kRawExc; i++) patch(r.ex[i].x, r.ex[i].y);
     for (uint64_t e = r.e0 + (uint64_t)kRawExc; e < r.e1; e++) {
         const uint2 x = sv.exc[e];
-        const int mm = (int)x.x - (int)p0;
-#pragma unroll
-        for (int m = 0; m < M; m++) y[m] = (mm == m) ? x.y : y[m];
+        patch(x.x, x.y);
     }
 #pragma unroll
     for (int m = 0; m < M; m++) y[m] = (p0 + m < limit) ? y[m] : Y;
