@@ -366,9 +366,8 @@ int main(int nargs, char* args[]) {
         if (bamm_pack_codes_seeded(pos.codes.data(), pos.off.data(), pos.size(), o.ss ? 1 : 0, 42u, &packed)) die_abi("packing sequences");
         stage("encode + 2-bit pack (Sequence.cpp incl. rand() protocol)");
     }
-    // records beyond 8192 positions leave the register-resident kernels for the window-by-window path
-    // (csrc/long_seq.hip); initFromPWM's pass over such a record runs on the host
-    if (packed->max_len > BAMM_MAX_SEQ_POSITIONS) o.hostSeeding = true;
+    // (records beyond 8192 positions leave the register-resident kernels for the window-by-window path, csrc/long_seq.hip;
+    // initFromPWM's pass and EM::mask keep their per-wave arrays in a global scratch region there: no limit on the length)
 
     if (o.verbose) std::cout << std::endl << "************************" << std::endl << "*   Background Model   *" << std::endl << "************************" << std::endl;
     BgModel bg;

@@ -304,3 +304,38 @@ def test_cli_device_sampler_and_host_sampler_write_the_same_files(flags, tmp_pat
     assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 4
     for name in outs[0]:
         assert outs[0][name] == outs[1][name], name
+
+
+def test_cli_long_records(tmp_path, gpu_ctx):
+    """Records beyond 8192 positions (both strands of 4 100+ bases) and beyond 65 535 (33 000+ bases): the window-by-window
+    EM path, initFromPWM's pass with its per-wave arrays in the global scratch region (device seeding == --hostSeeding,
+    byte for byte) and --advanceEM (EM::mask, 32-bit window lists there) run through the command line."""
+    build.build_host()
+    import random
+    rnd = random.Random(11)
+    fa = tmp_path / "long.fasta"
+    with open(fa, "w") as f:
+        for i, L in enumerate([300, 5000, 9000, 120, 34000, 2500, 800, 12000, 60, 450]):
+            s = "".join(rnd.choice("ACGT") for _ in range(L))
+            if i % 3 == 0:
+                k = rnd.randint(5, L - 5)
+                s = s[:k] + "N" + s[k + 1:]
+            f.write(f">rec{i}\n")
+            for a in range(0, L, 80):
+                f.write(s[a:a + 80] + "\n")
+    outs = []
+    for extra in ([], ["--hostSeeding"]):
+        out = tmp_path / ("dev" if not extra else "host")
+        r = subprocess.run([build.CLI, str(out), str(fa), "--PWMFile", MEME, "--EM", "-k", "1", "--maxPWM", "1", "--maxEMIterations", "4",
+                            "--saveBaMMs", "--saveInitialBaMMs"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+        outs.append({p.name: p.read_bytes() for p in sorted(out.iterdir())})
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 4
+    for name in outs[0]:
+        assert outs[0][name] == outs[1][name], name
+    out = tmp_path / "adv"
+    r = subprocess.run([build.CLI, str(out), str(fa), "--PWMFile", MEME, "--EM", "-k", "1", "--maxPWM", "1", "--maxEMIterations", "3",
+                        "--advanceEM", "--verbose"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    assert "3th iteration" in r.stdout or "2th iteration" in r.stdout
+    assert any(p.name.endswith(".ihbcp") for p in out.iterdir())
