@@ -1249,6 +1249,15 @@ size_t m_list_lds_bytes(uint32_t cols, uint32_t Y, uint32_t logC, int M, uint32_
 }
 
 int launch_m_list(int mclass, const EmKernelArgs& a, uint32_t j0, uint32_t j1, uint32_t blocks, uint32_t threads, hipStream_t st) {
+    // 16 positions per lane (config 4): the walk needs far fewer registers than the E pass the class's block size was chosen
+    // for -- 16 waves per block where their copies of the decoded sequence still fit beside the count slice
+    if (kMClasses[mclass] == 16 && threads == 768u && j1 > j0 && m_list_lds_bytes(j1 - j0, a.Y, a.logC, 16, 16u) <= 160 * 1024) {
+        const size_t lds16 = m_list_lds_bytes(j1 - j0, a.Y, a.logC, 16, 16u);
+        if (int rc = allow_lds(reinterpret_cast<const void*>(&k_m_list<16, 1024>), lds16)) return rc;
+        hipLaunchKernelGGL((k_m_list<16, 1024>), dim3(blocks), dim3(1024), lds16, st, a, j0, j1);
+        BAMM_HIP(hipGetLastError());
+        return BAMM_OK;
+    }
     const size_t lds = m_list_lds_bytes(j1 - j0, a.Y, a.logC, kMClasses[mclass], threads / 64u);
     if (lds > 160 * 1024 || j1 <= j0) { set_error("bad list M slice [%u,%u)", j0, j1); return BAMM_ERR_UNSUPPORTED; }
     switch (mclass) {
