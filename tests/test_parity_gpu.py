@@ -539,3 +539,32 @@ def test_external_reduce_buffer(gpu_ctx, orc):
     with pytest.raises(bm.abi.BammError):
         em.set_reduce_buffer(red.data_ptr(), 3)
     em.close(); ss.close()
+
+
+def test_kernel_timing_modes(gpu_ctx, orc):
+    """bamm_em_set_kernel_timing: a pair of HIP events around every n-th pass, none, or ONE pair around all passes of a call
+    (BAMM_TIMING_WHOLE_CALL) -- `launches` counts the passes an interval covers, the whole-call interval lies inside the host's
+    clock around the call, and the timing mode changes nothing in the model."""
+    import time
+    c = Case(**SMALL_CASES[6])
+    models = []
+    for every, want in ((1, 12), (4, 3), (0, 0), (-1, 12)):
+        em, ss, kmer, off, vbg = make_em(gpu_ctx, c, orc, max_iterations=40)
+        em.set_kernel_timing(every)
+        em.iterate(3)                                         # an earlier call's events are not carried over
+        gpu_ctx.sync()
+        t0 = time.perf_counter()
+        em.iterate(12)
+        gpu_ctx.sync()
+        host_ms = (time.perf_counter() - t0) * 1e3
+        ms, n = em.kernel_time()
+        assert n == want, (every, n)
+        if want:
+            assert 0.0 < ms <= host_ms * 1.05, (every, ms, host_ms)
+        models.append(em.getV().copy())
+        if every == -1:
+            em.optimize()                                     # look-ahead passes that found the stop flag raised are launches too
+            ms2, n2 = em.kernel_time()
+            assert n2 >= em.iteration() - 15 and ms2 > 0.0
+        em.close(); ss.close()
+    assert all(np.array_equal(models[0], m) for m in models[1:])

@@ -33,7 +33,12 @@ int main(int argc, char** argv) {
     lap("first launch + sync");
     (void)hipMemsetAsync(d, 0, mb << 20, st); (void)hipStreamSynchronize(st);
     lap("memset of the allocation");
-    if (!leave) { (void)hipFree(d); (void)hipHostFree(h); (void)hipStreamDestroy(st); lap("hipFree + hipHostFree + stream"); }
+    const bool reset = argc > 1 && !strcmp(argv[1], "reset");
+    if (reset) { (void)hipDeviceReset(); lap("hipDeviceReset"); }
+    else if (argc > 1 && !strcmp(argv[1], "free_dev")) { (void)hipFree(d); lap("hipFree"); }
+    else if (argc > 1 && !strcmp(argv[1], "free_host")) { (void)hipHostFree(h); lap("hipHostFree"); }
+    else if (argc > 1 && !strcmp(argv[1], "free_stream")) { (void)hipStreamDestroy(st); lap("hipStreamDestroy"); }
+    else if (!leave) { (void)hipFree(d); (void)hipHostFree(h); (void)hipStreamDestroy(st); lap("hipFree + hipHostFree + stream"); }
     printf("left %.4f\n", now());
     fflush(nullptr);
     _exit(0);
