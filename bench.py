@@ -363,28 +363,55 @@ def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_ma
     reason there is none.  barrier(): all ranks; sync(): this rank's stream; reduce_max(x): max over ranks."""
     W, K = wl["W"], wl["K"]
     em = None
-    try:
+    why = []                                                 # this rank's failures; every rank walks the SAME sequence of collectives
+
+    def step(what, f):
+        """A local step that may fail: the failure is kept, never raised -- a rank that left early would leave its peers in
+        the next barrier."""
+        if why:
+            return None
+        try:
+            return f()
+        except Exception as e:
+            why.append(f"{what}: {e!r}")
+            return None
+
+    def agreed():
+        """Collective: has any rank failed so far?"""
+        return reduce_max(1.0 if why else 0.0) > 0.0
+
+    def make():
         ctx.set_tuning(peer_allreduce=1)
-        em = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=args.steps + args.warmup + 8,
-                   n_seqs_bound=args.nseq)
-        em.set_comm(comm)
-        mode, note = em.comm_mode()                          # collective: the ranks vote
-        if mode != 2:
-            return {"ms_per_step_peer_allreduce": "unavailable: " + (note or "mode %d" % mode)}
-        em.set_kernel_timing(args.timing_every)
-        em.iterate(args.warmup); sync(); barrier()
+        e = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=args.steps + args.warmup + 8,
+                  n_seqs_bound=args.nseq)
+        e.set_comm(comm)
+        return e
+
+    try:
+        em = step("create", make)
+        if agreed():                                         # before the library's own vote: all ranks take part in it, or none
+            return {"ms_per_step_peer_allreduce": "unavailable: " + (why[0] if why else "another rank could not set it up")}
+        res = step("vote", lambda: em.comm_mode())           # collective: the ranks vote (same answer everywhere)
+        mode, note = res if res else (0, None)
+        if agreed() or mode != 2:
+            return {"ms_per_step_peer_allreduce": "unavailable: " + (why[0] if why else (note or "mode %d" % mode))}
+        step("timing", lambda: em.set_kernel_timing(args.timing_every))
+        step("warm-up", lambda: em.iterate(args.warmup))     # a block that waited in vain ends its launch with an error: bounded
+        step("sync", sync); barrier()
         t0 = time.perf_counter()
-        em.iterate(args.steps); sync(); barrier()
+        step("timed call", lambda: em.iterate(args.steps))
+        step("sync", sync); barrier()
         dt = reduce_max(time.perf_counter() - t0)
-        k_ms, k_n = em.kernel_time()
-        v = em.getV()                                        # raises BAMM_ERR_COMM if a block waited in vain
+        kt = step("kernel time", lambda: em.kernel_time()) or (0.0, 0)
+        v = step("read-back", lambda: em.getV())              # raises BAMM_ERR_COMM if a block waited in vain
+        k_us = reduce_max(kt[0] / max(kt[1], 1) * 1e3)
+        if agreed():
+            return {"ms_per_step_peer_allreduce": "unavailable: " + (why[0] if why else "another rank failed")}
         return {"ms_per_step_peer_allreduce": dt / args.steps * 1e3,
-                "peer_allreduce": {"kernel_us": reduce_max(k_ms / max(k_n, 1) * 1e3), "model_sha": hashlib.sha256(v.tobytes()).hexdigest()[:16],
+                "peer_allreduce": {"kernel_us": k_us, "model_sha": hashlib.sha256(v.tobytes()).hexdigest()[:16],
                                    "what": "every pass but the call's last hands its sums to the peers from the kernel's own epilogue (last block, "
-                                           "system-scope stores into peer-mapped inboxes), the next pass's block prologue waits for the flags and sums; "
-                                           "kernel_us then includes the wait for the slowest rank"}}
-    except Exception as e:                                   # an extra never costs the headline
-        return {"ms_per_step_peer_allreduce": "unavailable: " + repr(e)}
+                                           "system-scope stores into peer-mapped inboxes) and collects theirs there; kernel_us then includes the "
+                                           "wait for the slowest rank"}}
     finally:
         try:
             ctx.set_tuning(peer_allreduce=0)
