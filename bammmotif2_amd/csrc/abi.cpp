@@ -1071,7 +1071,11 @@ int bamm_ctx_set_tuning(bamm_ctx* c, const char* key, int value) {
 }
 
 // ------------------------------------------------------------------------------ sequences --
-int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t end, bamm_seqs** out) {
+// device arrays of a whole packed set that its maker already holds (bamm_seqs_from_codes): the resident set takes them over
+// instead of uploading the host copies again.  A pointer the set has taken is nulled here; the caller frees what is left.
+struct AdoptDev { uint32_t* words; uint64_t* word_off; uint32_t* len; uint64_t* pos_off; };   // words: 80 words of slack behind the stream
+
+static int seqs_upload_impl(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t end, bamm_seqs** out, AdoptDev* have) {
     if (!c || !p || !out || begin > end || end > p->n_seqs) {
         set_error("bamm_seqs_upload: bad argument");
         return BAMM_ERR_ARG;
@@ -1116,12 +1120,18 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
     }
     int rc;
     // 80 zero words of slack: the grouped kernel reads a lane's words without checking the sequence's end
-    if ((rc = dev_alloc(&s->d_words, (w1 - w0) + 80))) return rc;
-    BAMM_HIP(hipMemsetAsync(s->d_words + (w1 - w0), 0, 80 * sizeof(uint32_t), c->stream));
-    if (w1 > w0) BAMM_HIP(hipMemcpyAsync(s->d_words, p->words + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    if ((rc = dev_upload(&s->d_word_off, woff.data(), woff.size(), c->stream))) return rc;
-    if ((rc = dev_upload(&s->d_len, s->h_len.data(), s->h_len.size(), c->stream))) return rc;
-    if ((rc = dev_upload(&s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size(), c->stream))) return rc;
+    if (have && begin == 0 && end == p->n_seqs) {
+        s->d_words = have->words; s->d_word_off = have->word_off; s->d_len = have->len; s->d_pos_off = have->pos_off;
+        have->words = nullptr; have->word_off = nullptr; have->len = nullptr; have->pos_off = nullptr;   // the set's from here on
+        BAMM_HIP(hipMemsetAsync(s->d_words + (w1 - w0), 0, 80 * sizeof(uint32_t), c->stream));
+    } else {
+        if ((rc = dev_alloc(&s->d_words, (w1 - w0) + 80))) return rc;
+        BAMM_HIP(hipMemsetAsync(s->d_words + (w1 - w0), 0, 80 * sizeof(uint32_t), c->stream));
+        if (w1 > w0) BAMM_HIP(hipMemcpyAsync(s->d_words, p->words + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        if ((rc = dev_upload(&s->d_word_off, woff.data(), woff.size(), c->stream))) return rc;
+        if ((rc = dev_upload(&s->d_len, s->h_len.data(), s->h_len.size(), c->stream))) return rc;
+        if ((rc = dev_upload(&s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size(), c->stream))) return rc;
+    }
     int used = 0;
     for (int mc = 0; mc <= kNumMClasses; mc++) used += !members[mc].empty();
     for (int mc = 0; mc <= kNumMClasses; mc++) {
@@ -1141,6 +1151,10 @@ int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t
     s->hbm_bytes = (w1 - w0) * 4 + (s->n + 1) * 8 * 2 + s->n * 4;
     *out = s.release();
     return BAMM_OK;
+}
+
+int bamm_seqs_upload(bamm_ctx* c, const bamm_packed* p, uint64_t begin, uint64_t end, bamm_seqs** out) {
+    return seqs_upload_impl(c, p, begin, end, out, nullptr);
 }
 
 // bamm_pack_codes_seeded on the device (csrc/prep.hip), then bamm_seqs_upload: the same packed set, the same resident set
@@ -1214,7 +1228,7 @@ int bamm_seqs_from_codes(bamm_ctx* c, const uint8_t* codes, const uint64_t* off,
     if (hipMemcpyAsync(&n_exc, a.exc_off + n_seqs, sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
         set_error("bamm_seqs_from_codes: the exception count failed"); return release(BAMM_ERR_HIP);
     }
-    if ((rc = alloc(&a.words, tot[0])) || (rc = alloc(&a.exc_pos, n_exc)) || (rc = alloc(&a.exc_kmer, n_exc)) || (rc = alloc(&a.exc_clean, n_exc))) return release(rc);
+    if ((rc = alloc(&a.words, tot[0] + 80)) || (rc = alloc(&a.exc_pos, n_exc)) || (rc = alloc(&a.exc_kmer, n_exc)) || (rc = alloc(&a.exc_clean, n_exc))) return release(rc);
     if ((rc = launch_prep_pack(a, true, st))) return release(rc);
     // the host's view of the packed set (malloc: bamm_packed_free releases it)
     bamm_packed* p = (bamm_packed*)calloc(1, sizeof(bamm_packed));
@@ -1241,9 +1255,18 @@ int bamm_seqs_from_codes(bamm_ctx* c, const uint8_t* codes, const uint64_t* off,
     uint32_t mx = 0, mn = UINT32_MAX;
     for (uint64_t n = 0; n < n_seqs; n++) { mx = std::max(mx, p->len[n]); mn = std::min(mn, p->len[n]); }
     p->max_len = mx; p->min_len = mn;
+    if (seqs_out) {
+        // the stream, its offsets and the lengths are on the device already: the resident set takes those arrays over
+        AdoptDev have{a.words, a.word_off, a.len, a.pos_off};
+        rc = seqs_upload_impl(c, p, 0, n_seqs, seqs_out, &have);
+        for (void* taken : {(void*)a.words, (void*)a.word_off, (void*)a.len, (void*)a.pos_off}) {
+            const bool left = taken == (void*)have.words || taken == (void*)have.word_off || taken == (void*)have.len || taken == (void*)have.pos_off;
+            if (!left) owned.erase(std::remove(owned.begin(), owned.end(), taken), owned.end());
+        }
+        if (rc) { bamm_packed_free(p); return release(rc); }
+    }
     release(BAMM_OK);
     *packed_out = p;
-    if (seqs_out && (rc = bamm_seqs_upload(c, p, 0, n_seqs, seqs_out))) { bamm_packed_free(p); *packed_out = nullptr; return rc; }
     return BAMM_OK;
 }
 
