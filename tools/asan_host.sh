@@ -7,3 +7,7 @@ cd "$(dirname "$0")/../bammmotif2_amd"
 g++ -std=c++17 -O1 -g -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -fPIC -L. -Wl,-rpath,$PWD -shared \
     host/io.cpp host/fdr.cpp host/hooks.cpp -lbamm_em -o /tmp/libbamm_host_asan.so
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python3 ../tools/asan_host.py 2>&1 | grep -v "^Warning: Ignore FASTA"
+# ... and the host restatements of the input side (csrc/pack.cpp: Sequence::Sequence, BackgroundModel, the rand() stream's jump-ahead)
+g++ -std=c++17 -O1 -g -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer -fPIC -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -shared \
+    csrc/pack.cpp -o /tmp/libpack_asan.so
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python3 ../tools/asan_pack.py
