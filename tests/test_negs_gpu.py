@@ -57,3 +57,27 @@ def test_device_negatives_are_the_host_negatives(case, stride, generic, gpu_ctx,
     ref = bm.PackedSeqs.from_codes(want_codes, want_off, True, seed=None)
     assert np.array_equal(ref.words, neg.words)
     res.close(); pos.close()
+
+
+def test_random_shapes(gpu_ctx, host):
+    """Twenty-four seeded random positive sets (1..800 records, 3..600 bases, with and without N, both strand modes), random
+    m-fold, stride and flavour: the device's negatives base for base the host sampler's."""
+    rs = np.random.RandomState(77)
+    pwm = synth.make_pwm(8, 3)
+    for trial in range(24):
+        N = int(rs.choice([1, 3, 40, 800]))
+        L0 = int(rs.choice([3, 9, 50, 600]))
+        ragged = int(rs.randint(0, max(1, L0 - 2)))
+        codes, off = synth.make_sequences(N, L0, pwm, 100 + trial, 0.0, float(rs.choice([0.0, 0.02])), ragged)
+        ss = bool(rs.randint(2))
+        m = int(rs.choice([1, 2, 7, 33]))
+        stride = int(rs.choice([0, 2, 5]))
+        generic = bool(rs.randint(2))
+        packed = bm.PackedSeqs.from_codes(codes, off, ss, seed=42)
+        seqs = bm.SeqSet(gpu_ctx, packed)
+        want_codes, want_off = host_negatives(host, packed, m, generic, stride)
+        npk, nseqs = bm.sample_negatives(gpu_ctx, seqs, 2, m, generic, stride)
+        got = (npk.unpack_y(0) + 1).astype(np.uint8)         # the 2-bit stream back as codes 1..4
+        assert np.array_equal(npk.lengths, np.diff(want_off.astype(np.int64))), (trial, N, L0, m, stride)
+        assert np.array_equal(got, want_codes), (trial, N, L0, m, stride, generic)
+        nseqs.close(); seqs.close()

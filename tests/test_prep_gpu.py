@@ -73,3 +73,29 @@ def test_em_on_a_device_packed_set_is_the_same_em(gpu_ctx):
         em.close()
     assert np.array_equal(res[0], res[1])
     sd.close(); sh.close()
+
+
+def test_random_shapes(gpu_ctx):
+    """Forty seeded random sets: 1..3000 records of 1..700 bases (now and then one of 20 000), N fractions from none to all,
+    both strand modes -- every array of the packed set equal to the host packing's, and the background counts with it."""
+    rs = np.random.RandomState(2024)
+    for trial in range(40):
+        N = int(rs.choice([1, 2, 7, 60, 500, 3000]))
+        top = int(rs.choice([1, 3, 12, 40, 200, 700]))
+        lens = rs.randint(1, top + 1, size=N)
+        if trial % 9 == 0:
+            lens[rs.randint(N)] = 20000
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        codes = rs.randint(1, 5, size=int(off[-1])).astype(np.uint8)
+        codes[rs.random_sample(len(codes)) < rs.choice([0.0, 0.001, 0.05, 0.5, 1.0])] = 0
+        ss = bool(rs.randint(2))
+        seed = int(rs.choice([42, 1, 12345]))
+        host = bm.PackedSeqs.from_codes(codes, off, ss, seed=seed)
+        dev, seqs = bm.SeqSet.from_codes(gpu_ctx, codes, off, ss, seed=seed)
+        a, b = host.arrays(), dev.arrays()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (trial, N, top, ss, k)
+        K = int(rs.choice([0, 1, 2, 3, 5]))
+        alpha = np.array([1.0] + [10.0] * K, np.float32)
+        assert np.array_equal(seqs.bg_model(K, alpha), host.bg_model(K, alpha)), (trial, K)
+        seqs.close()
