@@ -17,6 +17,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o stats -
     python3 bench.py --no-cpu-baseline --no-extras > gpurun_out/prof/stats.log 2>&1
 cp "$(find gpurun_out/prof -name '*kernel_stats.csv' | head -1)" gpurun_out/${tag}_bench_kernel_stats.csv
 echo "stats done"; head -5 gpurun_out/${tag}_bench_kernel_stats.csv
+# the same trace, per dispatch: the mean over the launches of the timed call alone (what avg_kernel_ms covers)
+python3 tools/trace_timed_region.py "$(find gpurun_out/prof -name '*kernel_trace.csv' | head -1)" k_em_ 40 > gpurun_out/${tag}_bench_kernel_trace_timed.txt 2>&1 || true
+cat gpurun_out/${tag}_bench_kernel_trace_timed.txt
 # config 4: 1M x 500 bp, W = 30, k = 4 (column-sliced path)
 C4="--order 4 --len 500 --width 30 --steps 12 --warmup 12"
 bash tools/pmc_run.sh gpurun_out/${tag}_c4_hbm_traffic.json 1001000000 4 $C4
