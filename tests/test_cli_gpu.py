@@ -339,3 +339,13 @@ def test_cli_long_records(tmp_path, gpu_ctx):
     assert r.returncode == 0, r.stderr + r.stdout[-2000:]
     assert "3th iteration" in r.stdout or "2th iteration" in r.stdout
     assert any(p.name.endswith(".ihbcp") for p in out.iterdir())
+    # ... and sharded over two contexts (the ranks' plans differ: one shard holds the 68 001-position record): same files
+    out2 = tmp_path / "adv2"
+    r = subprocess.run([build.CLI, str(out2), str(fa), "--PWMFile", MEME, "--EM", "-k", "1", "--maxPWM", "1", "--maxEMIterations", "3",
+                        "--advanceEM", "--deviceList", "0,0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+    a = {p.name: p.read_bytes() for p in sorted(out.iterdir())}
+    b = {p.name: p.read_bytes() for p in sorted(out2.iterdir())}
+    assert a.keys() == b.keys()
+    for name in a:
+        assert a[name] == b[name], name
