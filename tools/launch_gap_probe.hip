@@ -12,6 +12,17 @@ __global__ void __launch_bounds__(1024) k_spin(unsigned long long ticks, unsigne
     if (threadIdx.x == 0 && blockIdx.x == 0) out[0] += 1u;          // a dependence from launch to launch
 }
 
+// the same with 160 KB of dynamic LDS per block (one block per CU, as the sequence kernels) and a 640-byte argument block
+struct Big { unsigned long long w[80]; };
+__global__ void __launch_bounds__(1024) k_spin_lds(unsigned long long ticks, unsigned* out, Big big) {
+    extern __shared__ unsigned lds[];
+    lds[threadIdx.x] = (unsigned)big.w[threadIdx.x % 80u];
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] += lds[5];
+}
+
 int main() {
     unsigned* d; CK(hipMalloc(&d, 4)); CK(hipMemset(d, 0, 4));
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -40,6 +51,16 @@ int main() {
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%3llu us kernel, graph of %d nodes    : %.2f us per launch -> %.2f us per boundary\n", us, N, ms * 1e3 / N, ms * 1e3 / N - (double)us);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        Big big{};
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spin_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int i = 0; i < 20; i++) hipLaunchKernelGGL(k_spin_lds, dim3(256), dim3(1024), 160 * 1024, st, ticks, d, big);
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < N; i++) hipLaunchKernelGGL(k_spin_lds, dim3(256), dim3(1024), 160 * 1024, st, ticks, d, big);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%3llu us kernel, 160 KB LDS + 640 B args   : %.2f us per launch -> %.2f us per boundary\n", us, ms * 1e3 / N, ms * 1e3 / N - (double)us);
     }
     return 0;
 }
