@@ -149,3 +149,50 @@ def test_mask_against_reference_golden(name, gpu_ctx, orc):
                 r = em.getR()[:nr]
                 np.testing.assert_allclose(r, g[t + "_r"], rtol=2e-3, atol=1e-9)
             em.close(); ss.close()
+
+
+@pytest.mark.parametrize("spec", [CASES[0], [d for d in CASES if d["name"] == "m_k7"][0], [d for d in CASES if d["name"] == "m_wide_lists"][0]],
+                         ids=["small", "k7_direct", "wide_lists"])
+def test_mask_sharded_over_two_contexts_is_the_one_rank_mask(spec, gpu_ctx, orc):
+    """EM::mask over two ranks (contexts on the one device, the host-staged communicator): the cut-off comes from the summed
+    integer histogram and the counts are integer sums, so cut-off, list size and the model equal the one-rank run's bit for
+    bit -- also where the ranks' plans differ (one shard holds the 83 095-position record) and where the counts go straight
+    into the accumulator (order 7)."""
+    import threading
+    c = Case(**spec)
+    one, ss1, kmer, off, vbg = make_em(gpu_ctx, c, orc, epsilon=0.0, max_iterations=3)
+    it1 = one.mask(0.1)
+    want = (it1, dict(one.last_mask), one.getV().copy(), one.getCounts().copy())
+    one.close(); ss1.close()
+    pk = bm.PackedSeqs.from_kmers(kmer, off)
+    ctxs = [bm.Context(0) for _ in range(2)]
+    comms = bm.Comm.init_local(ctxs, max(4 ** (c.K + 1) * c.W + 3, 2049))
+    sets, ems = [], []
+    for r in range(2):
+        b, e = pk.shard_range(c.W, r, 2)
+        ss = bm.SeqSet(ctxs[r], pk, b, e)
+        em = bm.EM(ctxs[r], ss, c.K, c.W, vbg, c.A, c.v0, c.q, bg_order=c.bg_order, n_seqs_global=c.N, n_seqs_bound=c.N,
+                   epsilon=0.0, max_iterations=3)
+        em.set_comm(comms[r])
+        sets.append(ss); ems.append(em)
+    got, errs = [None, None], [None, None]
+
+    def worker(r):
+        try:
+            it = ems[r].mask(0.1)
+            got[r] = (it, dict(ems[r].last_mask), ems[r].getV().copy(), ems[r].getCounts().copy())
+        except Exception as e:
+            errs[r] = e
+            for x in comms:
+                x.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=120)
+    assert not any(t.is_alive() for t in th) and errs == [None, None], errs
+    assert sum(g[1]["listed"] for g in got) == want[1]["listed"]          # a rank reports the windows IT lists
+    for r in range(2):
+        assert got[r][0] == want[0] and np.float32(got[r][1]["cutoff"]) == np.float32(want[1]["cutoff"])
+        assert np.array_equal(got[r][2], want[2]) and np.array_equal(got[r][3], want[3])
+    for x in ems + sets + comms + ctxs:
+        x.close()
