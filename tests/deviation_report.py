@@ -13,16 +13,23 @@ import bammmotif2_amd as bm  # noqa: E402
 import oracle  # noqa: E402
 from bammmotif2_amd import synth  # noqa: E402
 
-W, K = 20, 2
+import argparse  # noqa: E402
+ap = argparse.ArgumentParser()
+ap.add_argument("sizes", nargs="*", type=int, default=[1000, 10000, 50000])
+ap.add_argument("--width", type=int, default=20)
+ap.add_argument("--order", type=int, default=2)
+ap.add_argument("--len", type=int, default=200)
+args = ap.parse_args()
+W, K = args.width, args.order
 O = oracle.Oracle()
 O.set_threads(1)
 ctx = bm.Context(0)
 pwm = synth.make_pwm(W, 1234)
 A = synth.alpha_matrix(synth.default_alpha(K), W)
 v0 = synth.bamm_from_pwm((0.7 * pwm + 0.075).astype(np.float32), K)
-print("N  |gpu-f64|  |ref32-f64|  |gpu-ref32|   (max relative over v)")
-for N in [int(x) for x in (sys.argv[1:] or ["1000", "10000", "50000"])]:
-    codes, off = synth.make_sequences(N, 200, pwm, 1234)
+print(f"N x {args.len} bp, W = {W}, k = {K}:  |gpu-f64|  |ref32-f64|  |gpu-ref32|   (max relative over v)", flush=True)
+for N in args.sizes:
+    codes, off = synth.make_sequences(N, args.len, pwm, 1234)
     _, kmer, o = O.encode_set(codes, off, False, 42)
     vbg = O.bg_model(kmer, o, 2, np.array([1, 10, 10], np.float32))
     v64, _, _, _ = O.em_step_f64(kmer, o, K, W, 2, vbg, A, v0, 0.3)
@@ -33,5 +40,5 @@ for N in [int(x) for x in (sys.argv[1:] or ["1000", "10000", "50000"])]:
     em.iterate(1)
     vg = em.getV()
     rel = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))
-    print(f"{N}  {rel(vg, v64):.2e}  {rel(res['v'], v64):.2e}  {rel(vg, res['v']):.2e}")
+    print(f"{N}  {rel(vg, v64):.2e}  {rel(res['v'], v64):.2e}  {rel(vg, res['v']):.2e}", flush=True)
     em.close(); ss.close()
