@@ -451,6 +451,7 @@ size_t format_g(char* out, float xf, int P) {
     auto ge_pow = [&](int k) { return k >= 0 ? x >= p10[k] : x * p10[-k] >= 1.0; };   // x >= 10^k (x * 10^-k exact enough: checked again below)
     if (ge_pow(e + 1)) e++;
     const int k = P - 1 - e;                                 // scale to P digits in front of the point
+    if (k < -22 || k > 22) return slow();
     double v = k >= 0 ? x * p10[k] : x / p10[-k];
     const double lo = p10[P - 1], hi = p10[P];
     if (v < lo || v >= hi) {                                 // e was one off at a power of ten (x * 10^-k rounding): settle it exactly

@@ -242,7 +242,7 @@ def test_row_formatter_is_printf_g(host):
     }
     for name, x in sets.items():
         x = np.ascontiguousarray(x, dtype=np.float32)
-        for precision in (6, 3):
+        for precision in (6, 3, 1, 9):
             bits = C.c_uint32(0)
             bad = host.bh_format_g_check(x.ctypes.data_as(C.c_void_p), len(x), precision, C.byref(bits))
             assert bad == 0, (name, precision, bad, hex(bits.value))
