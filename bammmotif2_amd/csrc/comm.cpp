@@ -9,10 +9,17 @@
 // shards loads nothing, and a process that already carries an RCCL (torch ships its own) keeps using that
 // copy -- the loader hands back the library that is already mapped under the same SONAME.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <thread>
+
 #include <atomic>
+#include <cstring>
 #include <condition_variable>
 #include <mutex>
 
@@ -41,7 +48,45 @@ struct LocalGroup {
     }
 };
 
+// bamm_comm_init_shm: the same host-staged sum between PROCESSES of one host, through a POSIX shared-memory segment -- what
+// bamm_comm_init_local is to the threads of one process.  A self-test vehicle as well: it lets the cross-process half of the
+// in-kernel all-reduce (inboxes mapped through hipIpc*MemHandle) run between two processes on a 1-GPU box, where RCCL
+// refuses two ranks on one device.  Every wait is bounded.
+struct ShmGroup {
+    std::atomic<uint32_t> magic;            // kShmMagic once the creator has initialised the header
+    std::atomic<uint32_t> arrived, generation, aborted, attached;
+    uint32_t n;
+    uint64_t cap;
+    // long long inbox[n][cap] follows
+    long long* inbox(uint32_t r) { return reinterpret_cast<long long*>(this + 1) + (size_t)r * cap; }
+    // false when the group was aborted or a peer did not arrive within the limit
+    bool barrier(double limit_s = 60.0) {
+        if (aborted.load(std::memory_order_acquire)) return false;
+        const uint32_t gen = generation.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            arrived.store(0, std::memory_order_relaxed);
+            generation.fetch_add(1, std::memory_order_acq_rel);
+            return true;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (generation.load(std::memory_order_acquire) == gen) {
+            if (aborted.load(std::memory_order_acquire)) return false;
+            if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+                aborted.store(1, std::memory_order_release);
+                return false;
+            }
+        }
+        return true;
+    }
+};
+constexpr uint32_t kShmMagic = 0x42414d4du;
+
 struct bamm_comm {
+    ShmGroup* shm = nullptr;                // non-null: host-staged sum between processes (bamm_comm_init_shm)
+    size_t shm_bytes = 0;
+    std::string shm_name;
     // `mu` orders every use of `comm` against bamm_comm_abort / bamm_comm_destroy: ncclCommAbort frees the communicator,
     // so exactly one thread may call it, and nobody may enqueue on the handle afterwards (failing ranks abort ALL the
     // communicators of their group, from several threads at once).  An enqueue never waits for a peer -- the kernel
@@ -141,9 +186,29 @@ static int local_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipS
     return BAMM_OK;
 }
 
+static int shm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st) {
+    ShmGroup* g = c->shm;
+    if (n_words > g->cap) { set_error("shared-memory all-reduce of %zu words (capacity %llu)", n_words, (unsigned long long)g->cap); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipSetDevice(ctx_device(c->ctx)));
+    BAMM_HIP(hipMemcpyAsync(c->h_sum, dev_ptr, n_words * sizeof(long long), hipMemcpyDeviceToHost, st));
+    BAMM_HIP(hipStreamSynchronize(st));
+    memcpy(g->inbox(c->rank), c->h_sum, n_words * sizeof(long long));
+    if (!g->barrier()) { set_error("shared-memory all-reduce: the group was aborted or a rank did not arrive"); return BAMM_ERR_COMM; }
+    for (size_t i = 0; i < n_words; i++) {                   // integer sums: the rank order does not matter
+        long long t = 0;
+        for (uint32_t r = 0; r < g->n; r++) t += g->inbox(r)[i];
+        c->h_sum[i] = t;
+    }
+    if (!g->barrier()) { set_error("shared-memory all-reduce: the group was aborted or a rank did not arrive"); return BAMM_ERR_COMM; }
+    BAMM_HIP(hipMemcpyAsync(dev_ptr, c->h_sum, n_words * sizeof(long long), hipMemcpyHostToDevice, st));
+    BAMM_HIP(hipStreamSynchronize(st));                      // h_sum is reused by the next call
+    return BAMM_OK;
+}
+
 int comm_allreduce_i64(bamm_comm* c, void* dev_ptr, size_t n_words, hipStream_t st) {
     if (c->aborted.load(std::memory_order_acquire)) { set_error("the communicator was aborted"); return BAMM_ERR_COMM; }
     if (c->local) return local_allreduce_i64(c, dev_ptr, n_words, st);
+    if (c->shm) return shm_allreduce_i64(c, dev_ptr, n_words, st);
     const Rccl* r = rccl();
     if (!r) return BAMM_ERR_COMM;
     std::lock_guard<std::mutex> lock(c->mu);
@@ -335,9 +400,73 @@ int bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, 
     return BAMM_OK;
 }
 
+int bamm_comm_init_shm(bamm_ctx* ctx, const char* name, uint32_t rank, uint32_t world, uint64_t max_words, bamm_comm** out) {
+    if (!ctx || !name || !out || world == 0 || rank >= world || max_words == 0 || name[0] != '/') {
+        set_error("bamm_comm_init_shm: bad argument (the name starts with '/')");
+        return BAMM_ERR_ARG;
+    }
+    *out = nullptr;
+    const size_t bytes = sizeof(ShmGroup) + (size_t)world * (size_t)max_words * sizeof(long long);
+    // whoever creates the segment initialises it; the others wait for the magic word
+    bool creator = true;
+    int fd = shm_open(name, O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0) { creator = false; fd = shm_open(name, O_RDWR, 0600); }
+    const auto t0 = std::chrono::steady_clock::now();
+    while (fd < 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 30.0) {
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+        fd = shm_open(name, O_RDWR, 0600);
+    }
+    if (fd < 0) { set_error("bamm_comm_init_shm: cannot open %s", name); return BAMM_ERR_COMM; }
+    if (creator && ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); set_error("bamm_comm_init_shm: cannot size %s", name); return BAMM_ERR_COMM; }
+    if (!creator) {                                          // the creator may not have sized it yet
+        struct stat sb;
+        while (fstat(fd, &sb) == 0 && (size_t)sb.st_size < bytes &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 30.0)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { close(fd); set_error("bamm_comm_init_shm: %s has another size (another world / capacity?)", name); return BAMM_ERR_COMM; }
+    }
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { set_error("bamm_comm_init_shm: mmap failed"); return BAMM_ERR_COMM; }
+    ShmGroup* g = reinterpret_cast<ShmGroup*>(m);
+    if (creator) {
+        g->arrived.store(0); g->generation.store(0); g->aborted.store(0); g->attached.store(0);
+        g->n = world; g->cap = max_words;
+        g->magic.store(kShmMagic, std::memory_order_release);
+    } else {
+        while (g->magic.load(std::memory_order_acquire) != kShmMagic &&
+               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 30.0)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        if (g->magic.load(std::memory_order_acquire) != kShmMagic || g->n != world || g->cap != max_words) {
+            munmap(m, bytes);
+            set_error("bamm_comm_init_shm: %s belongs to another group (world / capacity differ)", name);
+            return BAMM_ERR_COMM;
+        }
+    }
+    bamm_comm* c = new bamm_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->shm = g; c->shm_bytes = bytes; c->shm_name = name;
+    if (hipSetDevice(ctx_device(ctx)) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_sum, (size_t)max_words * sizeof(long long), hipHostMallocDefault) != hipSuccess) {
+        munmap(m, bytes); delete c;
+        set_error("bamm_comm_init_shm: pinned host buffer could not be allocated");
+        return BAMM_ERR_HIP;
+    }
+    g->attached.fetch_add(1, std::memory_order_acq_rel);
+    if (!g->barrier(30.0)) {                                 // everybody is attached before anybody may unlink the name
+        (void)hipHostFree(c->h_sum); munmap(m, bytes); delete c;
+        if (creator) shm_unlink(name);
+        set_error("bamm_comm_init_shm: the other ranks did not attach to %s", name);
+        return BAMM_ERR_COMM;
+    }
+    if (creator) shm_unlink(name);                           // the mappings keep the segment alive; no name is left behind
+    *out = c;
+    return BAMM_OK;
+}
+
 int bamm_comm_abort(bamm_comm* c) {
     if (!c) return BAMM_OK;
     c->aborted.store(true, std::memory_order_release);       // whatever happens below: this rank's later calls fail
+    if (c->shm) { c->shm->aborted.store(1, std::memory_order_release); return BAMM_OK; }
     if (c->local) {
         { std::lock_guard<std::mutex> lock(c->local->mu); c->local->aborted = true; }
         c->local->cv.notify_all();
@@ -420,8 +549,8 @@ int bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rcc
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
     if (rccl_version) {
-        *rccl_version = 0;                                   // 0: the host-staged group of bamm_comm_init_local
-        if (!c->local) {
+        *rccl_version = 0;                                   // 0: the host-staged groups of bamm_comm_init_local / _shm
+        if (!c->local && !c->shm) {
             const Rccl* r = rccl();
             if (r) (void)r->GetVersion(rccl_version);
         }
@@ -431,6 +560,14 @@ int bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rcc
 
 int bamm_comm_destroy(bamm_comm* c) {
     if (!c) return BAMM_OK;
+    if (c->shm) {
+        (void)hipSetDevice(ctx_device(c->ctx));
+        peer_release(c);
+        (void)hipHostFree(c->h_sum);
+        munmap(c->shm, c->shm_bytes);
+        delete c;
+        return BAMM_OK;
+    }
     if (c->local) {
         LocalGroup* g = c->local;
         (void)hipSetDevice(ctx_device(c->ctx));

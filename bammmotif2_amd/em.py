@@ -205,6 +205,14 @@ class Comm:
         check(lib.bamm_comm_init_local(arr, len(ctxs), max_words, out))
         return [cls(c, C.c_void_p(h)) for c, h in zip(ctxs, out)]
 
+    @classmethod
+    def init_shm(cls, ctx: Context, name: str, rank: int, world: int, max_words: int):
+        """One PROCESS per rank on one host, the sum staged through the POSIX shared-memory segment `name` ("/..."): no RCCL
+        (self-tests of the cross-process paths on a 1-GPU box)."""
+        h = C.c_void_p()
+        check(ctx.lib.bamm_comm_init_shm(ctx.h, name.encode(), rank, world, max_words, C.byref(h)))
+        return cls(ctx, h)
+
     def abort(self):
         """Wake the peers blocked in a collective with this rank (they get BAMM_ERR_COMM)."""
         if self.h:

@@ -254,6 +254,12 @@ int  bamm_comm_init_rank(bamm_ctx* ctx, const void* id, uint32_t rank, uint32_t 
  * between the ranks' host threads, no RCCL.  max_words >= the largest buffer summed (4^(K+1)*W + 3; EM::mask: 2049).
  * For self-tests of the N > 1 logic on a 1-GPU box and for hosts without librccl; *rccl_version reports 0.       */
 int  bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, bamm_comm** out /* [n] */);
+/* the same between PROCESSES of one host: the sum is staged through a POSIX shared-memory segment `name` ("/something";
+ * created by whichever rank comes first, unlinked once all `world` ranks are attached).  Every rank calls it with the same
+ * name, world and max_words.  Every wait is bounded (a rank that does not arrive within a minute aborts the group).  For
+ * self-tests -- it lets the cross-process half of the in-kernel all-reduce (hipIpc-mapped inboxes) run between two processes
+ * on a 1-GPU box, where RCCL refuses two ranks on one device -- and for hosts without librccl.                          */
+int  bamm_comm_init_shm(bamm_ctx* ctx, const char* name, uint32_t rank, uint32_t world, uint64_t max_words, bamm_comm** out);
 int  bamm_comm_info(const bamm_comm* c, uint32_t* rank, uint32_t* world, int* rccl_version);
 /* a rank that fails calls this on its communicator (any thread): the collectives its peers are blocked in return
  * BAMM_ERR_COMM instead of waiting for it for ever (ncclCommAbort; the local kind wakes its waiters).  Safe to call

@@ -190,3 +190,47 @@ def test_two_processes_share_the_inboxes_through_ipc_handles(gpu_ctx, orc, tmp_p
         assert int(o["mode"]) == 2, str(o["note"])
         assert int(o["k"]) == want[3] and float(o["q"]) == want[1]
         assert np.array_equal(o["v"], want[0]) and np.array_equal(o["llh"], want[2])
+
+
+WORKER_SHM = WORKER.replace('''if rank == 0:
+    open(uid_path + ".tmp", "wb").write(bm.Comm.unique_id()); os.replace(uid_path + ".tmp", uid_path)
+import time
+t0 = time.time()
+while not os.path.exists(uid_path):
+    assert time.time() - t0 < 60
+    time.sleep(0.05)
+comm = bm.Comm.init_rank(ctx, open(uid_path, "rb").read(), rank, world)
+''', '''comm = bm.Comm.init_shm(ctx, uid_path, rank, world, 4 ** (c.K + 1) * c.W + 3)      # uid_path: the segment's name here
+''')
+assert WORKER_SHM != WORKER
+
+
+def test_two_processes_on_one_device_share_the_inboxes_through_ipc_handles(gpu_ctx, orc, tmp_path):
+    """The cross-process half of the in-kernel all-reduce on a 1-GPU box: one PROCESS per rank, both on device 0, the
+    set-up traffic (pids, pointers, hipIpc handles, the votes) over the shared-memory communicator (bamm_comm_init_shm; RCCL
+    refuses two ranks on one device), the inboxes opened with hipIpcOpenMemHandle in the other process -- what every rank
+    does under torch.distributed.run.  Mode 2 agreed, the model bit for bit the one-rank model."""
+    c = Case(**SMALL_CASES[6])
+    gpu_ctx.set_tuning(group_layout=8)
+    try:
+        one, ss, *_ = make_em(gpu_ctx, c, orc, optimizeQ=True, max_iterations=60)
+    finally:
+        gpu_ctx.set_tuning(group_layout=-1)
+    one.iterate(7)
+    it = one.optimize()
+    want = (one.getV(), one.getQ(), one.trace()[0], it)
+    one.close(); ss.close()
+    script = tmp_path / "worker_shm.py"
+    script.write_text(WORKER_SHM)
+    name = f"/bamm_test_{os.getpid()}"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(r), "2", name, str(tmp_path / f"shm{r}.npz")], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    for r in range(2):
+        o = np.load(tmp_path / f"shm{r}.npz")
+        assert int(o["mode"]) == 2, str(o["note"])
+        assert int(o["k"]) == want[3] and float(o["q"]) == want[1]
+        assert np.array_equal(o["v"], want[0]) and np.array_equal(o["llh"], want[2])
