@@ -73,6 +73,10 @@ def parse():
                     help="in-process form only: --gpus N ranks as N contexts on device 0 with the host-staged sum of "
                          "bamm_comm_init_local instead of RCCL (self-test of the N>1 logic on a 1-GPU box; never "
                          "used for reported numbers)")
+    ap.add_argument("--shm-comm", action="store_true",
+                    help="with --dist-backend gloo under a launcher: the library's host-staged communicator between processes "
+                         "(bamm_comm_init_shm) instead of RCCL -- a rehearsal of the one-process-per-rank form (the in-kernel "
+                         "all-reduce through hipIpc handles included) with all ranks on ONE device; never used for reported numbers")
     ap.add_argument("--timing-every", type=int, default=None,
                     help="HIP events of the timed call: -1 = ONE pair around all its passes (every pass covered, launch gaps "
                          "included, nothing added between passes: the default on 1 GPU); n >= 1 = a pair around every n-th pass "
@@ -659,6 +663,14 @@ def main():
             if comm is not None:
                 comm.close()
             print("[bench] using torch.distributed.all_reduce on every rank", file=sys.stderr)
+    if use_dist and args.dist_backend == "gloo" and args.shm_comm:
+        name = [f"/bamm_bench_{os.getpid()}" if rank == 0 else None]
+        dist.broadcast_object_list(name, src=0)
+        comm = bm.Comm.init_shm(ctx, name[0], rank, world, 4 ** (K + 1) * W + 3)
+        em.set_comm(comm)
+        keep.append(comm)
+        rank_info = comm.info()
+        allreduce_kind = "host-staged sum between the processes (bamm_comm_init_shm): a rehearsal, all ranks on one device"
     if use_dist and allreduce_kind == "none":
         allreduce_kind = "torch.distributed.all_reduce (%s) from a callback" % args.dist_backend
         _, n = em.reduce_buffer()
@@ -725,7 +737,7 @@ def main():
             raise SystemExit(f"bench.py: the ranks do not form a world of {world}: {ranks}")
     if use_dist and world > 1 and keep and isinstance(keep[0], bm.Comm) and not args.no_extras:
         def rmax(x):
-            t = torch.tensor([x], dtype=torch.float64, device="cuda")
+            t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
         with torch.cuda.stream(tstream):

@@ -67,3 +67,26 @@ def test_inprocess_ranks_without_a_launcher():
     assert rccl1.returncode == 0, rccl1.stderr[-3000:]
     j3 = json.loads([l for l in rccl1.stdout.splitlines() if l.startswith("{")][-1])
     assert j3["llh_last"] == j1["llh_last"]
+
+
+@pytest.mark.timeout(600)
+def test_two_processes_under_the_launcher_with_the_library_communicator():
+    """The driver's form -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- rehearsed with two
+    PROCESSES on the one GPU: the library's own communicator on the kernels' stream (here the shared-memory one, since RCCL
+    refuses two ranks on a device), `attribution`, and the in-kernel all-reduce extra through hipIpc-mapped inboxes with both
+    ranks ending on the same model."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29619", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--dist-backend", "gloo", "--shm-comm", "--nseq", "100000", "--steps", "12", "--warmup", "4",
+                          "--blocks", "112", "--no-cpu-baseline"], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and "bamm_comm_init_shm" in j["allreduce"]
+    assert [(r["rank"], r["world"]) for r in j["ranks"]] == [(0, 2), (1, 2)]
+    a = j["attribution"]
+    assert a["kernel_us"] > 0 and a["allreduce_us"] > 0 and a["step_us"] >= a["kernel_us"]
+    assert isinstance(j["ms_per_step_peer_allreduce"], float), j["ms_per_step_peer_allreduce"]
+    assert len(j["peer_allreduce"]["model_sha"]) == 16
