@@ -15,7 +15,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbamm_em.so")
-SOURCES = ["kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "grouped_mix.hip", "grouped_mix1.hip", "mask.hip", "seed.hip", "long_seq.hip", "prep.hip", "negs.hip", "abi.cpp", "comm.cpp", "pack.cpp"]
+SOURCES = ["model.hip", "kernels.hip", "grouped.hip", "grouped_long.hip", "grouped_xl.hip", "grouped_mix.hip", "grouped_mix1.hip", "mask.hip", "seed.hip", "long_seq.hip", "prep.hip", "negs.hip", "abi.cpp", "comm.cpp", "pack.cpp"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"), os.path.join(CSRC, "grouped_kernel.h"), os.path.join(CSRC, "mixed_kernel.h"), os.path.join(CSRC, "update_kernel.h"), os.path.join(CSRC, "phase_clock.h"),
            os.path.join(HERE, "..", "include", "bamm_em.h")]
 # -Rpass-analysis=kernel-resource-usage: registers / scratch / spills of every kernel go to the compiler's

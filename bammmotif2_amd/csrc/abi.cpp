@@ -51,14 +51,6 @@ int dev_alloc_bytes(void** p, size_t bytes) {
 template <class T>
 int dev_alloc(T** p, size_t count) { return dev_alloc_bytes((void**)p, count * sizeof(T)); }
 
-template <class T>
-int dev_upload(T** p, const T* host, size_t count, hipStream_t st) {
-    int rc = dev_alloc(p, count);
-    if (rc) return rc;
-    if (count) BAMM_HIP(hipMemcpyAsync(*p, host, count * sizeof(T), hipMemcpyHostToDevice, st));
-    return BAMM_OK;
-}
-
 struct Bucket {
     int mclass = 0;
     uint32_t count = 0;
@@ -121,6 +113,17 @@ struct bamm_ctx {
     size_t scratch_idle_bytes = 0, scratch_cap_bytes = 0;
     bool scratch_poison = false;                             // tests: every block is filled with 0xFF when it is handed out
     uint64_t scratch_hits = 0, scratch_misses = 0;
+    // Every transfer of 64 KiB or more between the CALLER's memory and the device goes through this pinned area (two chunks,
+    // filled and drained in turn), never through a hipMemcpy on the caller's pages.  The HIP runtime pins pageable memory in
+    // place for such a copy and keeps the registration; when the owner later unmaps those pages (a numpy array freed, a
+    // std::vector going out of scope) the driver evicts the process's queues until it has dropped the registration:
+    // the next launch or copy of the process then waits 17-39 ms (profiles/r05_first_call.txt -- the "29 ms second pass" of
+    // profiles/r04_pass_times.txt was getR()'s result being freed; bamm_em_create's first upload paid the same for the
+    // vectors of bamm_seqs_upload).  Memory this library pinned itself is never unmapped under a registration.
+    std::mutex stage_mu;
+    unsigned char* stage_buf[2] = {nullptr, nullptr};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_used[2] = {false, false};                     // an enqueued copy still reads (H2D) the chunk: wait for stage_ev first
 };
 
 constexpr size_t kScratchMinBytes = size_t(4) << 20;         // smaller blocks are plain allocations
@@ -138,6 +141,86 @@ static bool flush_idle_scratch(int device) {
         c->scratch_idle_bytes = 0;
     }
     return any;
+}
+
+constexpr size_t kStageChunk = size_t(8) << 20;               // bytes per pinned chunk
+constexpr size_t kStageMin = size_t(64) << 10;                // smaller transfers: the runtime copies them through its own staging buffer
+
+// memcpy on the host threads the process was granted (a chunk of 8 MB: 0.9 ms on one thread, 0.2 ms on eight)
+static void par_memcpy(void* dst, const void* src, size_t bytes) {
+    const uint32_t T = (uint32_t)std::max<size_t>(1, std::min<size_t>(host_threads_hint(), bytes >> 20));
+    if (T <= 1) { memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < T; t++) {
+        const size_t b = bytes * t / T & ~size_t(63), e = t + 1 == T ? bytes : (bytes * (t + 1) / T & ~size_t(63));
+        th.emplace_back([=] { memcpy((unsigned char*)dst + b, (const unsigned char*)src + b, e - b); });
+    }
+    for (auto& x : th) x.join();
+}
+
+static int stage_ready(bamm_ctx* c) {                         // stage_mu held
+    if (c->stage_buf[0]) return BAMM_OK;
+    unsigned char* p = nullptr;
+    if (hipHostMalloc((void**)&p, 2 * kStageChunk, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("hipHostMalloc of the %zu-byte staging area failed", 2 * kStageChunk);
+        return BAMM_ERR_HIP;
+    }
+    for (hipEvent_t& e : c->stage_ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(p); set_error("hipEventCreate failed"); return BAMM_ERR_HIP; }
+    c->stage_buf[0] = p; c->stage_buf[1] = p + kStageChunk;
+    return BAMM_OK;
+}
+
+// host -> device on the context's stream.  Returns when `src` has been read (the caller may free it); the copies themselves
+// are ordered on the stream like any other work.
+int ctx_upload(bamm_ctx* c, void* dst_dev, const void* src, size_t bytes) {
+    if (!bytes) return BAMM_OK;
+    if (bytes < kStageMin) { BAMM_HIP(hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, c->stream)); return BAMM_OK; }
+    std::lock_guard<std::mutex> l(c->stage_mu);
+    if (int rc = stage_ready(c)) return rc;
+    uint32_t b = 0;
+    for (size_t at = 0; at < bytes; at += kStageChunk, b ^= 1u) {
+        const size_t len = std::min(kStageChunk, bytes - at);
+        if (c->stage_used[b]) BAMM_HIP(hipEventSynchronize(c->stage_ev[b]));      // the copy that last read this chunk is done
+        par_memcpy(c->stage_buf[b], (const unsigned char*)src + at, len);
+        BAMM_HIP(hipMemcpyAsync((unsigned char*)dst_dev + at, c->stage_buf[b], len, hipMemcpyHostToDevice, c->stream));
+        BAMM_HIP(hipEventRecord(c->stage_ev[b], c->stream));
+        c->stage_used[b] = true;
+    }
+    return BAMM_OK;
+}
+
+// device -> host on the context's stream.  Returns when `dst` holds the data (everything enqueued on the stream before it
+// has completed by then).  Small transfers are enqueued only, like a hipMemcpyAsync: the caller synchronises.
+int ctx_download(bamm_ctx* c, void* dst, const void* src_dev, size_t bytes) {
+    if (!bytes) return BAMM_OK;
+    if (bytes < kStageMin) { BAMM_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, c->stream)); return BAMM_OK; }
+    std::lock_guard<std::mutex> l(c->stage_mu);
+    if (int rc = stage_ready(c)) return rc;
+    for (uint32_t b = 0; b < 2u; b++)
+        if (c->stage_used[b]) { BAMM_HIP(hipEventSynchronize(c->stage_ev[b])); c->stage_used[b] = false; }
+    const size_t chunks = (bytes + kStageChunk - 1) / kStageChunk;
+    for (size_t i = 0; i <= chunks; i++) {                   // chunk i is enqueued while chunk i - 1 is copied out
+        if (i < chunks) {
+            const size_t at = i * kStageChunk, len = std::min(kStageChunk, bytes - at);
+            BAMM_HIP(hipMemcpyAsync(c->stage_buf[i & 1u], (const unsigned char*)src_dev + at, len, hipMemcpyDeviceToHost, c->stream));
+            BAMM_HIP(hipEventRecord(c->stage_ev[i & 1u], c->stream));
+        }
+        if (i > 0) {
+            const size_t at = (i - 1) * kStageChunk, len = std::min(kStageChunk, bytes - at);
+            BAMM_HIP(hipEventSynchronize(c->stage_ev[(i - 1) & 1u]));
+            par_memcpy((unsigned char*)dst + at, c->stage_buf[(i - 1) & 1u], len);
+        }
+    }
+    return BAMM_OK;
+}
+
+template <class T>
+int dev_upload(bamm_ctx* c, T** p, const T* host, size_t count) {
+    int rc = dev_alloc(p, count);
+    if (rc) return rc;
+    return ctx_upload(c, *p, host, count * sizeof(T));
 }
 
 template <class T>
@@ -410,9 +493,9 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
     });
     k.h_off[s->n] = k.h_ex.size();
     k.count = k.h_ex.size();
-    int rc = dev_upload(&k.d_off, k.h_off.data(), k.h_off.size(), s->ctx->stream);
+    int rc = dev_upload(s->ctx, &k.d_off, k.h_off.data(), k.h_off.size());
     if (rc) return rc;
-    rc = dev_upload(&k.d_exc, k.h_ex.data(), k.h_ex.size(), s->ctx->stream);
+    rc = dev_upload(s->ctx, &k.d_exc, k.h_ex.data(), k.h_ex.size());
     if (rc) { (void)hipFree(k.d_off); return rc; }
     if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {
         (void)hipFree(k.d_off); (void)hipFree(k.d_exc);
@@ -475,7 +558,7 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
         xrec[n] = make_uint4(lo | (B << 12), w3[0], w3[1], w3[2]);
     }
     });
-    int rc = dev_upload(&x.d_xrec, xrec.data(), xrec.size(), s->ctx->stream);
+    int rc = dev_upload(s->ctx, &x.d_xrec, xrec.data(), xrec.size());
     if (rc) return rc;
     if (hipStreamSynchronize(s->ctx->stream) != hipSuccess) {
         (void)hipFree(x.d_xrec);
@@ -606,6 +689,25 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
         ga.peer.slot = (uint32_t)(ga.peer.seq % 3ull);
     }
     return launch_em_grp(eb.mclass, accum, write_r, ga, eb.blocks, threads, st);
+}
+
+// Make the kernel(s) one bucket's passes launch ready ahead of the first pass: the HIP runtime loads a translation unit's
+// code object on the first use of any kernel in it (0.8 ms for the mixed-row kernels, 8-14 ms for the 4 MB units), which
+// otherwise lands in the handle's first pass.  Runs on a thread of its own beside bamm_em_create's host work.
+int prime_bucket(bamm_ctx* c, const bamm_em_params& prm, uint32_t Y, bool sliced, const EmBucket& eb) {
+    if (hipSetDevice(c->device) != hipSuccess) { set_error("hipSetDevice failed"); return BAMM_ERR_HIP; }
+    EmKernelArgs a{};
+    a.K = prm.K; a.W = prm.W; a.Y = Y;
+    if (eb.mclass == kLongClass) return launch_long_em(a, true, false, false, kPrimeOnly, c->stream);
+    const uint32_t threads = bucket_threads(c, eb);
+    if (sliced || !eb.grouped) {                             // k_em_seq, the slices and the list walk share kernels.hip
+        a.logC = 0;
+        return launch_em_seq(eb.mclass, false, false, a, kPrimeOnly, threads, c->stream);
+    }
+    GrpKernelArgs ga{};
+    ga.e = a;
+    if (!grp_geometry(prm.K, prm.W, eb.G, kMClasses[eb.mclass], threads / 64u, true, eb.logc, eb.layout, &ga.g)) return BAMM_OK;   // (the launch reports it)
+    return launch_em_grp(eb.mclass, true, false, ga, kPrimeOnly, threads, c->stream);
 }
 
 void prepare_update(bamm_em* em, bool q_window, bool fused, UpdateArgs& u);
@@ -980,6 +1082,7 @@ int bamm_ctx_create(int device, void* hip_stream, bamm_ctx** out) {
         }
         c->own_stream = true;
     }
+    (void)prime_model_kernels();                             // k_make_s / k_update: the first kernels any handle launches
     {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c->scratch_cap_bytes = total_b / 4;
@@ -1011,6 +1114,11 @@ int bamm_ctx_destroy(bamm_ctx* c) {
     (void)hipSetDevice(c->device);
     if (!c->scratch_idle.empty()) (void)hipStreamSynchronize(c->stream);
     for (auto& b : c->scratch_idle) (void)hipFree(b.first);
+    if (c->stage_buf[0]) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipHostFree(c->stage_buf[0]);
+        for (hipEvent_t e : c->stage_ev) if (e) (void)hipEventDestroy(e);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BAMM_OK;
@@ -1127,10 +1235,10 @@ static int seqs_upload_impl(bamm_ctx* c, const bamm_packed* p, uint64_t begin, u
     } else {
         if ((rc = dev_alloc(&s->d_words, (w1 - w0) + 80))) return rc;
         BAMM_HIP(hipMemsetAsync(s->d_words + (w1 - w0), 0, 80 * sizeof(uint32_t), c->stream));
-        if (w1 > w0) BAMM_HIP(hipMemcpyAsync(s->d_words, p->words + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        if ((rc = dev_upload(&s->d_word_off, woff.data(), woff.size(), c->stream))) return rc;
-        if ((rc = dev_upload(&s->d_len, s->h_len.data(), s->h_len.size(), c->stream))) return rc;
-        if ((rc = dev_upload(&s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size(), c->stream))) return rc;
+        if ((rc = ctx_upload(c, s->d_words, p->words + w0, (w1 - w0) * sizeof(uint32_t)))) return rc;
+        if ((rc = dev_upload(c, &s->d_word_off, woff.data(), woff.size()))) return rc;
+        if ((rc = dev_upload(c, &s->d_len, s->h_len.data(), s->h_len.size()))) return rc;
+        if ((rc = dev_upload(c, &s->d_pos_off, s->h_pos_off.data(), s->h_pos_off.size()))) return rc;
     }
     int used = 0;
     for (int mc = 0; mc <= kNumMClasses; mc++) used += !members[mc].empty();
@@ -1143,7 +1251,7 @@ static int seqs_upload_impl(bamm_ctx* c, const bamm_packed* p, uint64_t begin, u
         else for (uint32_t n : members[mc]) b.work += s->h_len[n] / 8.0;   // ~8x the cost per position of the fast kernels
         s->buckets.push_back(b);
         if (used > 1) {
-            if ((rc = dev_upload(&s->buckets.back().d_idx, members[mc].data(), members[mc].size(), c->stream))) return rc;
+            if ((rc = dev_upload(c, &s->buckets.back().d_idx, members[mc].data(), members[mc].size()))) return rc;
             s->buckets.back().h_idx = std::move(members[mc]);
         }
     }
@@ -1191,8 +1299,7 @@ int bamm_seqs_from_codes(bamm_ctx* c, const uint8_t* codes, const uint64_t* off,
         // the records as one contiguous run starting at 0 (off[0] may be anything)
         std::vector<uint64_t> rel(n_seqs + 1);
         for (uint64_t n = 0; n <= n_seqs; n++) rel[n] = off[n] - off[0];
-        if (hipMemcpyAsync(d_codes, codes + off[0], n_codes, hipMemcpyHostToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(d_off, rel.data(), (n_seqs + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+        if (ctx_upload(c, d_codes, codes + off[0], n_codes) != BAMM_OK || ctx_upload(c, d_off, rel.data(), (n_seqs + 1) * sizeof(uint64_t)) != BAMM_OK ||
             hipStreamSynchronize(st) != hipSuccess) { set_error("bamm_seqs_from_codes: upload failed"); return release(BAMM_ERR_HIP); }
     }
     a.codes = d_codes; a.off = d_off; a.n = n_seqs; a.single_strand = single_strand;
@@ -1218,7 +1325,7 @@ int bamm_seqs_from_codes(bamm_ctx* c, const uint8_t* codes, const uint64_t* off,
         // threads enter the stream by jump-ahead, pack.cpp) while the device lists the zero positions
         std::vector<uint8_t> draws(tot[3] ? tot[3] : 1);
         rand_draws_mod4(seed, tot[3], draws.data());
-        if (tot[3] && (hipMemcpyAsync(d_draws, draws.data(), tot[3], hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) {
+        if (tot[3] && (ctx_upload(c, d_draws, draws.data(), tot[3]) != BAMM_OK || hipStreamSynchronize(st) != hipSuccess)) {
             set_error("bamm_seqs_from_codes: upload of the draws failed"); return release(BAMM_ERR_HIP);
         }
     }
@@ -1242,7 +1349,7 @@ int bamm_seqs_from_codes(bamm_ctx* c, const uint8_t* codes, const uint64_t* off,
     p->exc_kmer = (uint32_t*)calloc(n_exc ? n_exc : 1, sizeof(uint32_t));
     p->exc_clean = (uint32_t*)calloc(n_exc ? n_exc : 1, sizeof(uint32_t));
     bool ok = p->words && p->word_off && p->len && p->exc_off && p->exc_pos && p->exc_kmer && p->exc_clean;
-    auto down = [&](void* dst, const void* src, size_t bytes) { if (ok && bytes) ok = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st) == hipSuccess; };
+    auto down = [&](void* dst, const void* src, size_t bytes) { if (ok && bytes) ok = ctx_download(c, dst, src, bytes) == BAMM_OK; };
     down(p->words, a.words, tot[0] * sizeof(uint32_t));
     down(p->word_off, a.word_off, (n_seqs + 1) * sizeof(uint64_t));
     down(p->len, a.len, n_seqs * sizeof(uint32_t));
@@ -1389,8 +1496,7 @@ int bamm_sample_negatives(bamm_ctx* c, bamm_seqs* pos, uint32_t s_order, uint64_
         (rc = alloc(&a.out_words, n_words))) return release(rc);
     hipError_t e = hipMemcpyAsync(d_v, v.data(), tot * sizeof(float), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_bar, bar.data(), tot * sizeof(float), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_draw0, draw0.data(), pos->n * sizeof(uint64_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_wo, wo.data(), pos->n * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && (ctx_upload(c, d_draw0, draw0.data(), pos->n * sizeof(uint64_t)) || ctx_upload(c, d_wo, wo.data(), pos->n * sizeof(uint64_t)))) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemcpyAsync(d_seed, g.r, 34 * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_pw, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     if (e != hipSuccess) { set_error("bamm_sample_negatives: upload failed: %s", hipGetErrorString(e)); return release(BAMM_ERR_HIP); }
@@ -1409,7 +1515,7 @@ int bamm_sample_negatives(bamm_ctx* c, bamm_seqs* pos, uint32_t s_order, uint64_
     p->exc_clean = (uint32_t*)calloc(1, sizeof(uint32_t));
     uint32_t bad = 0;
     bool ok = p->words && p->word_off && p->len && p->exc_off && p->exc_pos && p->exc_kmer && p->exc_clean;
-    if (ok && n_words) ok = hipMemcpyAsync(p->words, a.out_words, n_words * sizeof(uint32_t), hipMemcpyDeviceToHost, st) == hipSuccess;
+    if (ok && n_words) ok = ctx_download(c, p->words, a.out_words, n_words * sizeof(uint32_t)) == BAMM_OK;
     if (ok) ok = hipMemcpyAsync(&bad, a.bad, sizeof bad, hipMemcpyDeviceToHost, st) == hipSuccess;
     if (ok) ok = hipStreamSynchronize(st) == hipSuccess;
     if (!ok) { bamm_packed_free(p); set_error("bamm_sample_negatives: the sampling pass failed"); return release(BAMM_ERR_HIP); }
@@ -1546,16 +1652,22 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
     }
     hipStream_t st = c->stream;
     int rc = BAMM_OK;
+    // the code objects of the kernels the handle will launch are loaded beside the host work below (prime_bucket), each as
+    // soon as the plan names the kernel; joined on every way out
+    struct Primers { std::vector<std::thread> t; ~Primers() { for (auto& x : t) if (x.joinable()) x.join(); } } primers;
+    auto prime = [&primers, c, prm_copy = em->prm, Y, sliced](const EmBucket& eb) {
+        primers.t.emplace_back([c, prm_copy, Y, sliced, eb] { (void)prime_bucket(c, prm_copy, Y, sliced, eb); });
+    };
     auto fail = [&](int code) { bamm_em_destroy(em); return code; };
     if ((rc = exceptions_for_order(seqs, prm->K, &em->exc))) return fail(rc);
-    if ((rc = dev_upload(&em->d_vbg, vbg, bg_size(prm->bg_order), st))) return fail(rc);
-    if ((rc = dev_upload(&em->d_A, A, (size_t)(prm->K + 1) * prm->W, st))) return fail(rc);
-    if ((rc = dev_upload(&em->d_v, v_init, em->vsz, st))) return fail(rc);
+    if ((rc = dev_upload(c, &em->d_vbg, vbg, bg_size(prm->bg_order)))) return fail(rc);
+    if ((rc = dev_upload(c, &em->d_A, A, (size_t)(prm->K + 1) * prm->W))) return fail(rc);
+    if ((rc = dev_upload(c, &em->d_v, v_init, em->vsz))) return fail(rc);
     if ((rc = dev_alloc(&em->d_n, em->vsz))) return fail(rc);
     if ((rc = dev_alloc(&em->d_s, (size_t)prm->W * (Y + 1)))) return fail(rc);
     if ((rc = dev_alloc(&em->d_s_alt, (size_t)prm->W * (Y + 1)))) return fail(rc);
     for (auto& slot : em->d_qbuf)
-        if ((rc = dev_upload(&slot, &prm->q, 1, st))) return fail(rc);
+        if ((rc = dev_upload(c, &slot, &prm->q, 1))) return fail(rc);
     em->d_q = em->d_qbuf[0];
     if ((rc = dev_alloc(&em->d_status, 8))) return fail(rc);
     if ((rc = dev_alloc(&em->d_trace, (size_t)em->prm.max_iterations * 3))) return fail(rc);
@@ -1586,7 +1698,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         return fail(BAMM_ERR_HIP);
     }
     if (seq_mask && seqs->n)
-        if ((rc = dev_upload(&em->d_mask, seq_mask, seqs->n, st))) return fail(rc);
+        if ((rc = dev_upload(c, &em->d_mask, seq_mask, seqs->n))) return fail(rc);
     em->n_active = seqs->n;
     if (seq_mask) em->n_active = (uint64_t)std::count_if(seq_mask, seq_mask + seqs->n, [](uint8_t m) { return m != 0; });
     if (hipHostMalloc((void**)&em->h_status, 24 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
@@ -1613,6 +1725,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             eb.mclass = kLongClass; eb.count = b.count; eb.d_idx = b.d_idx;
             eb.work = b.mclass == kLongClass ? b.work : (double)b.count * kMClasses[b.mclass];
             em->ebuckets.push_back(eb);
+            prime(eb);
             continue;
         }
         const int Mcls = kMClasses[b.mclass];
@@ -1631,6 +1744,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
             grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, plan_n * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
+            { EmBucket pb; pb.mclass = b.mclass; pb.grouped = true; pb.logc = glogc; pb.G = gG; pb.layout = glayout; prime(pb); }
             if ((rc = xrec_for_group(seqs, prm->K, gG, em->exc, &xr))) return fail(rc);
             // exceptions within the virtual rows for them, and clear of the rows for the LW1 edge
             auto capable = [&](uint32_t n) {
@@ -1649,7 +1763,7 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
             if (all) { eb.count = b.count; eb.d_idx = b.d_idx; }
             else {
                 uint32_t* d = nullptr;
-                if ((rc = dev_upload(&d, yes.data(), yes.size(), st))) return fail(rc);
+                if ((rc = dev_upload(c, &d, yes.data(), yes.size()))) return fail(rc);
                 em->owned_idx.push_back(d);
                 eb.count = (uint32_t)yes.size(); eb.d_idx = d;
             }
@@ -1661,12 +1775,13 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         eb.mclass = b.mclass;
         if (!no.empty()) {
             uint32_t* d = nullptr;
-            if ((rc = dev_upload(&d, no.data(), no.size(), st))) return fail(rc);
+            if ((rc = dev_upload(c, &d, no.data(), no.size()))) return fail(rc);
             em->owned_idx.push_back(d);
             eb.count = (uint32_t)no.size(); eb.d_idx = d;
         } else { eb.count = b.count; eb.d_idx = b.d_idx; }
         eb.work = (double)eb.count * Mcls;
         em->ebuckets.push_back(eb);
+        prime(eb);
     }
     if (!em->owned_idx.empty() && hipStreamSynchronize(st) != hipSuccess) { set_error("stream sync failed"); return fail(BAMM_ERR_HIP); }
     // launch geometry: blocks split over the launches in proportion to their work
@@ -2122,7 +2237,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
 static int copy_out(bamm_em* em, float* dst, const float* src, size_t count) {
     if (!em || !dst) { set_error("bad argument"); return BAMM_ERR_ARG; }
     BAMM_HIP(hipSetDevice(em->ctx->device));
-    BAMM_HIP(hipMemcpyAsync(dst, src, count * sizeof(float), hipMemcpyDeviceToHost, em->ctx->stream));
+    if (int rc = ctx_download(em->ctx, dst, src, count * sizeof(float))) return rc;
     BAMM_HIP(hipStreamSynchronize(em->ctx->stream));
     return comm_still_sound(em);
 }
@@ -2174,7 +2289,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
     BAMM_HIP(hipSetDevice(em->ctx->device));
     hipStream_t st = em->ctx->stream;
     if (em->mask_done) {                                    // EM::mask keeps r_ materialised (EM.cpp:409-430)
-        BAMM_HIP(hipMemcpyAsync(out, em->d_mask_r + base, total * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (int rc = ctx_download(em->ctx, out, em->d_mask_r + base, total * sizeof(float))) return rc;
         BAMM_HIP(hipStreamSynchronize(st));
         return BAMM_OK;
     }
@@ -2188,7 +2303,7 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         em->events_used = used; em->pass_no = pass_no;
         em->d_mask = saved_mask;
         if (rc2) return rc2;
-        BAMM_HIP(hipMemcpyAsync(out, em->d_state + base, total * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (int rc3 = ctx_download(em->ctx, out, em->d_state + base, total * sizeof(float))) return rc3;
         BAMM_HIP(hipStreamSynchronize(st));
         if (!em->e_fused)
             for (uint64_t n = begin; n < end; n++) {
@@ -2214,9 +2329,8 @@ int bamm_em_get_r(bamm_em* em, uint64_t begin, uint64_t end, float* out, uint64_
         rc = launch_fused(em, bk, false, true, a, bucket_threads(em->ctx, bk), st);
     }
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(out, d_r, total * sizeof(float), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { set_error("copy of r failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
+        rc = ctx_download(em->ctx, out, d_r, total * sizeof(float));
+        if (!rc && hipStreamSynchronize(st) != hipSuccess) { set_error("copy of r failed"); rc = BAMM_ERR_HIP; }
     }
     scratch_free(em->ctx, d_r);
     return rc;
@@ -2308,7 +2422,7 @@ int bamm_seed_from_pwm(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, const 
     uint32_t* d_z = nullptr;
     unsigned char* d_wave = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_score); (void)hipFree(d_u); (void)hipFree(d_counts); (void)hipFree(d_z); scratch_free(c, d_wave); };
-    if ((rc = dev_upload(&d_score, score, (size_t)4 * W, st)) || (rc = dev_upload(&d_u, u, s->n, st)) ||
+    if ((rc = dev_upload(c, &d_score, score, (size_t)4 * W)) || (rc = dev_upload(c, &d_u, u, s->n)) ||
         (rc = dev_alloc(&d_counts, vsz)) || (z && (rc = dev_alloc(&d_z, s->n)))) { cleanup(); return rc; }
     if (hipMemsetAsync(d_counts, 0, vsz * sizeof(int), st) != hipSuccess) { set_error("hipMemsetAsync failed"); cleanup(); return BAMM_ERR_HIP; }
     SeedKernelArgs a{};
@@ -2324,8 +2438,8 @@ int bamm_seed_from_pwm(bamm_ctx* c, bamm_seqs* s, uint32_t K, uint32_t W, const 
     }
     rc = launch_seed_pwm(a, (uint32_t)std::max(1, c->num_cus), st);
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(counts, d_counts, vsz * sizeof(int), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && z) e = hipMemcpyAsync(z, d_z, s->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        hipError_t e = ctx_download(c, counts, d_counts, vsz * sizeof(int)) ? hipErrorUnknown : hipSuccess;
+        if (e == hipSuccess && z && ctx_download(c, z, d_z, s->n * sizeof(uint32_t))) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("bamm_seed_from_pwm: copy failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
     }
@@ -2366,9 +2480,9 @@ int bamm_logodds_subset(bamm_ctx* c, bamm_seqs* s, const uint8_t* seq_mask, uint
     uint32_t* d_z = nullptr;
     uint8_t* d_smask = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_tab); (void)hipFree(d_mops); (void)hipFree(d_zoops); (void)hipFree(d_moff); (void)hipFree(d_z); (void)hipFree(d_smask); };
-    if ((rc = dev_upload(&d_tab, tab.data(), tab.size(), st)) || (rc = dev_upload(&d_moff, moff.data(), moff.size(), st)) ||
+    if ((rc = dev_upload(c, &d_tab, tab.data(), tab.size())) || (rc = dev_upload(c, &d_moff, moff.data(), moff.size())) ||
         (rc = dev_alloc(&d_zoops, s->n)) || (rc = dev_alloc(&d_z, s->n)) || (mops && (rc = dev_alloc(&d_mops, moff[s->n]))) ||
-        (seq_mask && (rc = dev_upload(&d_smask, seq_mask, s->n, st)))) {
+        (seq_mask && (rc = dev_upload(c, &d_smask, seq_mask, s->n)))) {
         cleanup();
         return rc;
     }
@@ -2396,9 +2510,9 @@ int bamm_logodds_subset(bamm_ctx* c, bamm_seqs* s, const uint8_t* seq_mask, uint
     }
     std::vector<uint32_t> hz(s->n);
     if (!rc) {
-        hipError_t e = hipMemcpyAsync(zoops, d_zoops, s->n * sizeof(float), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(hz.data(), d_z, s->n * sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && mops) e = hipMemcpyAsync(mops, d_mops, moff[s->n] * sizeof(float), hipMemcpyDeviceToHost, st);
+        hipError_t e = ctx_download(c, zoops, d_zoops, s->n * sizeof(float)) ? hipErrorUnknown : hipSuccess;
+        if (e == hipSuccess && ctx_download(c, hz.data(), d_z, s->n * sizeof(uint32_t))) e = hipErrorUnknown;
+        if (e == hipSuccess && mops && ctx_download(c, mops, d_mops, moff[s->n] * sizeof(float))) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) { set_error("bamm_logodds: copy failed: %s", hipGetErrorString(e)); rc = BAMM_ERR_HIP; }
     }

@@ -38,6 +38,17 @@ inline int allow_lds(const void* kernel, size_t lds) {
     return BAMM_OK;
 }
 
+// A launcher called with this block count makes the kernel ready to launch -- the runtime loads the code object of the
+// kernel's translation unit on first use: 0.8 ms for the mixed-row kernels, 8-14 ms for kernels.hip -- and launches
+// nothing.  bamm_em_create primes the kernels of the handle's passes, so that the first pass costs what the others do.
+constexpr uint32_t kPrimeOnly = 0xffffffffu;
+inline int prime_kernel(const void* kernel) {
+    hipFuncAttributes at;
+    const hipError_t e = hipFuncGetAttributes(&at, kernel);
+    if (e != hipSuccess) { set_error("hipFuncGetAttributes failed: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
+    return BAMM_OK;
+}
+
 inline size_t ipow4(size_t e) { return size_t(1) << (2 * e); }
 inline size_t v_offset(size_t k, size_t W) { return W * ((ipow4(k + 1) - 4) / 3); }
 inline size_t v_size(size_t K, size_t W) { return v_offset(K + 1, W); }
@@ -336,6 +347,7 @@ int launch_reduce_partials(const unsigned long long* partial_n, const double* pa
 int launch_make_s(const float* v, const float* vbg, uint32_t K, uint32_t W, uint32_t Kbg, float* s,
                   hipStream_t st);
 int launch_update(const UpdateArgs& a, hipStream_t st);
+int prime_model_kernels();
 int launch_stat_only(long long* acc, uint32_t cells, float* status, hipStream_t st);
 uint32_t max_threads_for_mclass(int mclass);
 

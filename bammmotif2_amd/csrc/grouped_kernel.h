@@ -810,12 +810,15 @@ int launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t bl
         int rc;
         if (write_r) {
             if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>), lds))) return rc;
+            if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>));
             hipLaunchKernelGGL((k_em_grp<M, G, KG, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
         } else if (accum) {
             if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>), lds))) return rc;
+            if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>));
             hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
         } else {
             if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, false, THREADS>), lds))) return rc;
+            if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, false, THREADS>));
             hipLaunchKernelGGL((k_em_grp<M, G, KG, false, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
         }
         return BAMM_OK;

@@ -158,6 +158,7 @@ __global__ void __launch_bounds__(256) k_long_score(ScoreKernelArgs a) {
 
 int launch_long_em(const EmKernelArgs& a, bool accum, bool write_r, bool slot_layout, uint32_t blocks, hipStream_t st) {
     if (blocks == 0) return BAMM_OK;
+    if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_long_em));
     hipLaunchKernelGGL(k_long_em, dim3(blocks), dim3(256), 0, st, a, accum ? 1 : 0, write_r ? 1 : 0, slot_layout ? 1 : 0);
     BAMM_HIP(hipGetLastError());
     return BAMM_OK;

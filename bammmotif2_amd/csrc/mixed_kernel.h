@@ -556,12 +556,15 @@ int launch_mix_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_
     int rc;
     if (write_r) {
         if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, false, true, THREADS>), lds))) return rc;
+        if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, false, true, THREADS>));
         hipLaunchKernelGGL((k_em_mix<M, A, NQ, false, true, THREADS>), dim3(blocks), dim3(THREADS), lds, st, a);
     } else if (accum) {
         if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, true, false, THREADS>), lds))) return rc;
+        if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, true, false, THREADS>));
         hipLaunchKernelGGL((k_em_mix<M, A, NQ, true, false, THREADS>), dim3(blocks), dim3(THREADS), lds, st, a);
     } else {
         if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, false, false, THREADS>), lds))) return rc;
+        if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_mix<M, A, NQ, false, false, THREADS>));
         hipLaunchKernelGGL((k_em_mix<M, A, NQ, false, false, THREADS>), dim3(blocks), dim3(THREADS), lds, st, a);
     }
     return BAMM_OK;

@@ -712,6 +712,7 @@ int main(int nargs, char* args[]) {
                 if (bamm_em_create(devs[d].ctx, devs[d].shard, &p, bg.v.data(), motif.A.data(), motif.v.data(), nullptr, &ems[d])) die_abi("EM");
                 if (devs[d].comm && bamm_em_set_comm(ems[d], devs[d].comm)) die_abi("EM communicator");
             }
+            const auto t_created = std::chrono::high_resolution_clock::now();
             // one std::thread per rank, not an OpenMP team (which may come back smaller than asked for and leave ranks
             // out of the collective); a rank that still fails aborts every communicator so that its peers return
             auto run_rank = [&](size_t d) {
@@ -734,6 +735,7 @@ int main(int nargs, char* args[]) {
                 if (!thread_err[d].empty()) die("Error: EM on GPU " + std::to_string(devs[d].device) + ": " + thread_err[d]);
             bamm_em* em = ems[0];
             const uint32_t it = its[0];
+            const auto t_optimized = std::chrono::high_resolution_clock::now();
             if (bamm_em_get_v(em, motif.v.data())) die_abi("get_v");
             float q = 0;
             bamm_em_get_q(em, &q);
@@ -755,6 +757,9 @@ int main(int nargs, char* args[]) {
             motif_calculate_p(motif, bg);
             auto dt = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0);
             std::cout << "\n--- Runtime for EM: " << dt.count() << " seconds ---\n";        // EM.cpp:134
+            if (timing) std::cerr << "[timing-beside] EM of motif " << n + 1 << ": create " << std::chrono::duration<double>(t_created - t0).count()
+                                  << " s, " << (o.advanceEM ? "mask" : "optimize") << " " << std::chrono::duration<double>(t_optimized - t_created).count()
+                                  << " s (" << it << " passes), read-back + calculateP " << (dt - std::chrono::duration<double>(t_optimized - t0)).count() << " s" << std::endl;
             stage("EM (create + optimize + read-back)");
             if (o.saveBaMMs) {                                // EM::write (EM.cpp:553-601)
                 std::vector<float> cnts(bamm_v_size(motif.K, motif.W));

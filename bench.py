@@ -327,7 +327,7 @@ def report(args, wl, world, dt, kernel_ms, launches, local_positions, local_wind
         "parity": "learned v within 1e-5 of the reference on its own fixtures up to ~2k sequences; beyond that the "
                   "reference's fp32 CAS accumulation is itself 4e-5 (10k) to 4e-4 (200k) off exact arithmetic, while "
                   "this path stays within 3e-7 of the fp64 restatement at every size (integer accumulation; "
-                  "profiles/r02_deviation_vs_fp64.txt, tests/test_golden_gpu.py, tests/golden_tolerance_report.py)",
+                  "profiles/r04_deviation_vs_fp64.txt, profiles/r04_parity_margins.txt, tests/test_golden_gpu.py, tests/test_fullsize_parity_gpu.py)",
         "llh_last": llh_last,
         **extras,
     }
@@ -425,6 +425,26 @@ def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_ma
             pass
 
 
+def first_call(bm, ctx, seqs, wl, args, sync):
+    """The FIRST handle of the process, nothing warmed up (no kernel of the library has run yet): what bamm_em_create costs
+    and what the first optimize() call costs -- code-object loads, first-use allocations and the slow early passes included.
+    Runs before the timed handle is even created; single rank only."""
+    n_cold = 20
+    W, K = wl["W"], wl["K"]
+    sync()
+    t0 = time.perf_counter()
+    e = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=n_cold, epsilon=0.0, n_seqs_bound=args.nseq)
+    sync()
+    t1 = time.perf_counter()
+    it = e.optimize()
+    sync()
+    t2 = time.perf_counter()
+    e.close()
+    return {"first_create_ms": (t1 - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3, "first_call_passes": it,
+            "first_call_is": "bamm_em_create, then optimize() (epsilon 0, %d passes) on the first handle of the process before anything "
+                             "else of the library has run on the device; wall clock, stream synchronised on both sides" % n_cold}
+
+
 def from_seed_extras(bm, ctx, seqs, wl, args, sync):
     """Beside the steady-state figure: what a run from the seed pays (the first passes are slower: few
     responsibilities are exactly zero yet), as iterate() and as optimize() (EM.cpp:81-128: the stopping rule looks
@@ -448,6 +468,13 @@ def from_seed_extras(bm, ctx, seqs, wl, args, sync):
     return out
 
 
+def merge_first_call(extras, first):
+    """`from_seed` carries the first-call figures beside the per-step ones."""
+    if first:
+        extras.setdefault("from_seed", {}).update(first)
+    return extras
+
+
 def main_inprocess(args, result_fd):
     """`python bench.py --gpus N` without a launcher: ONE process, a context + host thread per GPU, the library's
     own RCCL communicator (ncclCommInitAll).  ctypes releases the GIL during the calls, so the N iterate() calls
@@ -469,6 +496,7 @@ def main_inprocess(args, result_fd):
     wl = workload(args)
     packed, W, K = wl["packed"], wl["W"], wl["K"]
     ctxs, seqs, ems = [], [], []
+    first = None
     for r in range(N):
         ctx = bm.Context(devices[r])
         if args.blocks or args.threads:
@@ -481,6 +509,8 @@ def main_inprocess(args, result_fd):
             ctx.set_tuning(fused_update=0)
         b, e = packed.shard_range(W, r, N)
         ss = bm.SeqSet(ctx, packed, b, e)
+        if N == 1 and not args.force_dist and not args.no_extras:
+            first = first_call(bm, ctx, ss, wl, args, ctx.sync)
         em = bm.EM(ctx, ss, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=args.steps + args.warmup + 8,
                    n_seqs_bound=args.nseq)
         em.set_kernel_timing(args.timing_every)
@@ -562,6 +592,7 @@ def main_inprocess(args, result_fd):
             extras["ms_per_step_peer_allreduce"] = "unavailable: the ranks' models differ after the in-kernel all-reduce"
     if N == 1 and not comms and not args.no_extras:
         extras.update(from_seed_extras(bm, ctxs[0], seqs[0], wl, args, ctxs[0].sync))
+    merge_first_call(extras, first)
     lp = int(seqs[0].off[-1])
     lw = int((seqs[0].lengths.astype(np.int64) - W + 1).sum())
     out = report(args, wl, N, dt, kernel_ms, launches, lp, lw, name, mixed, float(llh[-1]) if len(llh) else None,
@@ -629,6 +660,10 @@ def main():
         ctx.set_tuning(fused_update=0)
     begin, end = packed.shard_range(W, rank, world)
     seqs = bm.SeqSet(ctx, packed, begin, end)
+    first = None
+    if world == 1 and not use_dist and not args.no_extras:
+        with torch.cuda.stream(tstream):
+            first = first_call(bm, ctx, seqs, wl, args, torch.cuda.synchronize)
     em = bm.EM(ctx, seqs, K, W, vbg, A, v0, q, bg_order=2, max_iterations=args.steps + args.warmup + 8,
                n_seqs_bound=args.nseq)      # same unit of the integer count accumulator whatever the number of ranks
 
@@ -721,6 +756,7 @@ def main():
     if world == 1 and not use_dist and not args.no_extras:
         with torch.cuda.stream(tstream):
             extras = from_seed_extras(bm, ctx, seqs, wl, args, torch.cuda.synchronize)
+    merge_first_call(extras, first)
     local_positions = int(seqs.off[-1])
     local_windows = int((seqs.lengths.astype(np.int64) - W + 1).sum())
     llh, vdiff, _ = em.trace()

@@ -1,4 +1,4 @@
-"""The model update spread over blocks (k_update_counts + k_update_model, csrc/kernels.hip) against the one-block
+"""The model update spread over blocks (k_update_counts + k_update_model, csrc/model.hip) against the one-block
 k_update<false>: tables beyond the update's LDS form (k >= 3 at usual widths, k = 2 at W > 32, orders 7-10).
 
 Both restate EM.cpp:247-254 (lower-order counts: four rows of the next order, ascending) and Motif.h:95-136 (the

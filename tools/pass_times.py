@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Milliseconds of every one of the first passes of the bench workload (1M x 200 bp both strands, W = 20, k = 2) from the
-seed model, and the share of exactly-zero responsibilities (r < 2^-40 adds nothing to the integer counts) on a sample.
+seed model, on the first handle of a fresh process (up to round 4 a first handle was run and closed beforehand), and the share of exactly-zero responsibilities (r < 2^-40 adds nothing to the integer counts) on a sample.
     python tools/pass_times.py [nseq] [passes]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,9 +19,7 @@ A = synth.alpha_matrix(synth.default_alpha(K), W)
 v0 = synth.bamm_from_pwm((0.7 * pwm + 0.3 * 0.25).astype(np.float32), K)
 ctx = bm.Context(0)
 seqs = bm.SeqSet(ctx, pk)
-em = bm.EM(ctx, seqs, K, W, vbg, A, v0, 0.3, max_iterations=P + 8)
-em.iterate(1); ctx.sync(); em.close()
-em = bm.EM(ctx, seqs, K, W, vbg, A, v0, 0.3, max_iterations=P + 8)
+em = bm.EM(ctx, seqs, K, W, vbg, A, v0, 0.3, max_iterations=P + 8)      # the process's FIRST handle: nothing was warmed up
 ms, nz = [], []
 for p in range(P):
     ctx.sync(); t0 = time.perf_counter(); em.iterate(1); ctx.sync(); ms.append((time.perf_counter() - t0) * 1e3)
