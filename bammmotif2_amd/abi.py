@@ -49,7 +49,7 @@ SYMBOLS = [
     "bamm_em_destroy", "bamm_em_estep", "bamm_em_mstep", "bamm_em_optimize_q", "bamm_em_iterate",
     "bamm_em_optimize", "bamm_em_mask", "bamm_em_accumulate", "bamm_em_reduce_buffer", "bamm_em_update", "bamm_em_set_reduce_buffer",
     "bamm_em_set_allreduce", "bamm_em_set_comm", "bamm_comm_init_all", "bamm_comm_unique_id", "bamm_comm_init_rank",
-    "bamm_comm_info", "bamm_comm_destroy", "bamm_comm_time_allreduce", "bamm_em_comm_mode", "bamm_seqs_from_codes", "bamm_seqs_bg_model", "bamm_sample_negatives", "bamm_rand_stream_draws", "bamm_comm_init_local", "bamm_comm_init_shm", "bamm_comm_abort", "bamm_device_count", "bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s", "bamm_em_get_q",
+    "bamm_comm_info", "bamm_comm_destroy", "bamm_comm_time_allreduce", "bamm_em_comm_mode", "bamm_seqs_from_codes", "bamm_seqs_bg_model", "bamm_sample_negatives", "bamm_rand_stream_draws", "bamm_comm_init_local", "bamm_comm_init_shm", "bamm_comm_abort", "bamm_device_count", "bamm_device_pci_bus_id", "bamm_device_can_access_peer", "bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s", "bamm_em_get_q",
     "bamm_em_get_llh", "bamm_em_get_vdiff", "bamm_em_get_iteration", "bamm_em_get_r",
     "bamm_em_get_trace", "bamm_em_kernel_time", "bamm_em_set_kernel_timing", "bamm_em_plan", "bamm_em_plan_mixed", "bamm_seed_from_pwm", "bamm_set_host_threads", "bamm_logodds", "bamm_logodds_subset", "bamm_bg_model", "bamm_calculate_p", "bamm_v_size",
     "bamm_v_offset", "bamm_bg_size",
@@ -120,6 +120,8 @@ def load() -> C.CDLL:
     L.bamm_comm_init_local.argtypes = [P(vp), u32, u64, P(vp)]
     L.bamm_comm_init_shm.argtypes = [vp, C.c_char_p, u32, u32, u64, P(vp)]
     L.bamm_device_count.argtypes = [P(i)]
+    L.bamm_device_pci_bus_id.argtypes = [i, C.c_char_p, C.c_size_t]
+    L.bamm_device_can_access_peer.argtypes = [i, i, P(i)]
     for name in ("bamm_em_get_v", "bamm_em_get_counts", "bamm_em_get_s"):
         getattr(L, name).argtypes = [vp, f32p]
     for name in ("bamm_em_get_q", "bamm_em_get_llh", "bamm_em_get_vdiff"):

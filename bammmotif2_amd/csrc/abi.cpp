@@ -407,6 +407,7 @@ struct bamm_em {
     // in-kernel all-reduce (PeerArgs): the last block of every accumulating pass exchanges the GPU's totals with the peers
     // and leaves the sum in the accumulator, in place -- no collective launch behind the pass
     bool peer_on = false;                       // agreed with every rank in verify_comm()
+    bool pass_summed_in_kernel = false;         // the pass just enqueued carried the tail (launch_fused): run_allreduce has nothing to add
     uint32_t* d_peer_words = nullptr;           // [0] ticket, [1] err
     std::string peer_note;                      // why peer_on is false although asked for
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -681,6 +682,7 @@ int launch_fused(bamm_em* em, const EmBucket& eb, bool accum, bool write_r, EmKe
         ga.fused = 1u; ga.upd = *fuse; ga.upd_off = em->fuse_upd_off; ga.s_block = em->d_s_block;
     }
     if (em->peer_on && accum && !write_r) {                  // in-kernel all-reduce in the launch's tail (the pass's only launch)
+        em->pass_summed_in_kernel = true;
         comm_peer_args(em->comm, &ga.peer);
         ga.peer.words = (uint32_t)em->cells + 3u;
         ga.peer.ticket = em->d_peer_words; ga.peer.err = em->d_peer_words + 1;
@@ -746,6 +748,7 @@ int run_accumulate(bamm_em* em, bool accum, bool replay_last = false, bool dense
     int rc = use_device(em->ctx);
     if (rc) return rc;
     UpdateArgs fuse{};
+    em->pass_summed_in_kernel = false;
     const bool fusing = fuse_q_window >= 0;
     if (fusing) prepare_update(em, fuse_q_window != 0, true, fuse);     // consumes the previous pass's sums on the stream
     else if ((rc = clean_accumulator(em))) return rc;
@@ -857,7 +860,10 @@ int allreduce_words(bamm_em* em, void* dev_ptr, size_t n_words) {
 }
 
 int run_allreduce(bamm_em* em) {
-    if (em->peer_on) return BAMM_OK;                         // the pass's own launch summed over the ranks (launch_fused, peer_allreduce_tail)
+    // mode 2: a pass whose launch carried the tail left the all-reduced sums in the accumulator (launch_fused,
+    // peer_allreduce_tail).  Every other pass of such a handle -- EStep() alone (an E-only launch has no tail), EM::mask's
+    // kernels, a replay -- is summed by the communicator's collective like in mode 1: same integers either way.
+    if (em->pass_summed_in_kernel) { em->pass_summed_in_kernel = false; return BAMM_OK; }
     if (em->comm) return comm_allreduce_i64(em->comm, em->d_acc, em->cells + 3, em->ctx->stream);
     if (!em->allreduce) return BAMM_OK;
     int rc = em->allreduce(em->allreduce_user, em->d_acc, em->cells + 3, (void*)em->ctx->stream);
@@ -1102,6 +1108,27 @@ int bamm_device_count(int* n) {
         return BAMM_ERR_NO_DEVICE;
     }
     *n = count;
+    return BAMM_OK;
+}
+
+int bamm_device_pci_bus_id(int device, char* buf, size_t cap) {
+    if (!buf || cap < 16) { set_error("bamm_device_pci_bus_id: buffer of at least 16 bytes"); return BAMM_ERR_ARG; }
+    buf[0] = 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return BAMM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= count) { set_error("device %d out of range (0..%d)", device, count - 1); return BAMM_ERR_ARG; }
+    BAMM_HIP(hipDeviceGetPCIBusId(buf, (int)cap, device));
+    return BAMM_OK;
+}
+
+int bamm_device_can_access_peer(int device, int peer, int* can) {
+    if (!can) { set_error("bamm_device_can_access_peer: null argument"); return BAMM_ERR_ARG; }
+    *can = 0;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) { set_error("no HIP device visible"); return BAMM_ERR_NO_DEVICE; }
+    if (device < 0 || device >= count || peer < 0 || peer >= count) { set_error("device %d / peer %d out of range (0..%d)", device, peer, count - 1); return BAMM_ERR_ARG; }
+    if (device == peer) { *can = 1; return BAMM_OK; }
+    BAMM_HIP(hipDeviceCanAccessPeer(can, device, peer));
     return BAMM_OK;
 }
 
@@ -2087,6 +2114,7 @@ int bamm_em_mask(bamm_em* em, float f, uint32_t* iterations, float* cutoff, uint
     if (!em) { set_error("null em"); return BAMM_ERR_ARG; }
     if (int vrc = verify_comm(em)) return vrc;
     bamm_seqs* s = em->seqs;
+    em->pass_summed_in_kernel = false;                       // EM::mask's kernels carry no tail: every one of its sums goes through the communicator
     if (!(f > 0.0f && f < 1.0f)) { set_error("bamm_em_mask: fraction %g outside (0,1)", (double)f); return BAMM_ERR_ARG; }
     if (em->n_active == 0) { set_error("bamm_em_mask: no sequences (the reference indexes an empty array, EM.cpp:343)"); return BAMM_ERR_ARG; }
     if (em->prm.W < 2) { set_error("bamm_em_mask: W=1 reads past pos_[n] in the reference (EM.cpp:416)"); return BAMM_ERR_UNSUPPORTED; }

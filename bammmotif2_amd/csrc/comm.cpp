@@ -57,6 +57,8 @@ struct ShmGroup {
     std::atomic<uint32_t> arrived, generation, aborted, attached;
     uint32_t n;
     uint64_t cap;
+    // the join handshake (bamm_comm_init_shm): rank r writes a fresh nonce into hello[r], the creator answers ack[r] = hello[r]
+    std::atomic<unsigned long long> hello[64], ack[64];
     // long long inbox[n][cap] follows
     long long* inbox(uint32_t r) { return reinterpret_cast<long long*>(this + 1) + (size_t)r * cap; }
     // false when the group was aborted or a peer did not arrive within the limit
@@ -82,6 +84,7 @@ struct ShmGroup {
     }
 };
 constexpr uint32_t kShmMagic = 0x42414d4du;
+constexpr uint32_t kShmMaxWorld = 64;
 
 struct bamm_comm {
     ShmGroup* shm = nullptr;                // non-null: host-staged sum between processes (bamm_comm_init_shm)
@@ -237,6 +240,28 @@ static int sum_words(bamm_comm* c, long long* h, size_t n) {
     return BAMM_OK;
 }
 
+// Who a rank of the table is: "same process" must mean the same address space, and a pid alone does not say that -- ranks in
+// different pid namespaces or on different hosts (containers commonly all run as pid 1..20; an RCCL communicator may span
+// nodes) can carry equal pids.  A rank is this process only if the host (hostname + boot id + pid namespace), the pid AND a
+// nonce drawn once per process all match; everything else goes through hipIpcOpenMemHandle, which fails cleanly across hosts.
+struct ProcessId { long long host, nonce; };
+static const ProcessId& process_id() {
+    static const ProcessId id = [] {
+        auto fnv = [](unsigned long long h, const char* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } return h; };
+        unsigned long long h = 1469598103934665603ull;
+        char buf[256];
+        if (gethostname(buf, sizeof buf) == 0) { buf[sizeof buf - 1] = 0; h = fnv(h, buf, strlen(buf)); }
+        if (FILE* f = fopen("/proc/sys/kernel/random/boot_id", "r")) { const size_t n = fread(buf, 1, sizeof buf, f); fclose(f); h = fnv(h, buf, n); }
+        const ssize_t n = readlink("/proc/self/ns/pid", buf, sizeof buf);
+        if (n > 0) h = fnv(h, buf, (size_t)n);
+        unsigned long long r = 0;
+        if (FILE* f = fopen("/dev/urandom", "rb")) { if (fread(&r, sizeof r, 1, f) != 1) r = 0; fclose(f); }
+        r ^= (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count() * 0x9e3779b97f4a7c15ull ^ ((unsigned long long)getpid() << 32);
+        return ProcessId{(long long)(h >> 2), (long long)(r >> 2) | 1ll};          // non-negative: the table travels as a sum
+    }();
+    return id;
+}
+
 static void peer_release(bamm_comm* c) {
     for (uint32_t r = 0; r < kPeerMaxWorld; r++) {
         if (c->peer_map[r] && c->peer_ipc[r]) (void)hipIpcCloseMemHandle(c->peer_map[r]);
@@ -280,14 +305,15 @@ int comm_peer_setup(bamm_comm* c, uint32_t stride_words, int* ready) {
         have_handle = hipIpcGetMemHandle(&handle, c->peer_inbox) == hipSuccess;
         if (!have_handle) (void)hipGetLastError();           // only needed by ranks in other processes (checked below)
     }
-    // row r of the table: [pid, device, pointer, handle present, 8 words of IPC handle, stride]
-    constexpr size_t ROW = 13;
+    // row r of the table: [pid, device, pointer, handle present, 8 words of IPC handle, stride, host id, process nonce]
+    constexpr size_t ROW = 15;
     std::vector<long long> tab((size_t)world * ROW, 0);
     long long* mine = tab.data() + (size_t)me * ROW;
     mine[0] = (long long)getpid(); mine[1] = ctx_device(c->ctx); mine[2] = (long long)(uintptr_t)c->peer_inbox;
     mine[3] = have_handle ? 1 : 0;
     memcpy(mine + 4, &handle, sizeof handle);
     mine[12] = stride_words;
+    mine[13] = process_id().host; mine[14] = process_id().nonce;
     int rc = sum_words(c, tab.data(), tab.size());
     if (rc) { peer_release(c); return rc; }
     for (uint32_t r = 0; r < world && ok; r++) {
@@ -295,7 +321,7 @@ int comm_peer_setup(bamm_comm* c, uint32_t stride_words, int* ready) {
         if (row[12] != (long long)stride_words) { ok = false; why = "the ranks ask for inboxes of different sizes"; break; }
         if (r == me) continue;
         if (row[2] == 0) { ok = false; why = "a peer has no inbox"; break; }
-        if (row[0] == (long long)getpid()) {                 // a rank of this process: its pointer is valid here
+        if (row[0] == (long long)getpid() && row[13] == process_id().host && row[14] == process_id().nonce) {   // a rank of THIS process: its pointer is valid here
             if ((int)row[1] != ctx_device(c->ctx)) {
                 const hipError_t e = hipDeviceEnablePeerAccess((int)row[1], 0);
                 if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { ok = false; why = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); }
@@ -401,64 +427,95 @@ int bamm_comm_init_local(bamm_ctx* const* ctxs, uint32_t n, uint64_t max_words, 
 }
 
 int bamm_comm_init_shm(bamm_ctx* ctx, const char* name, uint32_t rank, uint32_t world, uint64_t max_words, bamm_comm** out) {
-    if (!ctx || !name || !out || world == 0 || rank >= world || max_words == 0 || name[0] != '/') {
-        set_error("bamm_comm_init_shm: bad argument (the name starts with '/')");
+    if (!ctx || !name || !out || world == 0 || rank >= world || max_words == 0 || name[0] != '/' || world > kShmMaxWorld) {
+        set_error("bamm_comm_init_shm: bad argument (the name starts with '/', at most %u ranks)", kShmMaxWorld);
         return BAMM_ERR_ARG;
     }
     *out = nullptr;
     const size_t bytes = sizeof(ShmGroup) + (size_t)world * (size_t)max_words * sizeof(long long);
-    // whoever creates the segment initialises it; the others wait for the magic word
-    bool creator = true;
-    int fd = shm_open(name, O_RDWR | O_CREAT | O_EXCL, 0600);
-    if (fd < 0) { creator = false; fd = shm_open(name, O_RDWR, 0600); }
     const auto t0 = std::chrono::steady_clock::now();
-    while (fd < 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 30.0) {
-        std::this_thread::sleep_for(std::chrono::milliseconds(2));
-        fd = shm_open(name, O_RDWR, 0600);
-    }
-    if (fd < 0) { set_error("bamm_comm_init_shm: cannot open %s", name); return BAMM_ERR_COMM; }
-    if (creator && ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); set_error("bamm_comm_init_shm: cannot size %s", name); return BAMM_ERR_COMM; }
-    if (!creator) {                                          // the creator may not have sized it yet
-        struct stat sb;
-        while (fstat(fd, &sb) == 0 && (size_t)sb.st_size < bytes &&
-               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 30.0)
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        if (fstat(fd, &sb) != 0 || (size_t)sb.st_size < bytes) { close(fd); set_error("bamm_comm_init_shm: %s has another size (another world / capacity?)", name); return BAMM_ERR_COMM; }
-    }
-    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) { set_error("bamm_comm_init_shm: mmap failed"); return BAMM_ERR_COMM; }
-    ShmGroup* g = reinterpret_cast<ShmGroup*>(m);
-    if (creator) {
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    // Rank 0 -- and nobody else -- creates the segment, after removing whatever carries the name (a creator killed before
+    // its shm_unlink leaves the name behind with a stale barrier state in it; names are recycled with pids).  An attacher
+    // cannot tell a stale segment from the new one by looking at it, so it does not try: it writes a fresh nonce into its
+    // hello slot and only a LIVE rank 0 answers (ack = hello), which it does in the segment it created and in no other.  No
+    // answer within a moment: unmap, open the name again (by then rank 0 has replaced it).
+    ShmGroup* g = nullptr;
+    if (rank == 0) {
+        (void)shm_unlink(name);
+        const int fd = shm_open(name, O_RDWR | O_CREAT | O_EXCL, 0600);
+        if (fd < 0) { set_error("bamm_comm_init_shm: cannot create %s", name); return BAMM_ERR_COMM; }
+        if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); shm_unlink(name); set_error("bamm_comm_init_shm: cannot size %s", name); return BAMM_ERR_COMM; }
+        void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { shm_unlink(name); set_error("bamm_comm_init_shm: mmap failed"); return BAMM_ERR_COMM; }
+        g = reinterpret_cast<ShmGroup*>(m);
         g->arrived.store(0); g->generation.store(0); g->aborted.store(0); g->attached.store(0);
+        for (uint32_t r = 0; r < kShmMaxWorld; r++) { g->hello[r].store(0); g->ack[r].store(0); }
         g->n = world; g->cap = max_words;
         g->magic.store(kShmMagic, std::memory_order_release);
-    } else {
-        while (g->magic.load(std::memory_order_acquire) != kShmMagic &&
-               std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 30.0)
-            std::this_thread::sleep_for(std::chrono::milliseconds(1));
-        if (g->magic.load(std::memory_order_acquire) != kShmMagic || g->n != world || g->cap != max_words) {
-            munmap(m, bytes);
-            set_error("bamm_comm_init_shm: %s belongs to another group (world / capacity differ)", name);
-            return BAMM_ERR_COMM;
+        // answer the attachers until all of them have joined (each counts itself in `attached` once it has seen its answer; one
+        // that opened a stale segment first comes back with a new nonce)
+        while (g->attached.load(std::memory_order_acquire) + 1u < world) {
+            for (uint32_t r = 1; r < world; r++) {
+                const unsigned long long h = g->hello[r].load(std::memory_order_acquire);
+                if (h != 0ull && g->ack[r].load(std::memory_order_relaxed) != h) g->ack[r].store(h, std::memory_order_release);
+            }
+            if (elapsed() > 30.0) { g->aborted.store(1, std::memory_order_release); munmap(m, bytes); shm_unlink(name); set_error("bamm_comm_init_shm: the other ranks did not attach to %s", name); return BAMM_ERR_COMM; }
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
         }
+    } else {
+        unsigned long long nonce = (unsigned long long)process_id().nonce ^ ((unsigned long long)rank << 56);
+        std::string why = "rank 0 did not create it";
+        while (!g && elapsed() < 30.0) {
+            const int fd = shm_open(name, O_RDWR, 0600);
+            if (fd < 0) { std::this_thread::sleep_for(std::chrono::milliseconds(2)); continue; }
+            struct stat sb;
+            if (fstat(fd, &sb) != 0 || (size_t)sb.st_size != bytes) {      // not sized yet, or another group's
+                close(fd); why = "it has another size (another world / capacity?)";
+                std::this_thread::sleep_for(std::chrono::milliseconds(2)); continue;
+            }
+            void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            close(fd);
+            if (m == MAP_FAILED) { set_error("bamm_comm_init_shm: mmap failed"); return BAMM_ERR_COMM; }
+            ShmGroup* cand = reinterpret_cast<ShmGroup*>(m);
+            const auto t1 = std::chrono::steady_clock::now();
+            auto waited = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count(); };
+            while (cand->magic.load(std::memory_order_acquire) != kShmMagic && waited() < 0.2) std::this_thread::sleep_for(std::chrono::microseconds(200));
+            bool ok = cand->magic.load(std::memory_order_acquire) == kShmMagic && cand->n == world && cand->cap == max_words;
+            if (ok) {
+                nonce = nonce * 6364136223846793005ull + 1442695040888963407ull;       // a new one per attempt, never 0
+                if (nonce == 0ull) nonce = 1ull;
+                cand->hello[rank].store(nonce, std::memory_order_release);
+                while (cand->ack[rank].load(std::memory_order_acquire) != nonce && waited() < 0.5) std::this_thread::sleep_for(std::chrono::microseconds(200));
+                ok = cand->ack[rank].load(std::memory_order_acquire) == nonce;
+            }
+            if (ok) { g = cand; g->attached.fetch_add(1, std::memory_order_acq_rel); break; }
+            why = "nobody answered in it (a segment left behind by an earlier run?)";
+            munmap(m, bytes);
+            std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+        if (!g) { set_error("bamm_comm_init_shm: cannot join %s: %s", name, why.c_str()); return BAMM_ERR_COMM; }
     }
+    void* m = g;
     bamm_comm* c = new bamm_comm();
     c->ctx = ctx; c->rank = rank; c->world = world; c->shm = g; c->shm_bytes = bytes; c->shm_name = name;
     if (hipSetDevice(ctx_device(ctx)) != hipSuccess ||
         hipHostMalloc((void**)&c->h_sum, (size_t)max_words * sizeof(long long), hipHostMallocDefault) != hipSuccess) {
+        g->aborted.store(1, std::memory_order_release);
         munmap(m, bytes); delete c;
+        if (rank == 0) shm_unlink(name);
         set_error("bamm_comm_init_shm: pinned host buffer could not be allocated");
         return BAMM_ERR_HIP;
     }
-    g->attached.fetch_add(1, std::memory_order_acq_rel);
-    if (!g->barrier(30.0)) {                                 // everybody is attached before anybody may unlink the name
+    if (rank == 0) g->attached.fetch_add(1, std::memory_order_acq_rel);
+    if (!g->barrier(30.0)) {                                 // everybody is attached before the name goes away
         (void)hipHostFree(c->h_sum); munmap(m, bytes); delete c;
-        if (creator) shm_unlink(name);
+        if (rank == 0) shm_unlink(name);
         set_error("bamm_comm_init_shm: the other ranks did not attach to %s", name);
         return BAMM_ERR_COMM;
     }
-    if (creator) shm_unlink(name);                           // the mappings keep the segment alive; no name is left behind
+    if (rank == 0) shm_unlink(name);                         // the mappings keep the segment alive; no name is left behind
     *out = c;
     return BAMM_OK;
 }

@@ -56,7 +56,11 @@ __device__ __forceinline__ void peer_allreduce_tail(PeerArgsK pk, long long* acc
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's accumulator atomics are performed
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // release: the block's accumulator atomics (performed: vmcnt above) are ordered before the ticket for every other
+        // agent-scope observer; acquire: the block that draws the last ticket sees all of them when it reads the totals back.
+        // (One fence per block at the kernel's end; the vmcnt + a relaxed ticket sufficed on one device in every run, but
+        // that leans on gfx9 behaviour the memory model does not promise across XCDs.)
+        const uint32_t t = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         lds[0] = (t + 1u == gridDim.x) ? 1u : 0u;
         lds[1] = 0u;                                         // a lane's deadline passed
     }

@@ -147,6 +147,24 @@ def device_count() -> int:
     return int(n.value)
 
 
+def device_pci_bus_id(device: int) -> str:
+    buf = C.create_string_buffer(32)
+    check(abi.load().bamm_device_pci_bus_id(int(device), buf, 32))
+    return buf.value.decode()
+
+
+def device_can_access_peer(device: int, peer: int) -> bool:
+    can = C.c_int(0)
+    check(abi.load().bamm_device_can_access_peer(int(device), int(peer), C.byref(can)))
+    return bool(can.value)
+
+
+def peer_access_matrix():
+    """[d][p] = device d can address device p's memory (hipDeviceCanAccessPeer), over every visible device."""
+    n = device_count()
+    return [[device_can_access_peer(d, p) for p in range(n)] for d in range(n)]
+
+
 class Context:
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self.lib = abi.load()

@@ -890,6 +890,10 @@ int main(int nargs, char* args[]) {
     // where their results were taken); --debug keeps the orderly teardown for leak checkers.
     if (timing) fprintf(stderr, "[timing-abs] main left at %.4f\n", epoch());
     if (!o.debug) {
+        // (every writer of this file is a scoped std::ofstream / FILE closed where its stage ends; tests/test_cli_gpu.py compares
+        // the files of a --debug run, which takes the orderly way out below, byte for byte with this one's)
+        for (auto& dv : devs)
+            if (dv.comm) { bamm_comm_destroy(dv.comm); dv.comm = nullptr; }      // peers of a sharded run are told, not left waiting
         std::cout.flush(); std::cerr.flush();
         fflush(nullptr);
         _exit(0);

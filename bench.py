@@ -82,6 +82,13 @@ def parse():
                          "included, nothing added between passes: the default on 1 GPU); n >= 1 = a pair around every n-th pass "
                          "(a pair takes 7-8 us of stream time, profiles/r04_timing_every_cost.txt; 8 is the default with "
                          "N > 1, where the interval of -1 would include the collective); 0 = none")
+    ap.add_argument("--no-selftest-comm", action="store_true",
+                    help="N > 1: skip the communicator self-test in front of the timed region (3 passes through the RCCL collective and "
+                         "3 through the in-kernel all-reduce on handles of their own, model hashes compared across the ranks)")
+    ap.add_argument("--phase-cap-scale", type=float, default=1.0,
+                    help="scales the wall-clock caps of the watchdog (a child process started before anything touches the GPU; it "
+                         "kills this process when a phase -- set-up, communicator, self-test, warm-up, timed region, extras -- "
+                         "does not end: a collective that never returns costs one line, not the launcher's own time-out); 0 = no watchdog")
     ap.add_argument("--allreduce-iters", type=int, default=200, help="N > 1: bare all-reduces of the accumulator timed for `attribution`")
     ap.add_argument("--no-fused-update", action="store_true",
                     help="a k_update launch after every pass instead of the update fused into the next pass's kernel")
@@ -425,6 +432,135 @@ def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_ma
             pass
 
 
+WATCHDOG_SRC = r"""
+import os, select, signal, sys, time
+pid, tag = int(sys.argv[1]), sys.argv[2]
+deadline, phase, buf = None, "start", b""
+while True:
+    timeout = None if deadline is None else max(0.0, deadline - time.time())
+    ready, _, _ = select.select([0], [], [], timeout)
+    if ready:
+        chunk = os.read(0, 4096)             # unbuffered: select() must see everything that is still unread
+        if not chunk:
+            sys.exit(0)                      # the pipe closed: the bench ended (or died) by itself
+        buf += chunk
+        while b"\n" in buf:
+            line, buf = buf.split(b"\n", 1)
+            cap, phase = line.decode().split(" ", 1)
+            deadline = None if float(cap) <= 0 else time.time() + float(cap)
+    elif deadline is not None and time.time() >= deadline:
+        sys.stderr.write("[bench watchdog] %s: phase '%s' did not end within its wall-clock cap -- killing pid %d\n" % (tag, phase, pid))
+        sys.stderr.flush()
+        try:
+            os.kill(pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        sys.exit(3)
+"""
+
+
+class Watchdog:
+    """A hard wall-clock cap per phase, enforced from OUTSIDE the process that may be stuck: a child started before this
+    process touches the GPU (a fresh interpreter, never an exec of a GPU process) reads `cap phase` lines from a pipe and
+    kills this process (SIGKILL: the launcher sees a failed rank and ends the others) when a phase outlives its cap."""
+    def __init__(self, tag, scale=1.0):
+        import subprocess
+        self.scale = scale
+        self.proc = None
+        if scale > 0:
+            self.proc = subprocess.Popen([sys.executable, "-c", WATCHDOG_SRC, str(os.getpid()), tag], stdin=subprocess.PIPE, text=True)
+
+    def phase(self, name, cap_s):
+        if self.proc is not None and self.proc.poll() is None:
+            try:
+                self.proc.stdin.write("%g %s\n" % (cap_s * self.scale, name))
+                self.proc.stdin.flush()
+            except (BrokenPipeError, OSError):
+                pass
+
+    def close(self):
+        if self.proc is not None:
+            try:
+                self.proc.stdin.close()
+                self.proc.wait(timeout=5)
+            except Exception:
+                pass
+            self.proc = None
+
+
+def topology(bm, devices):
+    """What a first multi-GPU run wants on record beside its numbers: where each rank's device sits and who reaches whom."""
+    try:
+        n = bm.device_count()
+        return {"visible_devices": n, "pci_bus_id": [bm.device_pci_bus_id(d) for d in range(n)],
+                "can_access_peer": bm.peer_access_matrix(), "ranks_on_devices": list(devices)}
+    except Exception as e:                                   # a record, never a reason to lose the line
+        return {"error": repr(e)}
+
+
+def selftest_comm(bm, ctx, seqs, comm, wl, args, gather, sync):
+    """In front of the timed region, N > 1: three passes from the seed through the RCCL collective and three through the
+    in-kernel all-reduce, each on a handle of its own, and the models' hashes compared across the ranks -- a collective
+    that sums nothing, inboxes that map but do not deliver, ranks that disagree: one line that says which and why.
+    gather(x): list of every rank's x (a collective).  Every rank walks the same sequence of collectives whatever fails
+    locally (a failure is kept, not raised)."""
+    W, K = wl["W"], wl["K"]
+    out = {}
+    for kind in ("rccl", "peer"):
+        why, em, sha = [], None, None
+
+        def step(what, f):
+            if why:
+                return None
+            try:
+                return f()
+            except Exception as e:
+                why.append(f"{what}: {e!r}")
+                return None
+
+        def make():
+            ctx.set_tuning(peer_allreduce=1 if kind == "peer" else 0)
+            e = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=8, n_seqs_bound=args.nseq)
+            e.set_comm(comm)
+            return e
+
+        try:
+            em = step("create", make)
+            fails = gather(why[0] if why else None)
+            if any(fails):
+                out[kind] = {"ok": False, "why": "; ".join(f"rank {r}: {w}" for r, w in enumerate(fails) if w)}
+                continue
+            res = step("vote", lambda: em.comm_mode())       # collective on first use
+            modes = gather((why[0] if why else None, res[0] if res else None, res[1] if res else None))
+            if any(m[0] for m in modes):
+                out[kind] = {"ok": False, "why": "; ".join(f"rank {r}: {m[0]}" for r, m in enumerate(modes) if m[0])}
+                continue
+            if kind == "peer" and any(m[1] != 2 for m in modes):
+                out[kind] = {"ok": False, "why": "not agreed: " + "; ".join(sorted({str(m[2]) for m in modes if m[1] != 2}))}
+                continue
+            step("3 passes", lambda: em.iterate(3))
+            step("sync", sync)
+            v = step("read-back", lambda: em.getV())
+            sha = hashlib.sha256(v.tobytes()).hexdigest()[:16] if v is not None else None
+            got = gather((why[0] if why else None, sha))
+            if any(g[0] for g in got):
+                out[kind] = {"ok": False, "why": "; ".join(f"rank {r}: {g[0]}" for r, g in enumerate(got) if g[0])}
+            elif len({g[1] for g in got}) != 1:
+                out[kind] = {"ok": False, "why": "the ranks' models differ after 3 passes: " + ", ".join(f"rank {r}: {g[1]}" for r, g in enumerate(got))}
+            else:
+                out[kind] = {"ok": True, "model_sha": got[0][1]}
+        finally:
+            try:
+                ctx.set_tuning(peer_allreduce=0)
+                if em is not None:
+                    em.close()
+            except Exception:
+                pass
+    if out.get("rccl", {}).get("ok") and out.get("peer", {}).get("ok") and out["rccl"]["model_sha"] != out["peer"]["model_sha"]:
+        out["peer"] = {"ok": False, "why": "the in-kernel all-reduce and the collective end on different models (%s / %s)" % (out["peer"]["model_sha"], out["rccl"]["model_sha"])}
+    return out
+
+
 def first_call(bm, ctx, seqs, wl, args, sync):
     """The FIRST handle of the process, nothing warmed up (no kernel of the library has run yet): what bamm_em_create costs
     and what the first optimize() call costs -- code-object loads, first-use allocations and the slow early passes included.
@@ -480,6 +616,8 @@ def main_inprocess(args, result_fd):
     own RCCL communicator (ncclCommInitAll).  ctypes releases the GIL during the calls, so the N iterate() calls
     run side by side.  Nothing here touches torch."""
     import threading
+    wd = Watchdog("in-process ranks", args.phase_cap_scale)  # before anything touches the GPU
+    wd.phase("set-up (build, synthetic set, packing, resident shards)", 900)
     import bammmotif2_amd as bm
     from bammmotif2_amd import build
 
@@ -517,6 +655,7 @@ def main_inprocess(args, result_fd):
         ctxs.append(ctx); seqs.append(ss); ems.append(em)
     comms = []
     allreduce_kind = "none"
+    wd.phase("communicator (ncclCommInitAll)", 180)
     if N > 1 or args.force_dist:
         if args.local_ranks:
             comms = bm.Comm.init_local(ctxs, 4 ** (K + 1) * W + 3)
@@ -536,21 +675,40 @@ def main_inprocess(args, result_fd):
     gate = threading.Barrier(N)
     dts, errors, ar_us = [0.0] * N, [None] * N, [None] * N
     peer_out, peer_tmp = [None] * N, [0.0] * N
+    selftest, gather_tmp = [None] * N, [None] * N
 
     def worker(r):
         try:
+            if comms and N > 1 and not args.no_selftest_comm:
+                def gather(x, r=r):
+                    gather_tmp[r] = x
+                    gate.wait()
+                    got = list(gather_tmp)
+                    gate.wait()
+                    return got
+                if r == 0:
+                    wd.phase("communicator self-test (3 passes over RCCL, 3 over the in-kernel all-reduce)", 180)
+                selftest[r] = selftest_comm(bm, ctxs[r], seqs[r], comms[r], wl, args, gather, ctxs[r].sync)
+                if not selftest[r]["rccl"]["ok"]:
+                    raise RuntimeError("communicator self-test failed: " + selftest[r]["rccl"]["why"])
+            if r == 0:
+                wd.phase("warm-up passes", 180)
             ems[r].iterate(args.warmup)
             ctxs[r].sync()
             gate.wait()                                      # barrier + synchronize on both sides of the timed region
+            if r == 0:
+                wd.phase("timed region", 120 + 0.1 * args.steps)
             t0 = time.perf_counter()
             ems[r].iterate(args.steps)
             ctxs[r].sync()
             dts[r] = time.perf_counter() - t0
             gate.wait()
+            if r == 0:
+                wd.phase("after the timed region (bare all-reduce timing, in-kernel all-reduce extra)", 600)
             if comms and not args.local_ranks:               # outside the timed region: what the bare collective costs
                 ar_us[r] = comms[r].time_allreduce(4 ** (K + 1) * W + 3, args.allreduce_iters)
                 gate.wait()
-            if comms and N > 1 and not args.no_extras:
+            if comms and N > 1 and not args.no_extras and not (selftest[r] and not selftest[r]["peer"]["ok"]):
                 def rmax(x, r=r):
                     peer_tmp[r] = x
                     gate.wait()
@@ -582,7 +740,14 @@ def main_inprocess(args, result_fd):
     kernel_ms, launches = max(kernel)                        # the slowest rank's sequence kernel
     llh, _, _ = ems[0].trace()
     name, mixed = kernel_label(ems[0], K)
-    extras = {"ranks_agree_bitwise": agree, "ms_per_step_per_rank": [d / args.steps * 1e3 for d in dts]}
+    extras = {"ranks_agree_bitwise": agree, "ms_per_step_per_rank": [d / args.steps * 1e3 for d in dts],
+              "topology": topology(bm, devices)}
+    for rk in ranks:
+        rk["pci_bus_id"] = (extras["topology"].get("pci_bus_id") or [None] * (rk["device"] + 1))[rk["device"]]
+    if selftest[0] is not None:
+        extras["selftest_comm"] = selftest[0]
+        if not selftest[0]["peer"]["ok"]:
+            extras["ms_per_step_peer_allreduce"] = "unavailable: " + selftest[0]["peer"]["why"]
     if comms:
         extras["attribution"] = attribution(dt / args.steps * 1e6, [k[0] / max(k[1], 1) * 1e3 for k in kernel], ar_us, args)
     if peer_out[0] is not None:
@@ -590,6 +755,7 @@ def main_inprocess(args, result_fd):
         shas = {(p.get("peer_allreduce") or {}).get("model_sha") for p in peer_out}
         if len(shas) > 1:
             extras["ms_per_step_peer_allreduce"] = "unavailable: the ranks' models differ after the in-kernel all-reduce"
+    wd.phase("from-seed figures, CPU baseline, report", 1200)
     if N == 1 and not comms and not args.no_extras:
         extras.update(from_seed_extras(bm, ctxs[0], seqs[0], wl, args, ctxs[0].sync))
     merge_first_call(extras, first)
@@ -607,6 +773,7 @@ def main_inprocess(args, result_fd):
         c.close()
     for ctx in ctxs:
         ctx.close()
+    wd.close()
 
 
 def main():
@@ -624,6 +791,8 @@ def main():
     if world != max(args.gpus, 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (torch.distributed.run "
                          f"--nproc-per-node {args.gpus}) or drop the launcher and let bench.py run them in-process")
+    wd = Watchdog(f"rank {rank} of {world}", args.phase_cap_scale)     # before anything touches the GPU
+    wd.phase("set-up (imports, build, process group, synthetic set, packing, resident shard)", 900)
 
     import torch
     import torch.distributed as dist
@@ -670,6 +839,7 @@ def main():
     keep = []
     allreduce_kind = "none"
     rank_info = dict(rank=rank, world=world, rccl_version=None)
+    wd.phase("communicator (unique id over the process group, ncclCommInitRank)", 180)
     if use_dist and args.dist_backend == "nccl" and not args.torch_allreduce:
         # the library's own collective: ncclAllReduce(int64, sum) on the context's stream, no Python in the
         # loop.  Rank 0's unique id travels over the torch process group that also serves the barriers.
@@ -734,15 +904,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather(x):
+        got = [None] * world
+        dist.all_gather_object(got, x)
+        return got
+
+    selftest = None
+    if use_dist and world > 1 and keep and isinstance(keep[0], bm.Comm) and not args.no_selftest_comm:
+        wd.phase("communicator self-test (3 passes over the collective, 3 over the in-kernel all-reduce)", 180)
+        with torch.cuda.stream(tstream):
+            selftest = selftest_comm(bm, ctx, seqs, keep[0], wl, args, gather, torch.cuda.synchronize)
+        if not selftest["rccl"]["ok"]:                       # the same verdict on every rank (it came out of a gather)
+            if rank == 0:
+                print("[bench] communicator self-test failed: " + selftest["rccl"]["why"], file=sys.stderr)
+            raise SystemExit(4)
+
     # one HIP event pair around all passes of the timed call (1 GPU), or a pair around every 8th pass (N > 1): --timing-every
     em.set_kernel_timing(args.timing_every)
     with torch.cuda.stream(tstream):       # the context's stream is torch's current one for the callback
+        wd.phase("warm-up passes", 180)
         em.iterate(args.warmup)
         barrier()
+        wd.phase("timed region", 120 + 0.1 * args.steps)
         t0 = time.perf_counter()
         em.iterate(args.steps)
         barrier()
         dt = time.perf_counter() - t0
+    wd.phase("after the timed region (reductions, bare all-reduce timing, extras, CPU baseline, report)", 1800)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -762,7 +950,9 @@ def main():
     llh, vdiff, _ = em.trace()
     kernel_name, mixed = kernel_label(em, K)
     # what proves the N ranks: every rank's communicator view, gathered on rank 0
+    topo = topology(bm, [local_rank])
     me = {**rank_info, "device": local_rank, "device_name": ctx.device_name(), "n_seqs": seqs.n_seqs,
+          "pci_bus_id": (topo.get("pci_bus_id") or [None] * (local_rank + 1))[local_rank],
           "kernel_us": kernel_ms / max(launches, 1) * 1e3, "allreduce_us": my_ar_us}
     ranks = [me]
     if use_dist and world > 1:
@@ -771,7 +961,11 @@ def main():
         ranks = gathered
         if sorted(g["rank"] for g in ranks) != list(range(world)) or any(g["world"] != world for g in ranks):
             raise SystemExit(f"bench.py: the ranks do not form a world of {world}: {ranks}")
-    if use_dist and world > 1 and keep and isinstance(keep[0], bm.Comm) and not args.no_extras:
+    if selftest is not None:
+        extras["selftest_comm"] = selftest
+        if not selftest["peer"]["ok"]:
+            extras["ms_per_step_peer_allreduce"] = "unavailable: " + selftest["peer"]["why"]
+    if use_dist and world > 1 and keep and isinstance(keep[0], bm.Comm) and not args.no_extras and not (selftest and not selftest["peer"]["ok"]):
         def rmax(x):
             t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -783,6 +977,8 @@ def main():
         if len(set(shas)) > 1:
             extras["ms_per_step_peer_allreduce"] = "unavailable: the ranks' models differ after the in-kernel all-reduce"
     if use_dist:
+        topo["ranks_on_devices"] = [g["device"] for g in ranks]
+        extras["topology"] = topo
         extras["attribution"] = attribution(dt / args.steps * 1e6, [g["kernel_us"] for g in ranks], [g["allreduce_us"] for g in ranks], args)
         slow = max(ranks, key=lambda g: g["kernel_us"])                # the roofline line prices the slowest rank's kernel
         kernel_ms, launches = slow["kernel_us"] * 1e-3 * max(launches, 1), max(launches, 1)
@@ -801,6 +997,7 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    wd.close()
 
 
 if __name__ == "__main__":

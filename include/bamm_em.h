@@ -292,6 +292,12 @@ int  bamm_rand_stream_draws(uint32_t seed, uint64_t skip, int use_jump, uint32_t
 int  bamm_em_comm_mode(bamm_em* em, int* mode, char* note, size_t note_cap);
 /* HIP devices visible to the process (0 and BAMM_ERR_NO_DEVICE when there is none)                               */
 int  bamm_device_count(int* n);
+/* Where a device sits and whom it reaches -- what a first multi-GPU run wants on record beside its numbers: the PCI bus id
+ * ("0000:c1:00.0") of a visible device, and whether `device` can address `peer`'s memory directly (hipDeviceCanAccessPeer:
+ * xGMI or PCIe peer-to-peer; the in-kernel all-reduce of bamm_em_comm_mode 2 and RCCL's direct rings need it).  No context is
+ * created and nothing is enabled.                                                                                   */
+int  bamm_device_pci_bus_id(int device, char* buf, size_t cap);
+int  bamm_device_can_access_peer(int device, int peer, int* can);
 
 /* results (each synchronises the stream)                                                     */
 int  bamm_em_get_v(bamm_em* em, float* v_flat);        /* Motif::getV()                       */

@@ -90,3 +90,23 @@ def test_two_processes_under_the_launcher_with_the_library_communicator():
     assert a["kernel_us"] > 0 and a["allreduce_us"] > 0 and a["step_us"] >= a["kernel_us"]
     assert isinstance(j["ms_per_step_peer_allreduce"], float), j["ms_per_step_peer_allreduce"]
     assert len(j["peer_allreduce"]["model_sha"]) == 16
+    # the first-contact kit: the communicator self-test ran in front of the timed region (both ways of summing over the
+    # ranks end on one model), and the line says where the ranks' devices sit and who reaches whom
+    st = j["selftest_comm"]
+    assert st["rccl"]["ok"] and st["peer"]["ok"] and st["rccl"]["model_sha"] == st["peer"]["model_sha"], st
+    topo = j["topology"]
+    assert topo["visible_devices"] >= 1 and len(topo["pci_bus_id"]) == topo["visible_devices"]
+    assert len(topo["can_access_peer"]) == topo["visible_devices"] and topo["can_access_peer"][0][0] is True
+    assert all(r["pci_bus_id"] == topo["pci_bus_id"][r["device"]] and ":" in r["pci_bus_id"] for r in j["ranks"])
+
+
+@pytest.mark.timeout(600)
+def test_first_call_figures_on_one_gpu():
+    """from_seed.first_create_ms / first_call_ms: the first handle of the process, nothing warmed up."""
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--nseq", "50000", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    fs = j["from_seed"]
+    assert fs["first_call_passes"] == 20 and 0 < fs["first_call_ms"] < 200 and 0 < fs["first_create_ms"] < 500, fs
+    assert fs["ms_per_step_iterate"] > 0 and fs["ms_per_step_optimize"] > 0

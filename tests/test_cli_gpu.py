@@ -287,6 +287,25 @@ def test_cli_device_packing_and_host_packing_write_the_same_files(tmp_path, gpu_
         assert outs[0][name] == outs[1][name], name
 
 
+@pytest.mark.parametrize("flags", [["--FDR", "-m", "3", "-n", "3", "--saveBaMMs", "--saveInitialBaMMs"], ["--scoreSeqset", "--saveLogOdds"], ["--advanceEM", "--saveBaMMs"]],
+                         ids=["fdr", "score", "mask"])
+def test_cli_fast_exit_leaves_the_same_files_as_the_orderly_teardown(flags, tmp_path, gpu_ctx):
+    """The command leaves through _exit(0) once everything is written (host/main.cpp: no destructors, no atexit handlers);
+    --debug takes the orderly way out.  Every output file byte for byte: a writer still holding a buffer at the fast exit
+    would show here (round-4 advice)."""
+    build.build_host()
+    outs = []
+    for extra in ([], ["--debug"]):
+        out = tmp_path / ("fast" if not extra else "orderly")
+        r = subprocess.run([build.CLI, str(out), FASTA, "--PWMFile", MEME, "--EM", "-k", "2", "--maxPWM", "1"] + flags + extra,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr + r.stdout[-2000:]
+        outs.append({p.name: p.read_bytes() for p in sorted(out.iterdir())})
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) >= 3
+    for name in outs[0]:
+        assert outs[0][name] == outs[1][name], name
+
+
 @pytest.mark.parametrize("flags", [["--FDR", "-m", "3", "-n", "3"], ["--scoreSeqset"], ["--FDR", "-m", "2", "-n", "4", "--genericNeg"]],
                          ids=["fdr", "score", "fdr_generic"])
 def test_cli_device_sampler_and_host_sampler_write_the_same_files(flags, tmp_path, gpu_ctx):
