@@ -1005,9 +1005,12 @@ int verify_comm(bamm_em* em) {
     em->peer_on = false;
     if (world > 1 && want_peer == (long long)world) {        // (asked for on every rank: the set-up below is a collective)
         constexpr uint32_t kStride = 2056;                   // entries per (slot, source): 2048 top-order cells + 3 statistics, padded
-        // (k_em_mix carries the tail: K = 2, both strands, the widths the planner gives mixed rows -- the bench / config 2 / 3 / 5
-        // shapes; in k_em_grp the same code cost the single-GPU pass 0.8 % and was taken out again)
-        const bool can = em->ebuckets.size() == 1u && em->ebuckets[0].grouped && (em->ebuckets[0].layout & 8u) != 0u &&
+        // (the tail is built into k_em_mix -- K = 2, both strands, the widths the planner gives mixed rows: the bench / config
+        // 2 / 3 / 5 shapes -- and into k_em_grp's classes up to BAMM_FUSE_MAX_M positions per lane at K <= 2: single strand, k = 0 / 1,
+        // other widths)
+        const EmBucket& eb0 = em->ebuckets[0];
+        const bool can = em->ebuckets.size() == 1u && eb0.grouped && eb0.mclass != kLongClass &&
+                         ((eb0.layout & 8u) != 0u || (em->prm.K <= 2u && kMClasses[eb0.mclass] <= BAMM_FUSE_MAX_M)) &&
                          world <= kPeerMaxWorld && em->cells + 3u <= kStride && !em->allreduce;
         int ready = 0;
         // (every rank goes through the set-up, able or not: it is a collective; the vote inside it counts mapped inboxes)
@@ -1033,7 +1036,7 @@ int verify_comm(bamm_em* em) {
             em->peer_note.clear();
         } else {
             em->peer_note = !ready ? std::string("inboxes: ") + comm_peer_why(em->comm)
-                          : !can ? "this handle's pass is not one launch of the mixed-row kernel (K = 2, both strands, W = 13, 14, 16, 17 or 20, one length class)"
+                          : !can ? "this handle's pass is not one launch of a grouped-column kernel built with the tail (K <= 2, one length class of at most 1024 positions, no N-rich sequences beside it)"
                                  : "another rank could not";
         }
     } else if (em->ctx->use_peer_allreduce) {

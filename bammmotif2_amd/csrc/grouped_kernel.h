@@ -230,7 +230,10 @@ __device__ __forceinline__ void grp_chain(const uint32_t (&ra)[M], float (&U)[M]
 #undef BAMM_GRP_QUAD
 }
 
-template <int M, int G, int KG, bool ACCUM, bool WRITE_R, int THREADS>
+// WITH_TAIL: the instantiation a launch takes when its pass ends in the in-kernel all-reduce (peer.world > 1).  A variant of
+// its own, not a run-time branch of the one kernel: compiled into the single-GPU kernel the tail's mere presence cost the
+// k = 1 pass 0.8 % (register allocation of the sequence loop; profiles/r05_ab_peer_check_behind_prologue_and_grp_tail.txt).
+template <int M, int G, int KG, bool ACCUM, bool WRITE_R, int THREADS, bool WITH_TAIL = false>
 __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     static_assert(M >= G, "a group must not span more than two lanes");
     // K = 3 (the only order with two columns per 5-mer row): odds and count tables of 10+ groups leave no LDS
@@ -243,6 +246,8 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     // pass: a CU retires one scattered device-scope atomic per ~18 ns (tools/atomic_scatter_bench.hip), and a
     // sequence issued 14-19 of them.  The sequence record carries 10-bit y fields (Y = 256).
     constexpr bool FIXG = (KG - G == 3);
+    // the in-kernel all-reduce (update_kernel.h: peer_allreduce_tail) is built into the classes that carry the fused update
+    constexpr bool PEER = WITH_TAIL && ACCUM && !FIXG && M <= BAMM_FUSE_MAX_M;
     if (ga.e.stop != nullptr && *ga.e.stop != 0u) return;    // optimize(): the stop rule fired in an earlier pass
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const EmKernelArgs& a = ga.e;
@@ -346,6 +351,13 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
     }
     __syncthreads();
 
+    if constexpr (PEER) {                                    // an earlier launch gave up waiting for a peer: nothing is added any more
+        // (checked behind the prologue, where the scalar round trip through the kernel-argument segment is hidden: mixed_kernel.h)
+        const __attribute__((address_space(4))) GrpKernelArgs* kq =
+            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        if (kq->peer.world > 1u && *kq->peer.err != 0u) return;
+    }
     const float q = fused_now ? q_fused : *a.q;
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles
@@ -797,6 +809,18 @@ __global__ void __launch_bounds__(THREADS) k_em_grp(GrpKernelArgs ga) {
         for (uint32_t w = 0; w < waves_per_block; w++) acc += stat_lds[w * 3 + threadIdx.x];
         acc_add_stat(a.acc, W * Y, threadIdx.x, acc);
     }
+    if constexpr (PEER) {
+        // in-kernel all-reduce: the last block to get here sums the GPUs' totals.  Its arguments are read from the
+        // kernel-argument segment HERE, through a pointer the compiler cannot see through (as k_em_mix does: as ordinary
+        // arguments they lived in SGPRs across the sequence loop and cost it 0.8 %, profiles/r04_ab_peer_tail_as_arguments.txt)
+        const __attribute__((address_space(4))) GrpKernelArgs* kq =
+            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        if (kq->peer.world > 1u) {
+            __syncthreads();                                 // the LDS is nobody's any more
+            peer_allreduce_tail(&kq->peer, kq->e.acc, reinterpret_cast<uint32_t*>(lds_raw));
+        }
+    }
 }
 
 template <int M, int G, int KG, int THREADS>
@@ -813,6 +837,14 @@ int launch_variant(bool accum, bool write_r, const GrpKernelArgs& a, uint32_t bl
             if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, false, true, THREADS>));
             hipLaunchKernelGGL((k_em_grp<M, G, KG, false, true, THREADS>), dim3(blocks), dim3(threads), lds, st, a);
         } else if (accum) {
+            if constexpr (KG - G != 3 && M <= BAMM_FUSE_MAX_M) {             // the classes built with the all-reduce tail
+                if (a.peer.world > 1u) {
+                    if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS, true>), lds))) return rc;
+                    hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS, true>), dim3(blocks), dim3(threads), lds, st, a);
+                    return BAMM_OK;
+                }
+            }
+            if (a.peer.world > 1u) { set_error("grouped kernel: this class is not built with the in-kernel all-reduce"); return BAMM_ERR_UNSUPPORTED; }
             if ((rc = allow_lds(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>), lds))) return rc;
             if (blocks == kPrimeOnly) return prime_kernel(reinterpret_cast<const void*>(&k_em_grp<M, G, KG, true, false, THREADS>));
             hipLaunchKernelGGL((k_em_grp<M, G, KG, true, false, THREADS>), dim3(blocks), dim3(threads), lds, st, a);

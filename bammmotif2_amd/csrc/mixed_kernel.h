@@ -43,12 +43,6 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     constexpr uint32_t R6N = 4096u, R6V0 = R6N + 1u, R6T = R6V0 + V;
     constexpr uint32_t Y = 64u, Ys = 65u;                      // K = 2
     if (ga.e.stop != nullptr && *ga.e.stop != 0u) return;    // optimize(): the stop rule fired in an earlier pass
-    if constexpr (ACCUM) {                                   // in-kernel all-reduce: an earlier launch gave up waiting for a peer
-        const __attribute__((address_space(4))) GrpKernelArgs* kq =
-            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kq));
-        if (kq->peer.world > 1u && *kq->peer.err != 0u) return;
-    }
     extern __shared__ __align__(16) unsigned char lds_raw[];
     BAMM_PHASE(0);
     const EmKernelArgs& a = ga.e;
@@ -139,6 +133,16 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     }
 
     BAMM_PHASE(2);                                           // tables built, counts zeroed
+    if constexpr (ACCUM) {
+        // in-kernel all-reduce: an earlier launch gave up waiting for a peer -- nothing is added any more (the prologue above
+        // only read; block 0's publication of the model it computed from sums that never completed is as invalid as the handle,
+        // whose next read fails with BAMM_ERR_COMM).  Checked HERE, not at the entry: the scalar round trip through the
+        // kernel-argument segment is then behind the table build instead of in front of the first sequence fetch.
+        const __attribute__((address_space(4))) GrpKernelArgs* kq =
+            (const __attribute__((address_space(4))) GrpKernelArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        if (kq->peer.world > 1u && *kq->peer.err != 0u) return;
+    }
     const float q = (ACCUM && ga.fused) ? q_fused : *a.q;
     const float one_minus_q = 1.0f - q;
     const uint32_t lane_b = (uint32_t)lane / T, lane_t = (uint32_t)lane - lane_b * T;     // fix-lane roles: (row, group)

@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--len", type=int, default=200, dest="L0")
     ap.add_argument("--width", type=int, default=20)
     ap.add_argument("--order", type=int, default=2)
+    ap.add_argument("--config", default=None, choices=["c2", "c3", "c4", "c5"],
+                    help="a named BASELINE.json configuration instead of --nseq/--len/--width/--order: c2 = 50k x 200 bp W=20 k=2, "
+                         "c3 = 1M x 200 bp W=20 k=2 (the default, the headline), c4 = 1M x 500 bp W=30 k=4 (12 warm-up + 12 timed passes "
+                         "unless --steps/--warmup are given), c5 = the shape of config 5's runs, 200k x 200 bp W=20 k=2")
     ap.add_argument("--ss", action="store_true", help="single strand (default: both strands, L = 2*L0+1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=200000, help="sequences in the CPU-baseline sample (~15 s of host work)")
@@ -96,6 +100,15 @@ def parse():
                     help="gloo stages the fused buffer through the host: lets 2 ranks share ONE GPU (self-test of "
                          "the N>1 logic on a 1-GPU box; never used for reported numbers)")
     args = ap.parse_args()
+    if args.config:
+        given = set(a.split("=")[0] for a in sys.argv[1:] if a.startswith("--"))
+        shape = {"c2": (50_000, 200, 20, 2), "c3": (1_000_000, 200, 20, 2), "c4": (1_000_000, 500, 30, 4), "c5": (200_000, 200, 20, 2)}[args.config]
+        args.nseq, args.L0, args.width, args.order = shape
+        if args.config == "c4":                              # profiles/r04_c4_bench.json's timed region
+            if "--steps" not in given:
+                args.steps = 12
+            if "--warmup" not in given:
+                args.warmup = 12
     if args.timing_every is None:
         args.timing_every = -1 if args.gpus <= 1 else 8
     return args

@@ -286,9 +286,10 @@ int  bamm_rand_stream_draws(uint32_t seed, uint64_t skip, int use_jump, uint32_t
  * no separate flag), collects the peers' entries as they arrive and leaves the sum in the accumulator, in place: no
  * collective launch behind the pass.  Same integers, same model.  Every poll is bounded ("peer_timeout_ms", default
  * 2000): a block that waits in vain raises a device flag that turns the handle's later launches into no-ops, and the
- * next result read from the handle fails with BAMM_ERR_COMM.  Applies to handles whose pass is ONE launch of the
- * mixed-row kernel (K = 2, both strands, W = 13, 14, 16, 17 or 20, one length class: the shapes of BASELINE configs
- * 2, 3 and 5) on 2..8 ranks; the ranks vote, and one that cannot keeps all of them on mode 1 (`note` then says why).  Collective on first use: every rank calls it (or starts its first pass). */
+ * next result read from the handle fails with BAMM_ERR_COMM.  Applies to handles whose pass is ONE launch of a
+ * grouped-column kernel built with the tail -- the mixed-row kernel (K = 2, both strands, W = 13, 14, 16, 17 or 20: the shapes
+ * of BASELINE configs 2, 3 and 5) and the uniform-row kernel at K <= 2 (single strand, k = 0 / 1, other widths) -- over one
+ * length class of at most 1024 positions, on 2..8 ranks; the ranks vote, and one that cannot keeps all of them on mode 1 (`note` then says why).  Collective on first use: every rank calls it (or starts its first pass). */
 int  bamm_em_comm_mode(bamm_em* em, int* mode, char* note, size_t note_cap);
 /* HIP devices visible to the process (0 and BAMM_ERR_NO_DEVICE when there is none)                               */
 int  bamm_device_count(int* n);

@@ -22,15 +22,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _local_ranks(n, c, orc, calls, peer=True, timeout_ms=None, blocks=None):
+# shapes whose pass is ONE launch of a kernel built with the tail: the mixed-row kernel (layout 8: the bench / config 2 / 3 / 5
+# shapes), and k_em_grp's uniform rows -- the same shape with the layout forced, k = 1, and a single-stranded set
+SHAPES = {
+    "mix_k2_ds": (dict(SMALL_CASES[6]), 8),
+    "grp_k2_ds_uniform_rows": (dict(SMALL_CASES[6]), 3),
+    "grp_k1_ds": (dict(name="peer_k1", N=200, L0=200, W=12, K=1, seed=31), -1),
+    "grp_k2_ss": (dict(name="peer_ss", N=220, L0=200, W=20, K=2, ss=True, seed=32), -1),
+}
+
+
+def _local_ranks(n, c, orc, calls, peer=True, timeout_ms=None, blocks=None, layout=8):
     """n contexts on device 0, the sequences sharded over them, the host-staged communicator for whatever still goes
     through a collective (the set-up votes), peer_allreduce on every context."""
     seq, kmer, off, vbg = c.encode(orc)
     pk = bm.PackedSeqs.from_kmers(kmer, off)
     ctxs = [bm.Context(0) for _ in range(n)]
     for x in ctxs:
-        x.set_tuning(peer_allreduce=int(peer), group_layout=8)      # mixed rows (the kernel built with the tail): the planner
-                                                                    # takes them by itself only for tens of thousands of sequences
+        x.set_tuning(peer_allreduce=int(peer), group_layout=layout)   # 8 = mixed rows: the planner takes them by itself only
+                                                                      # for tens of thousands of sequences
         if timeout_ms:
             x.set_tuning(peer_timeout_ms=timeout_ms)
         x.set_launch(blocks or max(1, 224 // n), 0)           # the ranks' kernels are resident side by side: they wait for each other
@@ -65,14 +75,16 @@ def _local_ranks(n, c, orc, calls, peer=True, timeout_ms=None, blocks=None):
 
 
 @pytest.mark.parametrize("n", [2, 3])
-def test_ranks_on_one_device_equal_one_rank_bit_for_bit(n, gpu_ctx, orc):
-    c = Case(**SMALL_CASES[6])                               # config 2's shape: K = 2, W = 20, both strands, one length class
-    gpu_ctx.set_tuning(group_layout=8)
+@pytest.mark.parametrize("shape", list(SHAPES), ids=list(SHAPES))
+def test_ranks_on_one_device_equal_one_rank_bit_for_bit(shape, n, gpu_ctx, orc):
+    spec, layout = SHAPES[shape]
+    c = Case(**spec)
+    gpu_ctx.set_tuning(group_layout=layout)
     try:
         one, ss, *_ = make_em(gpu_ctx, c, orc, optimizeQ=True, max_iterations=60)
     finally:
         gpu_ctx.set_tuning(group_layout=-1)
-    assert one.plan_mixed() == c.N
+    assert one.plan_mixed() == (c.N if layout == 8 else 0) and one.plan()[1] == 0       # one grouped launch, mixed rows or uniform ones
     one.iterate(7)
     it = one.optimize()
     want = (one.getV(), one.getQ(), one.trace()[0], it, one.getCounts())
@@ -84,7 +96,7 @@ def test_ranks_on_one_device_equal_one_rank_bit_for_bit(n, gpu_ctx, orc):
         k = em.optimize()                                    # look-ahead, the stop rule in the fused prologues
         return em.getV(), em.getQ(), em.trace()[0], k, em.getCounts(), mode, note
 
-    out, errs = _local_ranks(n, c, orc, calls)
+    out, errs = _local_ranks(n, c, orc, calls, layout=layout)
     assert errs == [None] * n, [str(e) for e in errs]
     for r in range(n):
         assert out[r][5] == 2, out[r][6]                     # the in-kernel mode was agreed on
@@ -176,16 +188,18 @@ def test_without_the_tuning_or_on_an_unfit_handle_the_collective_stays(gpu_ctx, 
     assert errs == [None, None] and out[0][0][0] == 1 and np.array_equal(out[0][1], out[1][1])
     c4 = Case("k4", N=40, L0=120, W=12, K=4, seed=5)          # sliced path: not one grouped launch with the fused update
     out, errs = _local_ranks(2, c4, orc, lambda em, r: (em.comm_mode(), em.iterate(2), em.getV())[::2])
-    assert errs == [None, None] and out[0][0][0] == 1 and "not one launch of the mixed-row kernel" in out[0][0][1]
+    assert errs == [None, None] and out[0][0][0] == 1 and "not one launch of a grouped-column kernel built with the tail" in out[0][0][1]
     assert np.array_equal(out[0][1], out[1][1])
 
 
-def test_a_rank_that_arrives_too_late_is_an_error_not_a_hang(gpu_ctx, orc):
+@pytest.mark.parametrize("shape", ["mix_k2_ds", "grp_k1_ds"])
+def test_a_rank_that_arrives_too_late_is_an_error_not_a_hang(shape, gpu_ctx, orc):
     """Rank 1 starts 1.5 s late; rank 0's first pass waits 300 ms (peer_timeout_ms) for sums that do not come: the wait is
     bounded, the handle's later launches do nothing, and the next read fails with BAMM_ERR_COMM -- on rank 1 as well,
     whose second pass then waits in vain for the pass rank 0 never ran."""
     import time
-    c = Case(**SMALL_CASES[6])
+    spec, layout = SHAPES[shape]
+    c = Case(**spec)
     gate = threading.Barrier(2)
 
     def calls(em, r):
@@ -196,7 +210,7 @@ def test_a_rank_that_arrives_too_late_is_an_error_not_a_hang(gpu_ctx, orc):
         em.iterate(4)
         return em.getV()
 
-    out, errs = _local_ranks(2, c, orc, calls, timeout_ms=300)
+    out, errs = _local_ranks(2, c, orc, calls, timeout_ms=300, layout=layout)
     for r in range(2):
         assert isinstance(errs[r], bm.abi.BammError), (out, errs)
         assert errs[r].code == bm.abi.ERR_COMM, errs[r]

@@ -16,9 +16,12 @@ run() {
   one "$1 125k            " --nseq 125000 --steps 200 --warmup 20; one "$1 125k            " --nseq 125000 --steps 200 --warmup 20
   one "$1 50k             " --nseq 50000 --steps 300 --warmup 30; one "$1 50k             " --nseq 50000 --steps 300 --warmup 30
   one "$1 k=1             " --nseq 1000000 --order 1 --steps 100 --warmup 20
+  one "$1 k=1 125k        " --nseq 125000 --order 1 --steps 200 --warmup 20; one "$1 k=1 125k        " --nseq 125000 --order 1 --steps 200 --warmup 20
+  one "$1 --ss            " --nseq 1000000 --ss --steps 100 --warmup 20
+  one "$1 --ss 125k       " --nseq 125000 --ss --steps 200 --warmup 20; one "$1 --ss 125k       " --nseq 125000 --ss --steps 200 --warmup 20
   one "$1 k=3             " --nseq 1000000 --order 3 --steps 100 --warmup 20
 }
-timeout -k 10 600 python3 -m pytest tests/test_grouped_gpu.py tests/test_fuzz_gpu.py tests/test_fused_update_gpu.py tests/test_golden_gpu.py -x -q -m gpu 2>&1 | tail -3
+timeout -k 10 900 python3 -m pytest tests/test_grouped_gpu.py tests/test_fuzz_gpu.py tests/test_fused_update_gpu.py tests/test_golden_gpu.py tests/test_peer_allreduce_gpu.py tests/test_partition_exact_gpu.py -x -q -m gpu 2>&1 | tail -3
 run new
 mkdir -p /tmp/new
 # whatever ends the script (a timeout, Ctrl-C, a failed build): the tree's own files and library come back
