@@ -27,6 +27,7 @@
 using namespace bamm;
 
 static bool flush_idle_scratch(int device);
+static void par_memcpy(void* dst, const void* src, size_t bytes);
 
 namespace {
 
@@ -50,6 +51,17 @@ int dev_alloc_bytes(void** p, size_t bytes) {
 
 template <class T>
 int dev_alloc(T** p, size_t count) { return dev_alloc_bytes((void**)p, count * sizeof(T)); }
+
+// a std::vector whose resize() leaves the new elements uninitialised: the set-sized host mirrors are filled by a parallel
+// copy right after (a value-initialising resize is one more single-threaded pass over 100 MB)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
 
 struct Bucket {
     int mclass = 0;
@@ -301,11 +313,11 @@ struct bamm_seqs {
     uint32_t* d_len = nullptr;
     uint64_t* d_pos_off = nullptr;
     std::vector<uint32_t> h_len;
-    std::vector<uint32_t> h_words;              // host copy of the 2-bit stream (grouped kernel's exception records)
+    RawVec<uint32_t> h_words;                   // host copy of the 2-bit stream (grouped kernel's exception records)
     std::vector<uint64_t> h_word_off;
     std::vector<uint64_t> h_pos_off;
     std::vector<uint64_t> h_exc_off;            // full (11-mer level) exception list
-    std::vector<uint32_t> h_exc_pos, h_exc_kmer, h_exc_clean;
+    RawVec<uint32_t> h_exc_pos, h_exc_kmer, h_exc_clean;
     std::vector<Bucket> buckets;
     std::map<uint32_t, ExcK> exc_by_order;      // node-based: pointers into it stay valid
 
@@ -1240,14 +1252,14 @@ static int seqs_upload_impl(bamm_ctx* c, const bamm_packed* p, uint64_t begin, u
         s->min_len = std::min(s->min_len, s->h_len[n]);
     }
     woff[s->n] = w1 - w0;
-    s->h_words.assign(p->words + w0, p->words + w1);
+    s->h_words.resize(w1 - w0); par_memcpy(s->h_words.data(), p->words + w0, (w1 - w0) * sizeof(uint32_t));
     s->h_word_off = woff;
     s->h_pos_off[s->n] = pos;
     s->h_exc_off[s->n] = e1 - e0;
     s->total_len = pos;
-    s->h_exc_pos.assign(p->exc_pos + e0, p->exc_pos + e1);
-    s->h_exc_kmer.assign(p->exc_kmer + e0, p->exc_kmer + e1);
-    s->h_exc_clean.assign(p->exc_clean + e0, p->exc_clean + e1);
+    s->h_exc_pos.resize(e1 - e0); par_memcpy(s->h_exc_pos.data(), p->exc_pos + e0, (e1 - e0) * sizeof(uint32_t));
+    s->h_exc_kmer.resize(e1 - e0); par_memcpy(s->h_exc_kmer.data(), p->exc_kmer + e0, (e1 - e0) * sizeof(uint32_t));
+    s->h_exc_clean.resize(e1 - e0); par_memcpy(s->h_exc_clean.data(), p->exc_clean + e0, (e1 - e0) * sizeof(uint32_t));
 
     // length buckets: one kernel instantiation per positions-per-lane class
     // (+ one bucket for the sequences beyond the longest class: long_seq.hip walks those window by window)
