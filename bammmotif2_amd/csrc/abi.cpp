@@ -5,6 +5,7 @@
 // EM.cpp:7-259,505-527) and ScoreSeqSet::calcLogOdds (seq_scoring/ScoreSeqSet.cpp:25-67).
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -377,8 +378,9 @@ struct bamm_em {
     bool acc_external = false;                 // caller-owned (bamm_em_set_reduce_buffer)
     bool acc_dirty = false;                    // holds sums nobody consumed (accumulate without update, getR replay)
     uint32_t fix_shift = 40;                   // counts travel in units of 2^-fix_shift (40 unless the set is huge)
-    float* h_status = nullptr;                  // pinned, 8 floats (+ 2 x 8 for optimize()'s look-ahead)
-    float* d_status_mirror = nullptr;           // h_status as the device addresses it (k_update writes optimize()'s slots itself)
+    float* h_status = nullptr;                  // pinned, 8 floats (+ 2 x 8 for optimize()'s look-ahead where the mirror below is missing)
+    unsigned long long* h_tagged = nullptr;     // ... + 2 x 8 tagged words behind them: what the updates of optimize() report (UpdateArgs::status_mirror)
+    unsigned long long* d_status_mirror = nullptr;   // h_tagged as the device addresses it
     uint32_t* d_stop = nullptr;                 // optimize(): set by k_update when the stop rule fires
     const uint32_t* stop_arg = nullptr;         // what the kernels are handed: d_stop inside optimize(), else null
     hipEvent_t opt_events[2] = {nullptr, nullptr};
@@ -916,7 +918,7 @@ void prepare_update(bamm_em* em, bool q_window, bool fused, UpdateArgs& u) {
     if (em->stop_arg) {
         u.stop = em->d_stop; u.epsilon = em->prm.epsilon; u.opt_iteration = em->opt_iteration;
         u.llh_prev = em->opt_llh_prev; u.llh_prev_from_status = em->opt_iteration > 1u ? 1 : 0;
-        u.status_mirror = em->d_status_mirror ? em->d_status_mirror + 8 + 8 * (em->opt_iteration & 1u) : nullptr;
+        u.status_mirror = em->d_status_mirror ? em->d_status_mirror + 8 * (em->opt_iteration & 1u) : nullptr;
     }
     if (fused) {
         // every block of the carrying launch reads slot `acc_cur` and the old v; its writer block stores the new v
@@ -1743,12 +1745,13 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         if ((rc = dev_upload(c, &em->d_mask, seq_mask, seqs->n))) return fail(rc);
     em->n_active = seqs->n;
     if (seq_mask) em->n_active = (uint64_t)std::count_if(seq_mask, seq_mask + seqs->n, [](uint8_t m) { return m != 0; });
-    if (hipHostMalloc((void**)&em->h_status, 24 * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&em->h_status, 24 * sizeof(float) + 16 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc failed");
         return fail(BAMM_ERR_HIP);
     }
-    memset(em->h_status, 0, 24 * sizeof(float));
-    if (hipHostGetDevicePointer((void**)&em->d_status_mirror, em->h_status, 0) != hipSuccess) em->d_status_mirror = nullptr;   // then: copies
+    memset(em->h_status, 0, 24 * sizeof(float) + 16 * sizeof(unsigned long long));
+    em->h_tagged = reinterpret_cast<unsigned long long*>(em->h_status + 24);
+    if (hipHostGetDevicePointer((void**)&em->d_status_mirror, em->h_tagged, 0) != hipSuccess) em->d_status_mirror = nullptr;   // then: copies + events
     // launches of one pass: every length bucket, split into the sequences the grouped-column kernel
     // takes (no exception, or all of them within its virtual rows) and the rest
     const bool want_grouped = !sliced && prm->K <= 3u && c->use_grouped;
@@ -2062,6 +2065,12 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
     BAMM_HIP(hipMemsetAsync(em->d_stop, 0, sizeof(uint32_t), st));
     const uint32_t lag = em->fusable ? 1u : 0u;
     const uint32_t units = max_it + lag;
+    // The status of update i reaches the host through pinned memory the update's writer stores into (UpdateArgs::
+    // status_mirror) as six self-validating words tagged with i: the host POLLS them.  An event per unit, which this loop
+    // used to record and wait for, costs the stream 4 us per pass (optimize() against iterate(): +4.5 us at every size up to
+    // 50k sequences, profiles/r05_optimize_vs_iterate.txt); events remain the fallback where the mirror could not be mapped.
+    const bool poll = em->d_status_mirror != nullptr;
+    if (poll) memset(em->h_tagged, 0, 16 * sizeof(unsigned long long));         // no tag of an earlier call (tags start at 1)
     const uint32_t first_update = em->host_iteration;       // update(i) of this call is the handle's update first_update + i
     em->stop_arg = em->d_stop;
     em->opt_llh_prev = em->llh_prev;
@@ -2082,9 +2091,10 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
         }
         if (r) return r;
         const uint32_t upd = u - lag;                        // the update this unit carried (0: none)
-        if (upd >= 1u && !em->d_status_mirror)
-            BAMM_HIP(hipMemcpyAsync(em->h_status + 8 + 8 * (upd & 1u), em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
-        BAMM_HIP(hipEventRecord(em->opt_events[u & 1u], st));
+        if (!poll) {
+            if (upd >= 1u) BAMM_HIP(hipMemcpyAsync(em->h_status + 8 + 8 * (upd & 1u), em->d_status, 8 * sizeof(float), hipMemcpyDeviceToHost, st));
+            BAMM_HIP(hipEventRecord(em->opt_events[u & 1u], st));
+        }
         return BAMM_OK;
     };
     // every exit: the kernels stop looking at the flag; sums nobody consumed are cleared before the next pass
@@ -2097,11 +2107,40 @@ int bamm_em_optimize(bamm_em* em, uint32_t* iterations) {
             if ((rc = enqueue_unit(enqueued + 1u))) return leave(rc);
             enqueued++;
         }
-        if (hipEventSynchronize(em->opt_events[(done + lag) & 1u]) != hipSuccess) {
+        const float* hs = em->h_status + 8 + 8 * (done & 1u);
+        float polled[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (poll) {
+            const volatile unsigned long long* slot = em->h_tagged + 8 * (done & 1u);
+            auto arrived = [&] {
+                for (int i = 0; i < 6; i++) {
+                    const unsigned long long w = slot[i];
+                    if ((uint32_t)(w >> 32) != done) return false;
+                    const uint32_t bits = (uint32_t)w;
+                    memcpy(&polled[i], &bits, sizeof(float));
+                }
+                return true;
+            };
+            hs = polled;
+            for (uint32_t spins = 1;; spins++) {
+                if (arrived()) break;
+                if ((spins & 2047u) == 0u) {                                    // now and then: is anything still running?
+                    const hipError_t qs = hipStreamQuery(st);
+                    if (qs == hipSuccess) {                                     // the stream is idle: the tag is there, or never will be
+                        if (arrived()) break;
+                        if (int cs = comm_still_sound(em)) return leave(cs);   // (a block gave up waiting for a peer: every later launch did nothing)
+                        set_error("optimize(): pass %u ended without reporting its status (a kernel of the pass failed?)", done);
+                        return leave(BAMM_ERR_HIP);
+                    }
+                    if (qs != hipErrorNotReady) { (void)hipGetLastError(); set_error("optimize(): %s", hipGetErrorString(qs)); return leave(BAMM_ERR_HIP); }
+                    if (em->comm && comm_aborted(em->comm)) { set_error("the communicator was aborted while optimize() was waiting for pass %u", done); return leave(BAMM_ERR_COMM); }
+                }
+                __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else if (hipEventSynchronize(em->opt_events[(done + lag) & 1u]) != hipSuccess) {
             set_error("hipEventSynchronize failed in optimize()");
             return leave(BAMM_ERR_HIP);
         }
-        const float* hs = em->h_status + 8 + 8 * (done & 1u);
         const float llh_prev = llh;
         llh = hs[0];
         const float v_diff = hs[1];

@@ -193,8 +193,9 @@ struct UpdateArgs {
     const float* llh_in;         // the previous update's log-likelihood (a slot the writer does not store into)
     float* llh_out;              // nullable: where this update leaves its own
     uint32_t opt_iteration;      // 1-based pass number inside this optimize() call (`iteration > 10`)
-    float* status_mirror;        // nullable: pinned host memory (device address) that receives the 8 status words as
-                                 // well, so that the host needs no copy in the stream to see them
+    unsigned long long* status_mirror;   // nullable: pinned host memory (device address) that receives the first six status words
+                                 // as well, each as a self-validating 8-byte word {opt_iteration | float bits}: the host
+                                 // polls them, no copy and no event in the stream
     // tables beyond the LDS form of the update (K >= 3 at usual widths): the update is spread over blocks in two
     // launches (k_update_counts, k_update_model) instead of one block walking up to millions of cells
     double*   partial;           // nullable ([kUpdateMaxBlocks]): per-block partial sums of v_diff, summed in block order by the last block

@@ -207,8 +207,14 @@ __global__ void __launch_bounds__(1024) k_update(UpdateArgs a) {
         a.status[4] = (float)sum_r;
         a.status[5] = (float)nseq;
         if (a.status_mirror != nullptr) {
-            a.status_mirror[0] = (float)llh; a.status_mirror[1] = (float)v_diff; a.status_mirror[2] = q; a.status_mirror[3] = (float)it;
-            a.status_mirror[4] = (float)sum_r; a.status_mirror[5] = (float)nseq;
+            // six self-validating 8-byte words {pass number | float bits}: optimize() polls them instead of waiting for an event on
+            // the stream (4 us of stream time per pass); no fence between the words -- each carries its own tag (RCCL's LL idea)
+            {
+                const float f6[6] = {(float)llh, (float)v_diff, q, (float)it, (float)sum_r, (float)nseq};
+                const unsigned long long tag = (unsigned long long)a.opt_iteration << 32;
+#pragma unroll
+                for (int i = 0; i < 6; i++) __hip_atomic_store(a.status_mirror + i, tag | (unsigned long long)__float_as_uint(f6[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         if (a.trace && it - 1u < a.trace_cap) {
             a.trace[(size_t)(it - 1u) * 3 + 0] = (float)llh;
@@ -360,8 +366,14 @@ __global__ void __launch_bounds__(256) k_update_model(UpdateArgs a) {
     a.status[0] = (float)llh; a.status[1] = (float)v_diff; a.status[2] = q; a.status[3] = (float)it;
     a.status[4] = (float)sum_r; a.status[5] = (float)nseq;
     if (a.status_mirror != nullptr) {
-        a.status_mirror[0] = (float)llh; a.status_mirror[1] = (float)v_diff; a.status_mirror[2] = q; a.status_mirror[3] = (float)it;
-        a.status_mirror[4] = (float)sum_r; a.status_mirror[5] = (float)nseq;
+        // six self-validating 8-byte words {pass number | float bits}: optimize() polls them instead of waiting for an event on
+        // the stream (4 us of stream time per pass); no fence between the words -- each carries its own tag (RCCL's LL idea)
+        {
+            const float f6[6] = {(float)llh, (float)v_diff, q, (float)it, (float)sum_r, (float)nseq};
+            const unsigned long long tag = (unsigned long long)a.opt_iteration << 32;
+#pragma unroll
+            for (int i = 0; i < 6; i++) __hip_atomic_store(a.status_mirror + i, tag | (unsigned long long)__float_as_uint(f6[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (a.trace && it - 1u < a.trace_cap) {
         a.trace[(size_t)(it - 1u) * 3 + 0] = (float)llh;
