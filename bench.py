@@ -481,7 +481,11 @@ class Watchdog:
         self.scale = scale
         self.proc = None
         if scale > 0:
-            self.proc = subprocess.Popen([sys.executable, "-c", WATCHDOG_SRC, str(os.getpid()), tag], stdin=subprocess.PIPE, text=True)
+            try:
+                self.proc = subprocess.Popen([sys.executable, "-c", WATCHDOG_SRC, str(os.getpid()), tag], stdin=subprocess.PIPE, text=True)
+            except Exception as e:                           # no watchdog is not a reason to lose the run
+                print(f"[bench] no watchdog: {e!r}", file=sys.stderr)
+                self.proc = None
 
     def phase(self, name, cap_s):
         if self.proc is not None and self.proc.poll() is None:
