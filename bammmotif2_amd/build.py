@@ -24,6 +24,12 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "device_utils.h"),
 # hand-issued LDS reads, refused) instead of silently turning register arrays into scratch memory.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-result", "-Rpass-analysis=kernel-resource-usage"]
+# Translation units whose kernels exceed the 64 KB instruction cache (20 and more positions per lane: 72-153 KB of code each):
+# their kernels start on 16 KB boundaries.  Where such a kernel lands inside its code object decides how its loop maps onto
+# the cache -- the 64-per-lane class ran 5.75 ms per pass at one 256-byte offset and 4.93 ms 1280 bytes earlier, the same
+# instructions, three times the instruction-cache misses (SQC_ICACHE_MISSES; profiles/r05_icache_alignment.txt) -- and every
+# unrelated change to the unit moves it.  Aligned, the placement is the same in every build (4 KB: 5.23 ms, 16 KB: 4.88, 64 KB: 4.90).
+TU_FLAGS = {"grouped_long.hip": ["-falign-functions=16384"], "grouped_xl.hip": ["-falign-functions=16384"], "kernels.hip": ["-falign-functions=16384"]}
 OBJDIR = os.path.join(HERE, "build")
 RESOURCES = os.path.join(OBJDIR, "resources.json")
 
@@ -116,11 +122,15 @@ EXTRA_DEPS = {"prep.hip": [os.path.join(CSRC, "prep.h")], "negs.hip": [os.path.j
 FLAGS_STAMP = os.path.join(OBJDIR, "flags.txt")
 
 
+def _flags_stamp() -> str:
+    return " ".join(FLAGS) + " | " + " ".join(f"{k}: {' '.join(v)}" for k, v in sorted(TU_FLAGS.items()))
+
+
 def _flags_changed() -> bool:
     """The library in the tree was built with other compiler flags than this process would use (tools/phase_clock.py
     appends -DBAMM_PHASE_CLOCK): as stale as a changed source -- nobody benchmarks an instrumented build by accident."""
     try:
-        return open(FLAGS_STAMP).read() != " ".join(FLAGS)
+        return open(FLAGS_STAMP).read() != _flags_stamp()
     except OSError:
         return os.path.exists(LIB) and os.path.isdir(OBJDIR) and bool(os.listdir(OBJDIR))   # built before the stamp existed
 
@@ -166,7 +176,7 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), _obj(s)
         if force or _stale(obj, [src] + HEADERS + EXTRA_DEPS.get(s, [])) or not os.path.exists(_remarks(s)):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + TU_FLAGS.get(s, []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             log = open(_remarks(s) + ".tmp", "w")
@@ -188,7 +198,7 @@ def _build_library_locked(force: bool, verbose: bool) -> str:
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     with open(FLAGS_STAMP, "w") as fh:
-        fh.write(" ".join(FLAGS))
+        fh.write(_flags_stamp())
     return LIB
 
 
