@@ -156,7 +156,7 @@ static bool flush_idle_scratch(int device) {
     return any;
 }
 
-constexpr size_t kStageChunk = size_t(8) << 20;               // bytes per pinned chunk
+constexpr size_t kStageChunk = size_t(4) << 20;               // bytes per pinned chunk (two of them: 8 MB pinned per context, 1.5 ms to allocate)
 constexpr size_t kStageMin = size_t(64) << 10;                // smaller transfers: the runtime copies them through its own staging buffer
 
 // memcpy on the host threads the process was granted (a chunk of 8 MB: 0.9 ms on one thread, 0.2 ms on eight)
