@@ -76,12 +76,12 @@ struct ExcK {                    // exceptions relevant at one model order
     uint64_t* d_off = nullptr;
     uint2* d_exc = nullptr;
     uint64_t count = 0;
-    std::vector<uint64_t> h_off;          // host copies (the grouped kernel's records are built from them)
-    std::vector<uint2> h_ex;
+    RawVec<uint64_t> h_off;               // host copies (the grouped kernel's records are built from them)
+    RawVec<uint2> h_ex;
     struct XRec {                         // grouped kernel (grouped.hip), one set per group size G
         uint4* d_xrec = nullptr;          // per-sequence record
-        std::vector<uint8_t> h_B;         // group ends that need a virtual row (0 = no exception, 255 = too many)
-        std::vector<uint32_t> h_lo;       // first of them
+        RawVec<uint8_t> h_B;              // group ends that need a virtual row (0 = no exception, 255 = too many)
+        RawVec<uint32_t> h_lo;            // first of them
     };
     std::map<uint32_t, XRec> xrec;
 };
@@ -488,25 +488,44 @@ int exceptions_for_order(bamm_seqs* s, uint32_t K, ExcK** out) {
     if (it != s->exc_by_order.end()) { *out = &it->second; return BAMM_OK; }
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
     ExcK k;
-    k.h_off.assign(s->n + 1, 0);
-    host_ranges(s->n, [&](uint64_t n0, uint64_t n1) {         // count per sequence, then fill: the same list in the same order
+    k.h_off.resize(s->n + 1);
+    // two passes over fixed parts of the set, a thread each: counts per sequence (left in h_off[n + 1]) and per part, a scan over
+    // the parts, then every part turns its counts into offsets while it fills its stretch of the list -- the same list in the
+    // same order as one walk would give, with no pass over a million records on one thread
+    const uint32_t parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(host_threads_hint(), s->n / 16384 + 1));
+    std::vector<uint64_t> part_total(parts + 1, 0);
+    auto part_range = [&](uint32_t t, uint64_t& n0, uint64_t& n1) { n0 = s->n * t / parts; n1 = s->n * (t + 1) / parts; };
+    auto on_parts = [&](auto&& fn) {
+        if (parts == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < parts; t++) th.emplace_back([&fn, t] { fn(t); });
+        for (auto& x : th) x.join();
+    };
+    on_parts([&](uint32_t t) {
+        uint64_t n0, n1, total = 0;
+        part_range(t, n0, n1);
         for (uint64_t n = n0; n < n1; n++) {
             uint64_t c = 0;
             for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++) c += ((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u;
             k.h_off[n + 1] = c;
+            total += c;
         }
+        part_total[t + 1] = total;
     });
-    for (uint64_t n = 0; n < s->n; n++) k.h_off[n + 1] += k.h_off[n];
-    k.h_ex.resize(k.h_off[s->n]);
-    host_ranges(s->n, [&](uint64_t n0, uint64_t n1) {
+    for (uint32_t t = 0; t < parts; t++) part_total[t + 1] += part_total[t];
+    k.h_ex.resize(part_total[parts]);
+    k.h_off[0] = 0;
+    on_parts([&](uint32_t t) {
+        uint64_t n0, n1;
+        part_range(t, n0, n1);
+        uint64_t at = part_total[t];
         for (uint64_t n = n0; n < n1; n++) {
-            uint64_t at = k.h_off[n];
             for (uint64_t e = s->h_exc_off[n]; e < s->h_exc_off[n + 1]; e++)
                 if (((s->h_exc_kmer[e] ^ s->h_exc_clean[e]) & maskY) != 0u)
                     k.h_ex[at++] = make_uint2(s->h_exc_pos[e], s->h_exc_kmer[e] & maskY);
+            k.h_off[n + 1] = at;                              // (was the count: read above, by this thread)
         }
     });
-    k.h_off[s->n] = k.h_ex.size();
     k.count = k.h_ex.size();
     int rc = dev_upload(s->ctx, &k.d_off, k.h_off.data(), k.h_off.size());
     if (rc) return rc;
@@ -530,9 +549,9 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
     if (it != k->xrec.end()) { *out = &it->second; return BAMM_OK; }
     const uint32_t maskY = (uint32_t)(ipow4(K + 1) - 1);
     ExcK::XRec x;
-    x.h_B.assign(s->n, 0);
-    x.h_lo.assign(s->n, 0);
-    std::vector<uint4> xrec(s->n, make_uint4(0, 0, 0, 0));
+    x.h_B.resize(s->n);                                      // every element is written by the loop below
+    x.h_lo.resize(s->n);
+    RawVec<uint4> xrec(s->n);
     auto stream_y = [&](uint64_t n, int64_t pos) -> uint32_t {      // kmer_ mod 4^(K+1) as the stream alone gives it
         uint32_t y = 0;
         for (uint32_t d = 0; d <= K; d++) {
@@ -546,6 +565,7 @@ int xrec_for_group(bamm_seqs* s, uint32_t K, uint32_t G, ExcK* k, const ExcK::XR
     host_ranges(s->n, [&](uint64_t n_begin, uint64_t n_end) {
     for (uint64_t n = n_begin; n < n_end; n++) {
         const uint64_t e0 = k->h_off[n], e1 = k->h_off[n + 1];
+        x.h_B[n] = 0; x.h_lo[n] = 0; xrec[n] = make_uint4(0, 0, 0, 0);
         if (e0 == e1) continue;
         const uint32_t lo = k->h_ex[e0].x, hi = k->h_ex[e1 - 1].x, L = s->h_len[n];
         const uint32_t hiB = std::min(hi + G - 1u, L - 1u);
@@ -1781,11 +1801,16 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
         std::vector<uint32_t> yes, no;
         uint32_t glayout = 0;
         // do most sequences of this bucket carry exceptions (a double-stranded set: all of them)?
-        size_t with_exc = 0;
-        for (uint32_t i = 0; i < b.count; i++) {
-            const uint32_t n = b.d_idx ? b.h_idx[i] : i;
-            with_exc += em->exc->h_off[n + 1] != em->exc->h_off[n];
-        }
+        std::atomic<size_t> with_exc_a{0};
+        host_ranges(b.count, [&](uint64_t i0, uint64_t i1) {
+            size_t cnt = 0;
+            for (uint64_t i = i0; i < i1; i++) {
+                const uint32_t n = b.d_idx ? b.h_idx[i] : (uint32_t)i;
+                cnt += em->exc->h_off[n + 1] != em->exc->h_off[n];
+            }
+            with_exc_a.fetch_add(cnt, std::memory_order_relaxed);
+        });
+        const size_t with_exc = with_exc_a.load();
         if (want_grouped && grp_supported_class(Mcls, prm->K) &&
             grp_plan(prm->K, prm->W, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, 2 * with_exc > b.count, plan_n * (uint64_t)Mcls >= 40000ull * 7ull, c->group_size, c->group_layout, &gG, &glogc, &glayout) &&
             grp_geometry(prm->K, prm->W, gG, Mcls, std::min(threads, grp_max_threads(Mcls)) / 64u, true, glogc, glayout, &gg)) {
@@ -1796,8 +1821,12 @@ int bamm_em_create(bamm_ctx* c, bamm_seqs* seqs, const bamm_em_params* prm, cons
                 const uint32_t B = xr->h_B[n];
                 return B == 0u || (B <= gg.Bj && (gg.np != 0u || xr->h_lo[n] + B + gg.G <= seqs->h_len[n] - prm->W + 1u));
             };
-            bool all = true;
-            for (uint32_t i = 0; i < b.count && all; i++) all = capable(b.d_idx ? b.h_idx[i] : i);
+            std::atomic<bool> all_capable{true};
+            host_ranges(b.count, [&](uint64_t i0, uint64_t i1) {
+                for (uint64_t i = i0; i < i1 && all_capable.load(std::memory_order_relaxed); i++)
+                    if (!capable(b.d_idx ? b.h_idx[i] : (uint32_t)i)) all_capable.store(false, std::memory_order_relaxed);
+            });
+            const bool all = all_capable.load();
             if (!all)
                 for (uint32_t i = 0; i < b.count; i++) {
                     const uint32_t n = b.d_idx ? b.h_idx[i] : i;
