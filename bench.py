@@ -86,6 +86,12 @@ def parse():
                          "included, nothing added between passes: the default on 1 GPU); n >= 1 = a pair around every n-th pass "
                          "(a pair takes 7-8 us of stream time, profiles/r04_timing_every_cost.txt; 8 is the default with "
                          "N > 1, where the interval of -1 would include the collective); 0 = none")
+    ap.add_argument("--headline-collective", default="auto", choices=["auto", "rccl", "peer"],
+                    help="N > 1: which of the two timed regions the line's value / ms_per_step come from.  Both regions are the same "
+                         "(W warm-up passes, exactly K timed passes between barriers, max over ranks) and end on the same model bit for "
+                         "bit; one sums over the ranks with the RCCL collective behind every pass, the other inside the sequence kernel's "
+                         "tail over peer-mapped inboxes (no collective launch).  auto = the faster one, provided the in-kernel path passed "
+                         "the self-test and its own region; both timings are always reported (ms_per_step_rccl, ms_per_step_peer_allreduce)")
     ap.add_argument("--no-selftest-comm", action="store_true",
                     help="N > 1: skip the communicator self-test in front of the timed region (3 passes through the RCCL collective and "
                          "3 through the in-kernel all-reduce on handles of their own, model hashes compared across the ranks)")
@@ -320,7 +326,7 @@ def report(args, wl, world, dt, kernel_ms, launches, local_positions, local_wind
                      "algorithmic_achieved": achieved, "algorithmic_frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": pmc_src,
                      "kernel": kernel_name, "avg_kernel_ms": avg_kernel_s * 1e3,
-                     "avg_kernel_ms_is": ("one pair of HIP events around ALL passes of the timed call, divided by their number: every "
+                     "avg_kernel_ms_is": extras.pop("avg_kernel_ms_is", None) or ("one pair of HIP events around ALL passes of the timed call, divided by their number: every "
                                           "pass covered, the launch gaps between passes included (<= ms_per_step by construction)"
                                           if args.timing_every < 0 else
                                           "no pass timed" if args.timing_every == 0 else
@@ -419,7 +425,7 @@ def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_ma
         mode, note = res if res else (0, None)
         if agreed() or mode != 2:
             return {"ms_per_step_peer_allreduce": "unavailable: " + (why[0] if why else (note or "mode %d" % mode))}
-        step("timing", lambda: em.set_kernel_timing(args.timing_every))
+        step("timing", lambda: em.set_kernel_timing(-1))     # ONE pair of events around all passes: no collective sits between them here
         step("warm-up", lambda: em.iterate(args.warmup))     # a block that waited in vain ends its launch with an error: bounded
         step("sync", sync); barrier()
         t0 = time.perf_counter()
@@ -432,7 +438,7 @@ def peer_allreduce_extra(bm, ctx, seqs, comm, wl, args, barrier, sync, reduce_ma
         if agreed():
             return {"ms_per_step_peer_allreduce": "unavailable: " + (why[0] if why else "another rank failed")}
         return {"ms_per_step_peer_allreduce": dt / args.steps * 1e3,
-                "peer_allreduce": {"kernel_us": k_us, "model_sha": hashlib.sha256(v.tobytes()).hexdigest()[:16],
+                "peer_allreduce": {"kernel_us": k_us, "dt_s": dt, "model_sha": hashlib.sha256(v.tobytes()).hexdigest()[:16],
                                    "what": "every pass but the call's last hands its sums to the peers from the kernel's own epilogue (last block, "
                                            "system-scope stores into peer-mapped inboxes) and collects theirs there; kernel_us then includes the "
                                            "wait for the slowest rank"}}
@@ -596,6 +602,29 @@ def first_call(bm, ctx, seqs, wl, args, sync):
     return {"first_create_ms": (t1 - t0) * 1e3, "first_call_ms": (t2 - t1) * 1e3, "first_call_passes": it,
             "first_call_is": "bamm_em_create, then optimize() (epsilon 0, %d passes) on the first handle of the process before anything "
                              "else of the library has run on the device; wall clock, stream synchronised on both sides" % n_cold}
+
+
+def choose_headline(args, extras, dt, kernel_ms, launches, allreduce_kind, model_sha_rccl=None):
+    """N > 1: two identical timed regions were run, one per way of summing over the ranks; the line's value comes from the one
+    --headline-collective names (auto: the faster, if the in-kernel region completed on every rank and ended on the collective's
+    model).  Returns (dt, kernel_ms, launches, allreduce_kind) of the chosen region; both timings stay in the line."""
+    extras["ms_per_step_rccl"] = dt / args.steps * 1e3
+    extras["headline_collective"] = "rccl"
+    peer_ms, peer = extras.get("ms_per_step_peer_allreduce"), extras.get("peer_allreduce") or {}
+    if not isinstance(peer_ms, float) or args.headline_collective == "rccl":
+        return dt, kernel_ms, launches, allreduce_kind
+    if model_sha_rccl is not None and peer.get("model_sha") != model_sha_rccl:
+        extras["ms_per_step_peer_allreduce"] = "unavailable: its region ended on another model than the collective's (%s / %s)" % (peer.get("model_sha"), model_sha_rccl)
+        return dt, kernel_ms, launches, allreduce_kind
+    if args.headline_collective == "peer" or peer_ms < extras["ms_per_step_rccl"]:
+        extras["headline_collective"] = "peer"
+        extras["avg_kernel_ms_is"] = ("one pair of HIP events around ALL passes of the timed call, divided by their number (max over ranks): with the "
+                                      "all-reduce inside the kernel nothing else sits between two passes; it includes the wait for the slowest rank")
+        kind = ("in-kernel all-reduce: the last block of every pass exchanges the GPU's totals with the peers through inboxes mapped over "
+                "xGMI and leaves the sum in the accumulator -- no collective launch (bamm_em_comm_mode 2; same model as the collective bit "
+                "for bit: selftest_comm, model_sha).  The RCCL region of the same run: ms_per_step_rccl; set-up votes over: " + allreduce_kind)
+        return peer["dt_s"], peer["kernel_us"] * 1e-3 * max(launches, 1), max(launches, 1), kind
+    return dt, kernel_ms, launches, allreduce_kind
 
 
 def from_seed_extras(bm, ctx, seqs, wl, args, sync):
@@ -767,11 +796,15 @@ def main_inprocess(args, result_fd):
             extras["ms_per_step_peer_allreduce"] = "unavailable: " + selftest[0]["peer"]["why"]
     if comms:
         extras["attribution"] = attribution(dt / args.steps * 1e6, [k[0] / max(k[1], 1) * 1e3 for k in kernel], ar_us, args)
+        extras["attribution"]["of"] = "the timed region that sums over the ranks with the collective (ms_per_step_rccl)"
     if peer_out[0] is not None:
         extras.update(peer_out[0])
         shas = {(p.get("peer_allreduce") or {}).get("model_sha") for p in peer_out}
         if len(shas) > 1:
             extras["ms_per_step_peer_allreduce"] = "unavailable: the ranks' models differ after the in-kernel all-reduce"
+    if comms and N > 1:
+        dt, kernel_ms, launches, allreduce_kind = choose_headline(args, extras, dt, kernel_ms, launches, allreduce_kind,
+                                                                   hashlib.sha256(v0_.tobytes()).hexdigest()[:16])
     wd.phase("from-seed figures, CPU baseline, report", 1200)
     if N == 1 and not comms and not args.no_extras:
         extras.update(from_seed_extras(bm, ctxs[0], seqs[0], wl, args, ctxs[0].sync))
@@ -999,6 +1032,10 @@ def main():
         extras["attribution"] = attribution(dt / args.steps * 1e6, [g["kernel_us"] for g in ranks], [g["allreduce_us"] for g in ranks], args)
         slow = max(ranks, key=lambda g: g["kernel_us"])                # the roofline line prices the slowest rank's kernel
         kernel_ms, launches = slow["kernel_us"] * 1e-3 * max(launches, 1), max(launches, 1)
+        extras["attribution"]["of"] = "the timed region that sums over the ranks with the collective (ms_per_step_rccl)"
+    if use_dist and world > 1:
+        sha_rccl = hashlib.sha256(em.getV().tobytes()).hexdigest()[:16]
+        dt, kernel_ms, launches, allreduce_kind = choose_headline(args, extras, dt, kernel_ms, launches, allreduce_kind, sha_rccl)
     if rank == 0:
         out = report(args, wl, world, dt, kernel_ms, launches, local_positions, local_windows, kernel_name, mixed,
                      float(llh[-1]) if len(llh) else None, allreduce_kind, extras, ranks,

@@ -118,3 +118,27 @@ def test_selftest_comm_keeps_the_ranks_in_step_and_names_the_failure(fail_at, di
             assert not out[0][kind]["ok"] and "models differ" in out[0][kind]["why"]
         else:
             assert not out[0][kind]["ok"] and f"rank {fail_at[0]}" in out[0][kind]["why"] and fail_at[1].split()[0] in out[0][kind]["why"]
+
+
+def test_choose_headline_takes_the_faster_region_only_when_the_in_kernel_one_is_sound():
+    args = types.SimpleNamespace(steps=10, headline_collective="auto")
+    peer_ok = {"ms_per_step_peer_allreduce": 0.12, "peer_allreduce": {"kernel_us": 118.0, "dt_s": 0.0012, "model_sha": "aa"}}
+    # faster and on the collective's model: the in-kernel region is the headline, the collective's timing stays beside it
+    ex = dict(peer_ok)
+    dt, kms, n, kind = bench.choose_headline(args, ex, 0.0015, 1.4, 10, "rccl (...)", "aa")
+    assert ex["headline_collective"] == "peer" and dt == 0.0012 and abs(kms - 1.18) < 1e-9 and n == 10 and "in-kernel" in kind and "rccl (...)" in kind
+    assert ex["ms_per_step_rccl"] == pytest.approx(0.15)
+    # slower: the collective's region stays
+    ex = dict(peer_ok, ms_per_step_peer_allreduce=0.2)
+    assert bench.choose_headline(args, ex, 0.0015, 1.4, 10, "rccl (...)", "aa")[0] == 0.0015 and ex["headline_collective"] == "rccl"
+    # another model than the collective's: never, and the line says why
+    ex = dict(peer_ok)
+    assert bench.choose_headline(args, ex, 0.0015, 1.4, 10, "rccl (...)", "bb")[0] == 0.0015
+    assert ex["headline_collective"] == "rccl" and "another model" in ex["ms_per_step_peer_allreduce"]
+    # unavailable, or switched off
+    ex = {"ms_per_step_peer_allreduce": "unavailable: x"}
+    assert bench.choose_headline(args, ex, 0.0015, 1.4, 10, "k", "aa") == (0.0015, 1.4, 10, "k") and ex["headline_collective"] == "rccl"
+    ex = dict(peer_ok)
+    assert bench.choose_headline(types.SimpleNamespace(steps=10, headline_collective="rccl"), ex, 0.0015, 1.4, 10, "k", "aa")[0] == 0.0015
+    ex = dict(peer_ok, ms_per_step_peer_allreduce=0.2)
+    assert bench.choose_headline(types.SimpleNamespace(steps=10, headline_collective="peer"), ex, 0.0015, 1.4, 10, "k", "aa")[0] == 0.0012

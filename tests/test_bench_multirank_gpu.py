@@ -90,6 +90,10 @@ def test_two_processes_under_the_launcher_with_the_library_communicator():
     assert a["kernel_us"] > 0 and a["allreduce_us"] > 0 and a["step_us"] >= a["kernel_us"]
     assert isinstance(j["ms_per_step_peer_allreduce"], float), j["ms_per_step_peer_allreduce"]
     assert len(j["peer_allreduce"]["model_sha"]) == 16
+    # two identical timed regions, one per way of summing over the ranks: the line's value comes from the faster one (both sound)
+    assert isinstance(j["ms_per_step_rccl"], float) and j["headline_collective"] in ("rccl", "peer")
+    assert j["ms_per_step"] == pytest.approx(min(j["ms_per_step_rccl"], j["ms_per_step_peer_allreduce"]), rel=1e-9)
+    assert ("in-kernel all-reduce" in j["allreduce"]) == (j["headline_collective"] == "peer")
     # the first-contact kit: the communicator self-test ran in front of the timed region (both ways of summing over the
     # ranks end on one model), and the line says where the ranks' devices sit and who reaches whom
     st = j["selftest_comm"]
