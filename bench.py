@@ -634,6 +634,10 @@ def from_seed_extras(bm, ctx, seqs, wl, args, sync):
     n_cold = 20
     W, K = wl["W"], wl["K"]
     out = {}
+    # (set-sized scratch -- 10 GB per handle at config 4 -- is allocated on a handle's first pass and goes back to the context's
+    # pool when the handle closes: a throw-away handle takes that allocation, which `first_call_ms` prices, out of the pass times)
+    e1 = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=n_cold, n_seqs_bound=args.nseq)
+    e1.iterate(1); sync(); e1.close()
     e2 = bm.EM(ctx, seqs, K, W, wl["vbg"], wl["A"], wl["v0"], wl["q"], bg_order=2, max_iterations=n_cold, n_seqs_bound=args.nseq)
     sync()
     t1 = time.perf_counter(); e2.iterate(n_cold); sync()
