@@ -423,6 +423,10 @@ struct bamm_em {
     bool peer_on = false;                       // agreed with every rank in verify_comm()
     bool pass_summed_in_kernel = false;         // the pass just enqueued carried the tail (launch_fused): run_allreduce has nothing to add
     uint32_t* d_peer_words = nullptr;           // [0] ticket, [1] err
+    long long* d_comm_words = nullptr;          // four words for verify_comm()'s own sums, kept for the handle's life: a hipFree
+                                                // there would synchronise the DEVICE, and with several ranks on one device (the
+                                                // rehearsal forms) a peer that has already launched its first pass spins in that
+                                                // kernel's tail for THIS rank's sums, which this rank cannot launch from inside hipFree
     std::string peer_note;                      // why peer_on is false although asked for
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     uint32_t events_used = 0;
@@ -1008,16 +1012,15 @@ int verify_comm(bamm_em* em) {
     if (world > 1) {
         long long h[4] = {(long long)em->seqs->n, (long long)em->fix_shift, (long long)em->fix_shift * (long long)em->fix_shift,
                           em->ctx->use_peer_allreduce ? 1 : 0};
-        long long* d = nullptr;
         int rc = use_device(em->ctx);
-        if (!rc) rc = dev_alloc(&d, 4);
+        if (!rc && !em->d_comm_words) rc = dev_alloc(&em->d_comm_words, 4);
         if (rc) return rc;
+        long long* const d = em->d_comm_words;
         hipStream_t st = em->ctx->stream;
         hipError_t e = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) rc = comm_allreduce_i64(em->comm, d, 4, st);
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
-        (void)hipFree(d);
         if (rc) return rc;
         if (e != hipSuccess) { set_error("accumulator-unit check over the communicator: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
         want_peer = h[3];
@@ -1051,14 +1054,13 @@ int verify_comm(bamm_em* em) {
         int rc = comm_peer_setup(em->comm, kStride, &ready);
         if (rc) return rc;
         long long vote[1] = {(ready && can) ? 1 : 0};
-        long long* d = nullptr;
-        if ((rc = use_device(em->ctx)) || (rc = dev_alloc(&d, 1))) return rc;
+        if ((rc = use_device(em->ctx))) return rc;
+        long long* const d = em->d_comm_words;               // (allocated above: world > 1)
         hipStream_t st = em->ctx->stream;
         hipError_t e = hipMemcpyAsync(d, vote, sizeof vote, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) rc = comm_allreduce_i64(em->comm, d, 1, st);
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(vote, d, sizeof vote, hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && !rc) e = hipStreamSynchronize(st);
-        (void)hipFree(d);
         if (rc) return rc;
         if (e != hipSuccess) { set_error("in-kernel all-reduce vote: %s", hipGetErrorString(e)); return BAMM_ERR_HIP; }
         if (vote[0] == (long long)world) {
@@ -1642,6 +1644,7 @@ int bamm_em_destroy(bamm_em* em) {
     if (em->h_status) (void)hipHostFree(em->h_status);
     (void)hipFree(em->d_stop);
     (void)hipFree(em->d_peer_words);
+    (void)hipFree(em->d_comm_words);
     for (hipEvent_t e : em->opt_events) if (e) (void)hipEventDestroy(e);
     for (auto& ev : em->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     bamm_seqs_destroy(em->seqs);
