@@ -152,6 +152,12 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
     const uint32_t vbase5 = R5V0 + wave * kMixBv, vbase6 = R6V0 + wave * kMixBv;
     const uint32_t sg5_base = lds_offset(sg5), sg6_base = lds_offset(sg6);
 
+    // per lane, fixed for the launch: bit 6 (the value Y) of every 7-bit field of `yfix` whose column has a resident bin -- OR-ed
+    // into the sequence's codes it marks those columns "nothing to log" in one instruction
+    uint32_t resident_fill = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (lane_col0 + (uint32_t)c < n1c) resident_fill |= Y << (7 * c);
     double llh_acc = 0.0, sumr_acc = 0.0;
     uint32_t seq_cnt = 0, last_LW1 = 0;
     float pos_i = 0.0f;
@@ -412,19 +418,18 @@ __global__ void __launch_bounds__(THREADS) k_em_mix(GrpKernelArgs ga) {
             }
             // code: group (3 bits), then the y of its up to four columns (7 bits each, >= Y = nothing to log: neutral,
             // beyond the edge, or a resident bin, which takes the sum here)
-            uint32_t code = lane_t;
-            bool any = false;
+            // (fields of columns beyond the lane's group hold Y already: yfix is built that way)
+            if (acc != 0ull) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                uint32_t yc = ((uint32_t)c < lane_G) ? ((yfix >> (7 * c)) & 0x7fu) : Y;
-                if (yc != Y && lane_col0 + (uint32_t)c < n1c) {               // a resident bin: added here, not logged
-                    if (acc != 0ull) atomicAdd(&n1p[(lane_col0 + (uint32_t)c) * Y + yc], acc);
-                    yc = Y;
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t yc = (yfix >> (7 * c)) & 0x7fu;
+                    if (yc < Y && ((resident_fill >> (7 * c + 6)) & 1u) != 0u)   // a resident bin: added here, not logged
+                        atomicAdd(&n1p[(lane_col0 + (uint32_t)c) * Y + yc], acc);
                 }
-                any = any || yc != Y;
-                code |= yc << (3 + 7 * c);
             }
-            if (!any) acc = 0ull;                                // nothing left to log (also: a group wholly beyond the edge)
+            const uint32_t ylog = yfix | resident_fill;          // what is left to log: fields still below Y
+            const uint32_t code = lane_t | (ylog << 3);
+            if ((~ylog & (Y | (Y << 7) | (Y << 14) | (Y << 21))) == 0u) acc = 0ull;   // nothing left to log (also: a group wholly beyond the edge)
             const unsigned long long nzm = __ballot(acc != 0ull);
             if (acc != 0ull) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzm, 0u));
